@@ -1,0 +1,64 @@
+"""Shared replay harness: drive any env exposing the PettingZooEnv-level surface through a golden
+trace (tests/golden/env_trace_*.npz, produced by the real reference) and compare every output."""
+import numpy as np
+
+LOGGER_KEYS = ("total_messages_transmitted", "coverage", "messages_sent", "messages_received",
+               "n_neighbours", "interested_agents", "coverage_interested_fraction",
+               "coverage_interested_count", "uninterested_with_message", "episode_rewards_sum")
+
+
+def check_row(tr, r, obs, rew, term, trunc, info, state=None):
+    ctx = f"row {r}"
+    assert int(obs["agent_id"]) == int(tr["agent_id"][r]), ctx
+    np.testing.assert_array_equal(np.asarray(obs["obs"], dtype=np.float32), tr["obs"][r], err_msg=ctx)
+    np.testing.assert_array_equal(np.asarray(obs["mask"], dtype=bool), tr["mask"][r], err_msg=ctx)
+    # rewards: float64, same operation order as graph.py:402-463 -> exact
+    np.testing.assert_array_equal(np.asarray(rew, dtype=np.float64), tr["rew"][r], err_msg=ctx)
+    assert bool(term) == bool(tr["term"][r]), ctx
+    assert bool(trunc) == bool(tr["trunc"][r]), ctx
+    assert int(info["env_step"]) == int(tr["env_step"][r]), ctx
+    assert bool(info["environment_step"]) == bool(tr["environment_step"][r]), ctx
+    assert bool(info["explicit_reset"]) == bool(tr["explicit_reset"][r]), ctx
+    np.testing.assert_array_equal(np.asarray(info["active_one_hop_neighbors"], dtype=bool),
+                                  tr["active_nb"][r], err_msg=ctx)
+    stats = info.get("logger_stats")
+    assert (stats is not None) == bool(tr["has_stats"][r]), ctx
+    if stats is not None:
+        got = np.array([float(stats[k]) for k in LOGGER_KEYS])
+        np.testing.assert_array_equal(got, tr["stats"][r], err_msg=ctx)
+    if state is not None:
+        for key in ("agents_mask", "alive_mask", "terminated_mask", "has_message_mask",
+                    "interested_mask"):
+            assert int(state[key]) == int(tr[key][r]), f"{ctx} {key}"
+        assert int(state["origin"]) == int(tr["origin"][r]), ctx
+        np.testing.assert_array_equal(np.asarray(state["pos"], dtype=np.float64), tr["pos"][r], err_msg=ctx)
+        np.testing.assert_array_equal(np.asarray(state["one_hop"], dtype=np.uint64), tr["one_hop"][r], err_msg=ctx)
+        np.testing.assert_array_equal(np.asarray(state["two_hop"], dtype=np.uint64), tr["two_hop"][r], err_msg=ctx)
+
+
+def replay(tr, pz, state_fn=None):
+    """pz: object with reset() -> (obs, info) and step(a) -> (obs, rew, term, trunc, info) and a
+    sticky ``rewards`` list (tianshou PettingZooEnv surface).  Returns number of rows checked."""
+    n = int(tr["n"])
+    tape = tr["tape"]
+    r = 0
+    obs, info = pz.reset()
+    check_row(tr, r, obs, pz.rewards, False if not tr["term"][r] else True, False, info,
+              state_fn() if state_fn else None)
+    r += 1
+    done_count = 0
+    for t in range(len(tape)):
+        obs, rew, term, trunc, info = pz.step(int(tape[t]))
+        check_row(tr, r, obs, rew, term, trunc, info, state_fn() if state_fn else None)
+        r += 1
+        if term or trunc:
+            done_count += 1
+            if done_count == n or info.get("explicit_reset", False):
+                obs, info = pz.reset()
+                assert bool(tr["was_reset"][r])
+                check_row(tr, r, obs, pz.rewards, bool(tr["term"][r]), False, info,
+                          state_fn() if state_fn else None)
+                r += 1
+                done_count = 0
+    assert r == len(tr["agent_id"])
+    return r
