@@ -1,0 +1,246 @@
+/*
+ * melissa_hip.h - C ABI of libmelissa_hip.so: the MI355X (gfx950) hot path of Melissa.
+ *
+ * The drop-in boundary.  Every pointer marked "device" is a DEVICE pointer
+ * borrowed from the caller (e.g. torch.Tensor.data_ptr() of a ROCm tensor); the library never
+ * allocates, frees or retains caller memory, keeps no global mutable state except a thread-local
+ * error string, launches everything on the caller's HIP stream and never synchronises.  `stream`
+ * is a hipStream_t passed as void* so this header needs no HIP include.
+ *
+ * Every entry point returns mel_status (0 = ok, negative = error, see mel_last_error()).
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   mel_ldgn_forward   -> LDGNNetwork.forward        graph_env/env/utils/networks/l_dgn.py:92-151
+ *   mel_hldgn_forward  -> HLDGNNetwork.forward       graph_env/env/utils/networks/hl_dgn.py:82-119
+ *                         (both include build_pyg_batch_time, networks/common.py:6-64, and the
+ *                          [3P] radius_graph / GATv2Conv / global_*_pool / tianshou MLP they call)
+ *   mel_select_action  -> [3P] tianshou DQNPolicy.forward mask + argmax and exploration_noise,
+ *                         called at policies/multi_agent_managers/shared_policy.py:81-91,154
+ *   mel_env_reset      -> GraphEnv.reset + World.reset      graph.py:222-248, core.py:343-437
+ *   mel_env_step       -> GraphEnv.step (+ World.step ...)  graph.py:303-389,402-463, core.py:225-341,
+ *                         selector.py:25-48
+ *   mel_env_observe    -> GraphEnv.observe / last() + [3P] PettingZooEnv.step packing
+ *                         graph.py:181-216, SURVEY.md Appendix A.6
+ */
+#ifndef MELISSA_HIP_H
+#define MELISSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t mel_status;
+#define MEL_OK                 0
+#define MEL_ERR_INVALID_ARG   -1   /* null pointer, bad size, N outside [1, 64] ...              */
+#define MEL_ERR_SHAPE         -2   /* obs width != N*(in_dim+3)+1 (networks/common.py:24-29)      */
+#define MEL_ERR_UNSUPPORTED   -3   /* layer sizes the kernels are not built for                  */
+#define MEL_ERR_WORKSPACE     -4   /* ws_bytes < mel_workspace_bytes(...)                        */
+#define MEL_ERR_LAUNCH        -5   /* hipGetLastError() != hipSuccess after a launch             */
+
+#define MEL_MAX_NODES         64   /* node sets are 64-bit masks, one wavefront lane per node    */
+#define MEL_NODE_COLS          8   /* x, y, 5 features, dm flag (graph.py:80)                    */
+#define MEL_MAX_HEAD_LAYERS    6
+
+#define MEL_MODEL_LDGN         0
+#define MEL_MODEL_HLDGN        1
+
+#define MEL_AGG_MAX            0   /* hl_dgn.py:56-60 */
+#define MEL_AGG_MEAN           1
+#define MEL_AGG_ADD            2
+
+/* One torch.nn.Linear: weight [out_dim, in_dim] row-major fp32, bias [out_dim] fp32 (device). */
+typedef struct mel_linear {
+    const float* weight;
+    const float* bias;
+    int32_t in_dim;
+    int32_t out_dim;
+} mel_linear;
+
+/* [3P] PyG GATv2Conv parameters: lin_l / lin_r [heads*C, in], att [1, heads, C],
+ * bias [heads*C]; negative_slope 0.2, self-loops added, softmax eps 1e-16. */
+typedef struct mel_gatv2 {
+    mel_linear lin_l;
+    mel_linear lin_r;
+    const float* att;
+    const float* bias;
+    int32_t heads;
+    int32_t channels;      /* C, per head */
+} mel_gatv2;
+
+/* [3P] tianshou MLP: Linear, ReLU, ..., Linear (no activation after the last layer). */
+typedef struct mel_mlp {
+    mel_linear layer[MEL_MAX_HEAD_LAYERS];
+    int32_t n_layers;
+} mel_mlp;
+
+/* Borrowed views of the nn.Parameter storages of LDGNNetwork / HLDGNNetwork (state_dict keys
+ * encoder.model.{0,2}.*, conv1.*, conv2.* (L-DGN only), Q.model.*, V.model.*; l_dgn.py:49-86). */
+typedef struct mel_weights {
+    int32_t model;         /* MEL_MODEL_*                                            */
+    int32_t in_dim;        /* node features fed to the encoder (5)                   */
+    int32_t n_actions;     /* Q head output (2)                                      */
+    int32_t dueling;       /* 1: Q/V dueling heads; 0: q_head is the single out_linear (l_dgn.py:88) */
+    mel_mlp   encoder;     /* 2 layers: in_dim -> hidden -> hidden                   */
+    mel_gatv2 conv1;
+    mel_gatv2 conv2;       /* unused for HL-DGN                                      */
+    mel_mlp   q_head;      /* latent -> ... -> n_actions                             */
+    mel_mlp   v_head;      /* latent -> ... -> 1                                     */
+} mel_weights;
+
+/* Bytes of scratch the forward needs for `bs` observation rows of `n_nodes`-node graphs. */
+size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes);
+
+/* obs: device fp32 [bs, obs_width] row-major, obs_width must equal n_nodes*(in_dim+3)+1;
+ * logits: device fp32 [bs, n_actions].  L-DGN evaluates exactly the receptive field of the
+ * controlling agent (rows of conv1/conv2 that can reach logits), which yields the same logits as the
+ * full-graph evaluation of l_dgn.py:117-135. */
+mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
+                            int32_t obs_width, float* logits, void* workspace, size_t ws_bytes,
+                            void* stream);
+
+mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs,
+                             int32_t n_nodes, int32_t obs_width, float* logits, void* workspace,
+                             size_t ws_bytes, void* stream);
+
+/* Debug/parity taps: copies of intermediates after a forward with the same workspace.
+ * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
+ *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108).
+ * `out` is a device pointer with room for the requested tensor. */
+mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n_nodes,
+                           const void* workspace, void* out, void* stream);
+
+/* [3P] DQNPolicy.forward + exploration_noise:
+ *   q = logits + (1 - mask) * (min(logits) - max(logits) - 1)   (batch-wide min / max)
+ *   act = argmax(q);  if rand_u[b] < eps: act = argmax(rand_q[b, :] + mask)
+ * mask: device uint8 [bs, n_actions] or NULL; rand_u [bs], rand_q [bs, n_actions] device fp32 or NULL
+ * (eps-greedy off).  act: device int32 [bs].  scratch: device, >= 8 bytes. */
+mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t bs, int32_t n_actions,
+                             float eps, const float* rand_u, const float* rand_q, int32_t* act,
+                             void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Environment half.  State of B independent envs lives in caller-owned device memory laid out as
+ * struct-of-arrays (one wavefront steps one env, lane = node, node sets = 64-bit masks);
+ * mel_env_state_bytes() gives the size, mel_env_bind() carves the pointer table.
+ * ------------------------------------------------------------------------------------------------ */
+#define MEL_ENV_LOGGER_STATS  10   /* graph.py:167-177, in dict order                            */
+
+/* node_sets[b][k] */
+#define MEL_SET_HAS_MESSAGE    0   /* State.has_message                        core.py:18        */
+#define MEL_SET_ORIGIN         1   /* State.message_origin                     core.py:16        */
+#define MEL_SET_INTERESTED     2   /* Agent.is_interested                      core.py:71        */
+#define MEL_SET_SCRIPTED       3   /* Agent.is_scripted (always 0: out of scope)                 */
+#define MEL_SET_TRUNCATED      4   /* Agent.truncated                          graph.py:333      */
+#define MEL_SET_ALIVE          5   /* keys of GraphEnv.terminations            graph.py:282-286  */
+#define MEL_SET_TERMINATED     6   /* terminations[a] == True                  graph.py:334      */
+#define MEL_SET_AGENTS         7   /* GraphEnv.agents (always id-ordered)      graph.py:336-341  */
+/* sel_sets[b][k] */
+#define MEL_SEL_ACTIVE         0   /* CustomSelector active                    selector.py:43-44 */
+#define MEL_SEL_SELECTED       1   /* CustomSelector selected_round            selector.py:30    */
+#define MEL_SEL_INFO_VALID     2   /* infos[a] holds logger_stats              graph.py:358      */
+#define MEL_SEL_TAKEN_ACTION   3   /* State.has_taken_action                   core.py:272       */
+/* scalars[b][k] */
+#define MEL_S_ORIGIN           0   /* World.origin_agent                                         */
+#define MEL_S_SELECTION        1   /* GraphEnv.agent_selection (-1 = False)                      */
+#define MEL_S_SKIP             2   /* _skip_agent_selection (-2 = None, -1 = False)              */
+#define MEL_S_NUM_MOVES        3   /* GraphEnv.num_moves                                         */
+#define MEL_S_WORLD_MSGS       4   /* World.messages_transmitted                                 */
+#define MEL_S_NEW_ROUND        5   /* GraphEnv.is_new_round (-1 = None, 0, 1)                    */
+#define MEL_S_EPISODE          6   /* pool episode currently loaded                              */
+#define MEL_S_MOVE_CURSOR      7   /* movement draws consumed this episode                       */
+#define MEL_S_DECISIONS        8   /* live (non-dead) agent decisions since bind                 */
+#define MEL_S_DONE_COUNT       9   /* done observations this episode (multi_agent_collector.py:261-263) */
+#define MEL_S_EPISODES_DONE   10   /* episodes finished (auto-reset mode)                        */
+#define MEL_S_ERROR           11   /* bit 0: ran out of stored movement offsets                  */
+#define MEL_S_EP_CURSOR       12   /* episodes started (indexes the auto-reset episode table)    */
+#define MEL_ENV_SCALARS       16
+
+typedef struct mel_env_batch {
+    int32_t n_envs;
+    int32_t n_nodes;
+    int32_t dynamic_graph;     /* core.py:256                                                    */
+    int32_t has_local_ratio;   /* graph.py:376,380                                               */
+    double  local_ratio;
+    double*   pos;             /* [B, N, 2] float64 positions (graph node attr "pos")            */
+    uint64_t* one_hop;         /* [B, N]    Agent.one_hop_neighbours_ids as bit masks            */
+    uint64_t* two_hop;         /* [B, N]    Agent.two_hop_neighbours_ids                         */
+    uint64_t* node_sets;       /* [B, 8]    MEL_SET_*                                            */
+    uint64_t* sel_sets;        /* [B, 4]    MEL_SEL_*                                            */
+    int32_t*  scalars;         /* [B, 16]   MEL_S_*                                              */
+    int32_t*  agent_msgs;      /* [B, N]    Agent.messages_transmitted                           */
+    int32_t*  received;        /* [B, N]    sum(State.received_from)                             */
+    int32_t*  two_hop_cover;   /* [B, N]    Agent.two_hop_cover                                  */
+    int8_t*   agent_action;    /* [B, N]    Agent.action (-1 = None)                             */
+    int8_t*   current_actions; /* [B, N]    GraphEnv.current_actions (-1 = None)                 */
+    int8_t*   steps_taken;     /* [B, N]    Agent.steps_taken                                    */
+    int8_t*   sel_steps;       /* [B, N]    CustomSelector steps                                 */
+    double*   rewards;         /* [B, N]    GraphEnv.rewards                                     */
+    double*   pz_rewards;      /* [B, N]    [3P] PettingZooEnv.rewards (sticky)   */
+    double*   episode_rewards; /* [B]       GraphEnv.episode_rewards_sum                         */
+    float*    obs_matrix;      /* [B, N, 8] GraphEnv.obs_matrix                                  */
+    double*   info_stats;      /* [B, N, 10] infos[agent]['logger_stats']                        */
+} mel_env_batch;
+
+/* An episode pool: what World.reset samples (core.py:372-394), pre-drawn on the host with the
+ * reference's RNG calls and packed for the device (device pointers). */
+typedef struct mel_episode_pool {
+    int32_t n_episodes;
+    int32_t n_nodes;
+    int32_t max_moves;         /* movement offsets stored per episode                            */
+    int32_t reserved;
+    const double*   pos;       /* [E, N, 2] initial positions                                    */
+    const uint64_t* one_hop;   /* [E, N]    initial adjacency (graph edges)                      */
+    const uint64_t* interested;/* [E]                                                            */
+    const int32_t*  origin;    /* [E]                                                            */
+    const double*   moves;     /* [E, max_moves, 2, N] 0.06*U(-1,1): all x then all y (core.py:316-319) */
+} mel_episode_pool;
+
+/* Outputs of last() + [3P] PettingZooEnv packing, one row per listed env (device; any may be NULL). */
+typedef struct mel_env_obs {
+    float*    obs;             /* [n, 8N+1] obs_matrix flattened + controlling index (graph.py:186-188) */
+    int64_t   obs_stride;      /* floats between rows (>= 8N+1)                                  */
+    int32_t*  agent_id;        /* [n]                                                            */
+    uint8_t*  action_mask;     /* [n, 2]    graph.py:190-192                                     */
+    double*   rew;             /* [n, N]    sticky reward vector                                 */
+    uint8_t*  terminated;      /* [n]                                                            */
+    int32_t*  flags;           /* [n, 4]    env_step, environment_step, explicit_reset, has_stats */
+    uint64_t* active_nb;       /* [n]       info['active_one_hop_neighbors'] (graph.py:198-203)  */
+    double*   stats;           /* [n, 10]   info['logger_stats']                                 */
+} mel_env_obs;
+
+size_t mel_env_state_bytes(int32_t n_envs, int32_t n_nodes);
+/* Carves `state` (device, mel_env_state_bytes() bytes, 256-byte aligned) into the pointer table. */
+mel_status mel_env_bind(mel_env_batch* env, int32_t n_envs, int32_t n_nodes, void* state);
+
+/* GraphEnv.reset for the envs listed in env_ids (device int32 [n], or NULL = envs 0..n-1): loads pool
+ * episode episode_ids[k] (device int32 [n]), runs the forced source transmission (core.py:246,437)
+ * and, if `out` is not NULL, observes.  keep_graph != 0 keeps the env's current positions/edges
+ * (the reference's fixed-graph mode mutates one graph across episodes, core.py:130,303-314). */
+mel_status mel_env_reset(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* env_ids,
+                         const int32_t* episode_ids, int64_t n, int32_t keep_graph,
+                         const mel_env_obs* out, void* stream);
+
+/* One AEC step per listed env (GraphEnv.step; action ignored when the selected agent is dead), the
+ * sticky reward copy of PettingZooEnv.step, then - if `out` is not NULL - last().
+ * actions: device int32 [n].  If episode_table is not NULL (device int32 [B, table_stride]) an env
+ * whose observation says the episode is over (terminated and (explicit_reset or N agents reported
+ * done), multi_agent_collector.py:261-264) is reset in the same launch to pool episode
+ * episode_table[b, ep_cursor % table_stride] and observed again. */
+mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
+                        const int32_t* env_ids, int64_t n, const mel_env_obs* out,
+                        const int32_t* episode_table, int32_t table_stride, void* stream);
+
+/* last() only (mutates is_new_round exactly like GraphEnv.observe, graph.py:205-211). */
+mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n,
+                           const mel_env_obs* out, void* stream);
+
+const char* mel_last_error(void);
+const char* mel_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELISSA_HIP_H */

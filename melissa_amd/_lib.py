@@ -1,0 +1,135 @@
+"""ctypes binding of libmelissa_hip.so (include/melissa_hip.h).  There is no CPU fallback: if the
+library is missing the product path raises, loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_HEAD_LAYERS = 6
+MODEL_LDGN, MODEL_HLDGN = 0, 1
+AGG = {"max": 0, "mean": 1, "add": 2}
+OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = 0, -1, -2, -3, -4, -5
+ENV_SCALARS, ENV_LOGGER_STATS = 16, 10
+# scalars[b][k] / node_sets[b][k] / sel_sets[b][k] indices (melissa_hip.h MEL_S_* / MEL_SET_* / MEL_SEL_*)
+S_ORIGIN, S_SELECTION, S_SKIP, S_NUM_MOVES, S_WORLD_MSGS, S_NEW_ROUND, S_EPISODE, S_MOVE_CURSOR, \
+    S_DECISIONS, S_DONE_COUNT, S_EPISODES_DONE, S_ERROR, S_EP_CURSOR = range(13)
+SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_ALIVE, SET_TERMINATED, \
+    SET_AGENTS = range(8)
+
+# every symbol include/melissa_hip.h declares
+EXPORTS = ("mel_workspace_bytes", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
+           "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
+           "mel_env_observe", "mel_last_error", "mel_version")
+
+
+class MelLinear(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class MelGatv2(C.Structure):
+    _fields_ = [("lin_l", MelLinear), ("lin_r", MelLinear), ("att", C.c_void_p), ("bias", C.c_void_p),
+                ("heads", C.c_int32), ("channels", C.c_int32)]
+
+
+class MelMlp(C.Structure):
+    _fields_ = [("layer", MelLinear * MAX_HEAD_LAYERS), ("n_layers", C.c_int32)]
+
+
+class MelWeights(C.Structure):
+    _fields_ = [("model", C.c_int32), ("in_dim", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32),
+                ("encoder", MelMlp), ("conv1", MelGatv2), ("conv2", MelGatv2), ("q_head", MelMlp),
+                ("v_head", MelMlp)]
+
+
+class MelEnvBatch(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("n_nodes", C.c_int32), ("dynamic_graph", C.c_int32),
+                ("has_local_ratio", C.c_int32), ("local_ratio", C.c_double),
+                ("pos", C.c_void_p), ("one_hop", C.c_void_p), ("two_hop", C.c_void_p),
+                ("node_sets", C.c_void_p), ("sel_sets", C.c_void_p), ("scalars", C.c_void_p),
+                ("agent_msgs", C.c_void_p), ("received", C.c_void_p), ("two_hop_cover", C.c_void_p),
+                ("agent_action", C.c_void_p), ("current_actions", C.c_void_p), ("steps_taken", C.c_void_p),
+                ("sel_steps", C.c_void_p), ("rewards", C.c_void_p), ("pz_rewards", C.c_void_p),
+                ("episode_rewards", C.c_void_p), ("obs_matrix", C.c_void_p), ("info_stats", C.c_void_p)]
+
+
+class MelEpisodePool(C.Structure):
+    _fields_ = [("n_episodes", C.c_int32), ("n_nodes", C.c_int32), ("max_moves", C.c_int32),
+                ("reserved", C.c_int32), ("pos", C.c_void_p), ("one_hop", C.c_void_p),
+                ("interested", C.c_void_p), ("origin", C.c_void_p), ("moves", C.c_void_p)]
+
+
+class MelEnvObs(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("obs_stride", C.c_int64), ("agent_id", C.c_void_p),
+                ("action_mask", C.c_void_p), ("rew", C.c_void_p), ("terminated", C.c_void_p),
+                ("flags", C.c_void_p), ("active_nb", C.c_void_p), ("stats", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load the shared library (building it in-tree with hipcc if absent/stale and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and _build.is_stale():
+        try:
+            _build.build_library()
+        except Exception as e:  # keep a usable prebuilt .so if the toolchain is missing
+            if not os.path.exists(path):
+                raise RuntimeError(f"libmelissa_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: the HIP hot path is not built (run python -m melissa_amd.build)")
+    lib = C.CDLL(path)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    W, E, P, O = C.POINTER(MelWeights), C.POINTER(MelEnvBatch), C.POINTER(MelEpisodePool), C.POINTER(MelEnvObs)
+    lib.mel_last_error.restype = C.c_char_p
+    lib.mel_version.restype = C.c_char_p
+    lib.mel_workspace_bytes.restype = sz
+    lib.mel_workspace_bytes.argtypes = [W, i64, i32]
+    lib.mel_ldgn_forward.restype = i32
+    lib.mel_ldgn_forward.argtypes = [W, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_hldgn_forward.restype = i32
+    lib.mel_hldgn_forward.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_forward_tap.restype = i32
+    lib.mel_forward_tap.argtypes = [W, i32, i64, i32, vp, vp, vp]
+    lib.mel_select_action.restype = i32
+    lib.mel_select_action.argtypes = [vp, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
+    lib.mel_env_state_bytes.restype = sz
+    lib.mel_env_state_bytes.argtypes = [i32, i32]
+    lib.mel_env_bind.restype = i32
+    lib.mel_env_bind.argtypes = [E, i32, i32, vp]
+    lib.mel_env_reset.restype = i32
+    lib.mel_env_reset.argtypes = [E, P, vp, vp, i64, i32, O, vp]
+    lib.mel_env_step.restype = i32
+    lib.mel_env_step.argtypes = [E, P, vp, vp, i64, O, vp, i32, vp]
+    lib.mel_env_observe.restype = i32
+    lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().mel_last_error().decode()
+
+
+def check(status: int, what: str = ""):
+    """C status -> Python exception; shape errors are ValueError like networks/common.py:20-29."""
+    if status == OK:
+        return
+    msg = last_error()
+    if status == ERR_SHAPE:
+        raise ValueError(msg)
+    raise RuntimeError(f"{what or 'libmelissa_hip'} failed ({status}): {msg}")
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+    return int(torch.cuda.current_stream(device).cuda_stream)

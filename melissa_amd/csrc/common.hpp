@@ -1,0 +1,72 @@
+// Shared host/device helpers for libmelissa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/melissa_hip.h"
+
+namespace mel {
+
+void set_error(const char* fmt, ...);
+
+inline mel_status fail(mel_status code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline mel_status fail(mel_status code, const char* fmt, ...) {
+    char buf[480];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    set_error("%s", buf);
+    return code;
+}
+
+inline mel_status check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MEL_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MEL_OK;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller-provided workspace (256-byte granules).
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += align_up(count * sizeof(T), 256);
+        return p;
+    }
+};
+
+// ---- device helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// number of set bits of m strictly below bit i: the position of node i in a mask-ordered row list
+__device__ __forceinline__ int rank_below(uint64_t m, int i) {
+    return __popcll(m & ((1ull << i) - 1ull));
+}
+
+__device__ __forceinline__ int lowest_bit(uint64_t m) { return __ffsll((long long)m) - 1; }
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    uint32_t lo = __shfl((uint32_t)v, src, 64);
+    uint32_t hi = __shfl((uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, o, 64);
+        uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+        v |= ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+}  // namespace mel

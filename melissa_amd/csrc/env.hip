@@ -1,0 +1,551 @@
+// Batched message-dissemination environment for MI355X (gfx950).
+//
+// One wavefront steps one env; lane i is node/agent i (N <= 64); every node set is one 64-bit mask
+// held wave-uniformly, so the reference's Python list/dict walks become popcounts, ballots and a
+// handful of cross-lane reads.  Integer state is bit-exact with the reference; float64 arithmetic
+// (positions, rewards, logger stats) is written operation-for-operation like the Python expressions
+// and the library is built with -ffp-contract=off, so it is bit-exact too.
+//
+// Reference semantics (paths relative to the reference repo):
+//   GraphEnv.step / _execute_world_step / reward / observe / get_info   graph_env/env/graph.py:149-463
+//   World.step / relay_message / move_graph / update_*_hop / reset       graph_env/env/utils/core.py:225-437
+//   CustomSelector                                                       graph_env/env/utils/selector.py
+//   [3P] AECEnv._deads_step_first / _was_dead_step, tianshou PettingZooEnv.step
+// Scripted (heuristic) agents are out of scope: the scripted set is always empty.
+#include "common.hpp"
+
+namespace mel {
+
+constexpr int NONE = -1;        // Python None action / False agent selection
+constexpr int SKIP_NONE = -2;   // _skip_agent_selection is None
+constexpr int MAX_AGENT_STEPS = 4;          // graph.py:332, selector.py:44
+constexpr double R2_F64 = 0.04000000000000001;   // 0.2 ** 2 (nx.geometric_edges, core.py:311)
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    uint32_t lo = __shfl((uint32_t)u, src, 64), hi = __shfl((uint32_t)(u >> 32), src, 64);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t bit(int i) { return 1ull << i; }
+
+// Wave-uniform working copy of one env's masks/scalars + this lane's per-node values.
+struct Env {
+    // uniform
+    uint64_t has_msg, origin_set, interested, scripted, truncated, alive, terminated, agents;
+    uint64_t sel_active, sel_selected, info_valid, taken_action;
+    int origin, sel, skip, num_moves, world_msgs, new_round, episode, move_cursor, decisions, done_count,
+        episodes_done, error, ep_cursor;
+    double episode_rewards;
+    // per lane (node)
+    double px, py, reward, pz_reward;
+    uint64_t one_hop, two_hop;
+    int msgs, received, cover;
+    int act, cur_act, steps, sel_steps;
+};
+
+__device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane, Env& s) {
+    const int n = e.n_nodes;
+    const uint64_t* ns = e.node_sets + (size_t)b * 8;
+    s.has_msg = ns[0], s.origin_set = ns[1], s.interested = ns[2], s.scripted = ns[3];
+    s.truncated = ns[4], s.alive = ns[5], s.terminated = ns[6], s.agents = ns[7];
+    const uint64_t* ss = e.sel_sets + (size_t)b * 4;
+    s.sel_active = ss[0], s.sel_selected = ss[1], s.info_valid = ss[2], s.taken_action = ss[3];
+    const int32_t* sc = e.scalars + (size_t)b * MEL_ENV_SCALARS;
+    s.origin = sc[MEL_S_ORIGIN], s.sel = sc[MEL_S_SELECTION], s.skip = sc[MEL_S_SKIP];
+    s.num_moves = sc[MEL_S_NUM_MOVES], s.world_msgs = sc[MEL_S_WORLD_MSGS], s.new_round = sc[MEL_S_NEW_ROUND];
+    s.episode = sc[MEL_S_EPISODE], s.move_cursor = sc[MEL_S_MOVE_CURSOR], s.decisions = sc[MEL_S_DECISIONS];
+    s.done_count = sc[MEL_S_DONE_COUNT], s.episodes_done = sc[MEL_S_EPISODES_DONE], s.error = sc[MEL_S_ERROR];
+    s.ep_cursor = sc[MEL_S_EP_CURSOR];
+    s.episode_rewards = e.episode_rewards[b];
+    const size_t k = (size_t)b * n + lane;
+    const bool on = lane < n;
+    s.px = on ? e.pos[2 * k] : 0.0, s.py = on ? e.pos[2 * k + 1] : 0.0;
+    s.reward = on ? e.rewards[k] : 0.0, s.pz_reward = on ? e.pz_rewards[k] : 0.0;
+    s.one_hop = on ? e.one_hop[k] : 0ull, s.two_hop = on ? e.two_hop[k] : 0ull;
+    s.msgs = on ? e.agent_msgs[k] : 0, s.received = on ? e.received[k] : 0, s.cover = on ? e.two_hop_cover[k] : 0;
+    s.act = on ? e.agent_action[k] : NONE, s.cur_act = on ? e.current_actions[k] : NONE;
+    s.steps = on ? e.steps_taken[k] : 0, s.sel_steps = on ? e.sel_steps[k] : 0;
+}
+
+__device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lane, const Env& s) {
+    const int n = e.n_nodes;
+    if (lane == 0) {
+        uint64_t* ns = e.node_sets + (size_t)b * 8;
+        ns[0] = s.has_msg, ns[1] = s.origin_set, ns[2] = s.interested, ns[3] = s.scripted;
+        ns[4] = s.truncated, ns[5] = s.alive, ns[6] = s.terminated, ns[7] = s.agents;
+        uint64_t* ss = e.sel_sets + (size_t)b * 4;
+        ss[0] = s.sel_active, ss[1] = s.sel_selected, ss[2] = s.info_valid, ss[3] = s.taken_action;
+        int32_t* sc = e.scalars + (size_t)b * MEL_ENV_SCALARS;
+        sc[MEL_S_ORIGIN] = s.origin, sc[MEL_S_SELECTION] = s.sel, sc[MEL_S_SKIP] = s.skip;
+        sc[MEL_S_NUM_MOVES] = s.num_moves, sc[MEL_S_WORLD_MSGS] = s.world_msgs, sc[MEL_S_NEW_ROUND] = s.new_round;
+        sc[MEL_S_EPISODE] = s.episode, sc[MEL_S_MOVE_CURSOR] = s.move_cursor, sc[MEL_S_DECISIONS] = s.decisions;
+        sc[MEL_S_DONE_COUNT] = s.done_count, sc[MEL_S_EPISODES_DONE] = s.episodes_done, sc[MEL_S_ERROR] = s.error;
+        sc[MEL_S_EP_CURSOR] = s.ep_cursor;
+        e.episode_rewards[b] = s.episode_rewards;
+    }
+    if (lane < n) {
+        const size_t k = (size_t)b * n + lane;
+        e.pos[2 * k] = s.px, e.pos[2 * k + 1] = s.py;
+        e.rewards[k] = s.reward, e.pz_rewards[k] = s.pz_reward;
+        e.one_hop[k] = s.one_hop, e.two_hop[k] = s.two_hop;
+        e.agent_msgs[k] = s.msgs, e.received[k] = s.received, e.two_hop_cover[k] = s.cover;
+        e.agent_action[k] = (int8_t)s.act, e.current_actions[k] = (int8_t)s.cur_act;
+        e.steps_taken[k] = (int8_t)s.steps, e.sel_steps[k] = (int8_t)s.sel_steps;
+    }
+}
+
+// core.py:334-341: one-hop OR neighbours' one-hop, minus self
+__device__ __forceinline__ uint64_t two_hop_of(uint64_t one_hop, int lane, int n) {
+    uint64_t m = one_hop;
+    for (int j = 0; j < n; ++j) {
+        const uint64_t t = readlane_u64(one_hop, j);
+        if ((one_hop >> j) & 1ull) m |= t;
+    }
+    return m & ~bit(lane);
+}
+
+// nx.geometric_edges (core.py:311): edge iff dx*dx + dy*dy <= 0.2**2 in float64
+__device__ __forceinline__ uint64_t geometric_one_hop(double px, double py, int lane, int n) {
+    uint64_t m = 0;
+    for (int j = 0; j < n; ++j) {
+        const double dx = px - shfl_f64(px, j), dy = py - shfl_f64(py, j);
+        const double d2 = dx * dx + dy * dy;
+        if (d2 <= R2_F64) m |= bit(j);
+    }
+    return (lane < n) ? (m & ~bit(lane)) : 0ull;
+}
+
+// selector.py:25-34
+__device__ __forceinline__ int selector_next(Env& s, int lane) {
+    const uint64_t cand = s.sel_active & ~s.sel_selected;
+    if (!cand) return NONE;
+    const int i = lowest_bit(cand);
+    if (lane == i) s.sel_steps += 1;
+    s.sel_selected |= bit(i);
+    return i;
+}
+// selector.py:43-44
+__device__ __forceinline__ void selector_enable(Env& s, uint64_t agents, int lane) {
+    const uint64_t can = __ballot(s.sel_steps < MAX_AGENT_STEPS);
+    s.sel_active = (s.sel_active & ~agents) | (agents & can);
+}
+
+// World.step core.py:225-266 (no scripted agents)
+__device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env& s,
+                                           int lane) {
+    const int n = e.n_nodes;
+    // :246 the source always transmits on its first opportunity
+    const int origin_msgs = __shfl(s.msgs, s.origin, 64);
+    if (lane == s.origin && origin_msgs == 0) s.act = 1;
+    // :249-254 relay in id order; has_message is re-read at each agent's turn
+    uint64_t cand = __ballot(lane < n && s.act != NONE && s.act != 0);
+    while (cand) {
+        const int i = lowest_bit(cand);
+        cand &= cand - 1;
+        if ((s.has_msg >> i) & 1ull) {                       // relay_message core.py:268-279
+            const uint64_t nb = readlane_u64(s.one_hop, i);
+            s.world_msgs += 1;
+            if (lane == i) s.msgs += 1;
+            s.taken_action |= bit(i);
+            s.received += (int)((nb >> lane) & 1ull);
+            s.has_msg |= nb;
+        }
+    }
+    // :256-257 move_graph -> update_position + one/two hop recompute (core.py:281-341)
+    if (e.dynamic_graph) {
+        int mv = s.move_cursor;
+        if (mv >= pool.max_moves) {
+            mv = pool.max_moves - 1;
+            s.error |= 1;
+        }
+        if (lane < n) {
+            const double* off = pool.moves + ((size_t)s.episode * pool.max_moves + mv) * 2 * n;
+            s.px = s.px + off[lane];
+            s.py = s.py + off[n + lane];
+        }
+        s.move_cursor += 1;
+        s.one_hop = geometric_one_hop(s.px, s.py, lane, n);
+        s.two_hop = two_hop_of(s.one_hop, lane, n);
+    }
+    // :260-261 -> Agent.update_two_hop_cover_from_one_hopper (core.py:94-102)
+    s.cover = __popcll(s.two_hop & (s.has_msg | s.origin_set));
+}
+
+// graph.py:254-271
+__device__ __forceinline__ void write_obs_matrix(const mel_env_batch& e, int b, const Env& s, int lane) {
+    if (lane >= e.n_nodes) return;
+    float4* row = reinterpret_cast<float4*>(e.obs_matrix + ((size_t)b * e.n_nodes + lane) * 8);
+    const float act = (s.act != NONE) ? (float)s.act : 0.f;
+    const float interested = ((s.interested >> lane) & 1ull) ? 1.f : 0.f;
+    const float has = (((s.has_msg | s.origin_set) >> lane) & 1ull) ? 1.f : 0.f;
+    const float dm = ((s.scripted >> lane) & 1ull) ? 0.f : 1.f;
+    row[0] = make_float4((float)s.px, (float)s.py, (float)__popcll(s.one_hop), (float)s.msgs);
+    row[1] = make_float4(act, interested, has, dm);
+}
+
+// graph.py:402-463, float64, same operation order
+__device__ __forceinline__ double agent_reward(const Env& s) {
+    const uint64_t covered = s.has_msg | s.origin_set;
+    const int total = __popcll(s.two_hop & s.interested);
+    const int cov = __popcll(s.two_hop & s.interested & covered);
+    double reward = total > 0 ? (double)cov / (double)total : 0.0;
+    const int deg = __popcll(s.one_hop);
+    if (s.act != NONE && s.act != 0) {
+        const double pen_unint = deg > 0 ? (double)__popcll(s.one_hop & ~s.interested) / (double)deg : 0.0;
+        const double pen_cov = deg > 0 ? (double)__popcll(s.one_hop & s.has_msg) / (double)deg : 0.0;
+        const double penalty = pen_unint + pen_cov;
+        reward -= penalty;
+    } else {
+        const int one_int = __popcll(s.one_hop & s.interested);
+        const int unc = __popcll(s.one_hop & s.interested & ~s.has_msg & ~s.origin_set);
+        if (unc > 0) reward -= (double)unc / (double)one_int;
+    }
+    return reward;
+}
+
+// graph.py:149-179 -> infos[agent]['logger_stats'] (10 float64 in dict order)
+__device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, int agent, const Env& s, int lane) {
+    const int n = e.n_nodes;
+    const int sent = wave_sum_i32(lane < n ? s.msgs : 0);
+    const int recv = wave_sum_i32(lane < n ? s.received : 0);
+    const int nbrs = wave_sum_i32(lane < n ? __popcll(s.one_hop) : 0);
+    if (lane == 0) {
+        double* st = e.info_stats + ((size_t)b * n + agent) * MEL_ENV_LOGGER_STATS;
+        const int n_int = __popcll(s.interested);
+        const int cov_int = __popcll(s.has_msg & s.interested);
+        st[0] = (double)s.world_msgs;
+        st[1] = (double)__popcll(s.has_msg) / (double)n;
+        st[2] = (double)sent;
+        st[3] = (double)recv;
+        st[4] = (double)nbrs;
+        st[5] = (double)n_int;
+        st[6] = n_int > 0 ? (double)cov_int / (double)n_int : 0.0;
+        st[7] = (double)cov_int;
+        st[8] = (double)__popcll(s.has_msg & ~s.interested);
+        st[9] = s.episode_rewards;
+    }
+}
+
+// GraphEnv.step graph.py:303-359 (+ the sticky reward copy of [3P] PettingZooEnv.step)
+__device__ __forceinline__ void env_step(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
+                                         int action, int lane) {
+    const int n = e.n_nodes;
+    const int a = s.sel;
+    if (a < 0) {                      // reference would raise KeyError; flag it and stay put
+        s.error |= 2;
+        return;
+    }
+    if ((s.terminated >> a) & 1ull) {                                   // :304-310 dead step
+        s.sel_active &= ~bit(a);
+        s.alive &= ~bit(a);                                             // _was_dead_step :274-301
+        s.terminated &= ~bit(a);
+        s.info_valid &= ~bit(a);
+        s.agents &= ~bit(a);
+        const uint64_t dead = s.agents & s.terminated;
+        if (dead) {
+            if (s.skip == SKIP_NONE) s.skip = a;
+            s.sel = lowest_bit(dead);
+        } else {
+            if (s.skip != SKIP_NONE) s.sel = s.skip;
+            s.skip = SKIP_NONE;
+        }
+    } else {
+        s.decisions += 1;
+        if (lane == a) {
+            s.cur_act = action;                                         // :314
+            s.steps += 1;                                               // :316-318
+        }
+        s.sel = selector_next(s, lane);                                 // :321
+        if (s.sel == NONE) {                                            // :324 round complete
+            if ((s.alive >> lane) & 1ull) s.reward = 0.0;               // _clear_rewards
+            s.act = s.cur_act;                                          // :362-365
+            world_step(e, pool, s, lane);
+            write_obs_matrix(e, b, s, lane);                            // :370-371
+            const double r0 = agent_reward(s);
+            double r = r0;
+            if (e.has_local_ratio) r = 0.0 * (1.0 - e.local_ratio) + r0 * e.local_ratio;   // :380-384
+            if ((s.agents >> lane) & 1ull) s.reward = r;                // :386
+            uint64_t rest = s.agents;                                   // :387 summed in id order
+            while (rest) {
+                const int i = lowest_bit(rest);
+                rest &= rest - 1;
+                s.episode_rewards += shfl_f64(r, i);
+            }
+            s.num_moves += 1;                                           // :328
+            const uint64_t expire = __ballot(lane < n && s.steps >= MAX_AGENT_STEPS) & s.agents & ~s.truncated;
+            s.truncated |= expire;                                      // :330-334
+            s.terminated |= expire;
+            s.agents = s.has_msg & s.alive & ~s.scripted;               // :336-341
+            selector_enable(s, s.agents, lane);                         // :342
+            s.sel_selected = 0;                                         // :343
+            s.new_round = 1;                                            // :344
+            s.sel = selector_next(s, lane);                             // :345
+            s.cur_act = NONE;                                           // :347
+        }
+        if (s.sel != NONE) {                                            // :358
+            write_info_stats(e, b, s.sel, s, lane);
+            s.info_valid |= bit(s.sel);
+        }
+        const uint64_t dead = s.agents & s.terminated;                  // :359 _deads_step_first
+        if (dead) {
+            s.skip = s.sel;
+            s.sel = lowest_bit(dead);
+        }
+    }
+    if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;               // PettingZooEnv.step (A.6)
+}
+
+// GraphEnv.reset + World.reset, graph.py:222-248 / core.py:343-437, from a pre-sampled pool episode
+__device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
+                                          int episode, int keep_graph, int lane) {
+    const int n = e.n_nodes;
+    const uint64_t full = (n == 64) ? ~0ull : (bit(n) - 1ull);
+    s.episode = episode;
+    s.move_cursor = 0;
+    if (!keep_graph) {
+        const size_t k = (size_t)episode * n + lane;
+        s.px = lane < n ? pool.pos[2 * k] : 0.0;
+        s.py = lane < n ? pool.pos[2 * k + 1] : 0.0;
+        s.one_hop = lane < n ? pool.one_hop[k] : 0ull;
+    }
+    s.two_hop = two_hop_of(s.one_hop, lane, n);                         // core.py:421
+    s.origin = pool.origin[episode];
+    s.interested = pool.interested[episode] & full;
+    s.scripted = 0;
+    s.world_msgs = 0;
+    s.has_msg = bit(s.origin);                                          // :432-434
+    s.origin_set = bit(s.origin);
+    s.taken_action = 0;
+    s.truncated = 0;
+    s.msgs = 0, s.received = 0, s.cover = 0;
+    s.act = NONE;
+    s.steps = (lane == s.origin) ? 1 : 0;                               // :424,435
+    world_step(e, pool, s, lane);                                       // :437
+    // GraphEnv.reset
+    s.sel_steps = (lane == s.origin) ? 1 : 0;                           // selector.reinit + enable(on_reset)
+    s.sel_active = 0, s.sel_selected = 0;
+    s.reward = 0.0;
+    s.alive = full, s.terminated = 0, s.info_valid = 0;
+    s.num_moves = 0;
+    s.episode_rewards = 0.0;
+    s.done_count = 0;
+    write_obs_matrix(e, b, s, lane);
+    s.agents = s.has_msg & ~s.scripted;                                 // :242-245
+    selector_enable(s, s.agents, lane);
+    s.sel = selector_next(s, lane);                                     // :247
+    s.skip = SKIP_NONE;
+    s.cur_act = NONE;                                                   // :248
+    s.ep_cursor += 1;
+}
+
+// GraphEnv.observe / last() graph.py:181-216 + PettingZooEnv packing; returns (terminated, explicit_reset)
+__device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s, const mel_env_obs& o,
+                                           int64_t row, int lane) {
+    const int n = e.n_nodes;
+    const int a = s.sel;
+    const int valid = a >= 0;
+    const int dead = valid ? (int)((s.terminated >> a) & 1ull) : 0;
+    int explicit_reset = 0, environment_step = 0;
+    if (__popcll(s.agents) == 1 && (s.agents & ~s.terminated) == 0) {   // :205-207
+        s.new_round = 0;
+        explicit_reset = 1;
+    }
+    if (s.new_round == 1) {                                             // :209-211
+        environment_step = 1;
+        s.new_round = 0;
+    }
+    if (o.obs) {
+        float* dst = o.obs + row * o.obs_stride;
+        const float* src = e.obs_matrix + (size_t)b * n * 8;
+        for (int c = lane; c < n * 8; c += 64) dst[c] = src[c];
+        if (lane == 0) dst[n * 8] = (float)a;
+    }
+    if (o.rew && lane < n) o.rew[row * n + lane] = s.pz_reward;
+    if (o.stats && lane < MEL_ENV_LOGGER_STATS) {
+        const int ok = valid && ((s.info_valid >> a) & 1ull);
+        o.stats[row * MEL_ENV_LOGGER_STATS + lane] =
+            ok ? e.info_stats[((size_t)b * n + a) * MEL_ENV_LOGGER_STATS + lane] : 0.0;
+    }
+    const uint64_t nb = readlane_u64(s.one_hop, valid ? a : 0);         // all lanes take part
+    if (lane == 0) {
+        if (o.agent_id) o.agent_id[row] = a;
+        if (o.action_mask) o.action_mask[2 * row] = o.action_mask[2 * row + 1] = dead ? 0 : 1;   // :190-192
+        if (o.terminated) o.terminated[row] = (uint8_t)dead;
+        if (o.flags) {
+            o.flags[4 * row + 0] = s.num_moves;
+            o.flags[4 * row + 1] = environment_step;
+            o.flags[4 * row + 2] = explicit_reset;
+            o.flags[4 * row + 3] = valid ? (int)((s.info_valid >> a) & 1ull) : 0;
+        }
+        if (o.active_nb) o.active_nb[row] = valid ? (nb & ~(s.truncated & ~s.agents)) : 0ull;   // :198-203
+    }
+    return dead | (explicit_reset << 1);
+}
+
+struct StepArgs {
+    mel_env_batch env;
+    mel_episode_pool pool;
+    const int32_t* actions;
+    const int32_t* env_ids;
+    const int32_t* episode_ids;
+    int64_t n;
+    mel_env_obs out;
+    int has_out;
+    int keep_graph;
+    const int32_t* episode_table;
+    int table_stride;
+};
+
+enum { OP_RESET = 0, OP_STEP = 1, OP_OBSERVE = 2 };
+
+template <int OP>
+__global__ __launch_bounds__(256) void env_kernel(StepArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n) return;
+    const int lane = lane_id();
+    const int b = a.env_ids ? a.env_ids[row] : (int)row;
+    Env s;
+    env_load(a.env, b, lane, s);
+    if (OP == OP_RESET) {
+        env_reset(a.env, a.pool, b, s, a.episode_ids[row], a.keep_graph, lane);
+        if (a.has_out) env_observe(a.env, b, s, a.out, row, lane);
+    } else if (OP == OP_STEP) {
+        env_step(a.env, a.pool, b, s, a.actions[row], lane);
+        if (a.has_out) {
+            const int r = env_observe(a.env, b, s, a.out, row, lane);
+            if (a.episode_table) {
+                if (r & 1) s.done_count += 1;
+                // multi_agent_collector.py:261-264: episode over -> reset this env
+                if ((r & 1) && ((r & 2) || s.done_count == a.env.n_nodes)) {
+                    s.episodes_done += 1;
+                    const int ep = a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)];
+                    env_reset(a.env, a.pool, b, s, ep, 0, lane);
+                    env_observe(a.env, b, s, a.out, row, lane);
+                }
+            }
+        }
+    } else {
+        env_observe(a.env, b, s, a.out, row, lane);
+    }
+    env_store(a.env, b, lane, s);
+}
+
+static mel_status check_env(const mel_env_batch* env, int64_t n) {
+    if (!env) return fail(MEL_ERR_INVALID_ARG, "env batch is null");
+    if (env->n_nodes < 1 || env->n_nodes > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, 64]", env->n_nodes);
+    if (n < 0 || n > env->n_envs) return fail(MEL_ERR_INVALID_ARG, "n=%ld outside [0, n_envs=%d]", (long)n, env->n_envs);
+    if (!env->pos || !env->scalars) return fail(MEL_ERR_INVALID_ARG, "env batch is not bound (mel_env_bind)");
+    return MEL_OK;
+}
+
+static mel_status check_pool(const mel_env_batch* env, const mel_episode_pool* pool) {
+    if (!pool) return fail(MEL_ERR_INVALID_ARG, "episode pool is null");
+    if (pool->n_nodes != env->n_nodes) return fail(MEL_ERR_INVALID_ARG, "pool has %d nodes, env %d", pool->n_nodes, env->n_nodes);
+    if (pool->n_episodes < 1 || !pool->origin || !pool->interested) return fail(MEL_ERR_INVALID_ARG, "empty episode pool");
+    if (env->dynamic_graph && (pool->max_moves < 1 || !pool->moves)) return fail(MEL_ERR_INVALID_ARG, "dynamic graph needs movement offsets");
+    return MEL_OK;
+}
+
+struct EnvLayout {
+    mel_env_batch e;
+    size_t bytes;
+};
+
+static EnvLayout carve_env(int32_t B, int32_t n, void* state) {
+    EnvLayout L{};
+    Carver c(state);
+    const size_t BN = (size_t)B * n;
+    L.e.n_envs = B, L.e.n_nodes = n;
+    L.e.pos = c.take<double>(BN * 2);
+    L.e.one_hop = c.take<uint64_t>(BN);
+    L.e.two_hop = c.take<uint64_t>(BN);
+    L.e.node_sets = c.take<uint64_t>((size_t)B * 8);
+    L.e.sel_sets = c.take<uint64_t>((size_t)B * 4);
+    L.e.scalars = c.take<int32_t>((size_t)B * MEL_ENV_SCALARS);
+    L.e.agent_msgs = c.take<int32_t>(BN);
+    L.e.received = c.take<int32_t>(BN);
+    L.e.two_hop_cover = c.take<int32_t>(BN);
+    L.e.agent_action = c.take<int8_t>(BN);
+    L.e.current_actions = c.take<int8_t>(BN);
+    L.e.steps_taken = c.take<int8_t>(BN);
+    L.e.sel_steps = c.take<int8_t>(BN);
+    L.e.rewards = c.take<double>(BN);
+    L.e.pz_rewards = c.take<double>(BN);
+    L.e.episode_rewards = c.take<double>(B);
+    L.e.obs_matrix = c.take<float>(BN * 8);
+    L.e.info_stats = c.take<double>(BN * MEL_ENV_LOGGER_STATS);
+    L.bytes = c.off;
+    return L;
+}
+
+}  // namespace mel
+
+using namespace mel;
+
+extern "C" {
+
+size_t mel_env_state_bytes(int32_t n_envs, int32_t n_nodes) {
+    if (n_envs < 1 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return 0;
+    return carve_env(n_envs, n_nodes, nullptr).bytes;
+}
+
+mel_status mel_env_bind(mel_env_batch* env, int32_t n_envs, int32_t n_nodes, void* state) {
+    if (!env || !state) return fail(MEL_ERR_INVALID_ARG, "null env/state");
+    if (n_envs < 1 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_envs=%d n_nodes=%d", n_envs, n_nodes);
+    if (reinterpret_cast<uintptr_t>(state) & 255) return fail(MEL_ERR_INVALID_ARG, "state must be 256-byte aligned");
+    const EnvLayout L = carve_env(n_envs, n_nodes, state);
+    const int32_t dyn = env->dynamic_graph, hlr = env->has_local_ratio;
+    const double lr = env->local_ratio;
+    *env = L.e;
+    env->dynamic_graph = dyn, env->has_local_ratio = hlr, env->local_ratio = lr;
+    return MEL_OK;
+}
+
+mel_status mel_env_reset(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* env_ids,
+                         const int32_t* episode_ids, int64_t n, int32_t keep_graph, const mel_env_obs* out,
+                         void* stream) {
+    if (mel_status st = check_env(env, n)) return st;
+    if (mel_status st = check_pool(env, pool)) return st;
+    if (!episode_ids) return fail(MEL_ERR_INVALID_ARG, "episode_ids is null");
+    if (!keep_graph && (!pool->pos || !pool->one_hop)) return fail(MEL_ERR_INVALID_ARG, "pool has no graphs");
+    if (n == 0) return MEL_OK;
+    StepArgs a{};
+    a.env = *env, a.pool = *pool, a.env_ids = env_ids, a.episode_ids = episode_ids, a.n = n, a.keep_graph = keep_graph;
+    if (out) a.out = *out, a.has_out = 1;
+    hipLaunchKernelGGL(env_kernel<OP_RESET>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("env_reset");
+}
+
+mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
+                        const int32_t* env_ids, int64_t n, const mel_env_obs* out, const int32_t* episode_table,
+                        int32_t table_stride, void* stream) {
+    if (mel_status st = check_env(env, n)) return st;
+    if (mel_status st = check_pool(env, pool)) return st;
+    if (!actions) return fail(MEL_ERR_INVALID_ARG, "actions is null");
+    if (episode_table && (table_stride < 1 || !out)) return fail(MEL_ERR_INVALID_ARG, "auto-reset needs table_stride >= 1 and an output block");
+    if (n == 0) return MEL_OK;
+    StepArgs a{};
+    a.env = *env, a.pool = *pool, a.actions = actions, a.env_ids = env_ids, a.n = n;
+    a.episode_table = episode_table, a.table_stride = table_stride;
+    if (out) a.out = *out, a.has_out = 1;
+    hipLaunchKernelGGL(env_kernel<OP_STEP>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("env_step");
+}
+
+mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n, const mel_env_obs* out,
+                           void* stream) {
+    if (mel_status st = check_env(env, n)) return st;
+    if (!out) return fail(MEL_ERR_INVALID_ARG, "output block is null");
+    if (n == 0) return MEL_OK;
+    StepArgs a{};
+    a.env = *env, a.env_ids = env_ids, a.n = n, a.out = *out, a.has_out = 1;
+    hipLaunchKernelGGL(env_kernel<OP_OBSERVE>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("env_observe");
+}
+
+}  // extern "C"

@@ -1,0 +1,754 @@
+// L-DGN / HL-DGN forward for MI355X (gfx950): plan (obs unpack + fp32 radius adjacency + receptive
+// field), fp32-MFMA row GEMMs (gemm_f32.hpp), GATv2 edge-softmax/aggregate, segmented pool, dueling
+// tail, DQN action selection.  Reference semantics: networks/common.py:6-64, l_dgn.py:92-151,
+// hl_dgn.py:82-119 and SURVEY.md Appendix A for the third-party operators.
+#include "common.hpp"
+#include "gemm_f32.hpp"
+
+namespace mel {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM dispatch
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+static void gemm_launch_t(const GemmArgs& g, int mode, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
+    if (mode == GEMM_MODE_ENC)
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, GEMM_MODE_ENC>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, GEMM_MODE_PLAIN>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
+}
+
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what) {
+    if (g.M <= 0) return MEL_OK;
+    if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
+        return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
+    // 128x128 tiles when they still give >= 2 workgroups per CU, else 64x64 single-wave tiles.
+    const long big = (long)((g.M + 127) / 128) * (g.N / 128);
+    if (g.N % 128 == 0 && big >= 512)
+        gemm_launch_t<2, 2>(g, mode, stream);
+    else
+        gemm_launch_t<1, 1>(g, mode, stream);
+    return check_launch(what);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan: one wavefront per observation row, lane = node
+// ------------------------------------------------------------------------------------------------
+struct PlanBuffers {
+    uint64_t* adj;      // [bs*N] sources of target i (radius rule, self excluded)
+    int32_t* gidx;      // [bs]   controlling agent (common.py:63)
+    uint64_t* s1;       // [bs]   closed one-hop set of g   (targets of conv1 that reach the logits)
+    uint64_t* s2;       // [bs]   closed two-hop set of g   (sources of those targets)
+    int32_t* cnt;       // [2*bs] |s1|, |s2|
+    int32_t* off1;      // [bs+1] exclusive scan of |s1| (off1[bs] = total)
+    int32_t* off2;      // [bs+1]
+    int32_t* nid2;      // [sum|s2|] global node id of packed row
+    int32_t* arow1;     // [sum|s1|] row of the |s2| list holding the same node
+    float* dm1;         // [sum|s1|] decision-maker flag of the node (l_dgn.py:128)
+    int32_t* arow_g;    // [bs] row of the |s1| list holding g
+    float* dm_g;        // [bs]
+};
+
+// [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
+// positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
+// the first 33 hits in index order (self included) survive, then self is dropped.
+__device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
+    const float r2 = (float)(0.2 * 0.2);
+    uint64_t m = 0;
+    for (int j = 0; j < n; ++j) {
+        const float xj = __shfl(x, j, 64), yj = __shfl(y, j, 64);
+        const float dx = x - xj, dy = y - yj;
+        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        if (d2 < r2) m |= 1ull << j;
+    }
+    while (__popcll(m) > 33) m &= ~(1ull << (63 - __clzll((long long)m)));
+    return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
+}
+
+__global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict__ obs, int bs, int n,
+                                                         int obs_width, int node_cols, PlanBuffers p,
+                                                         int want_receptive) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    const int lane = lane_id();
+    const float* row = obs + (size_t)b * obs_width;
+    float x = 0.f, y = 0.f;
+    if (lane < n) {
+        x = row[lane * node_cols];
+        y = row[lane * node_cols + 1];
+    }
+    const uint64_t src = radius_sources(x, y, lane, n);
+    if (lane < n) p.adj[(size_t)b * n + lane] = src;
+    // common.py:63: obs[:, -1].clamp(0, N-1).long()
+    float gf = row[obs_width - 1];
+    gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
+    const int g = (int)gf;
+    if (!want_receptive) {
+        if (lane == 0) p.gidx[b] = g;
+        return;
+    }
+    const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
+    const uint64_t s1 = readlane_u64(closed, g);
+    const uint64_t s2 = wave_or_u64(((s1 >> lane) & 1ull) ? closed : 0ull);
+    if (lane == 0) {
+        p.gidx[b] = g;
+        p.s1[b] = s1;
+        p.s2[b] = s2;
+        p.cnt[b] = __popcll(s1);
+        p.cnt[bs + b] = __popcll(s2);
+    }
+}
+
+// exclusive scans of |s1| and |s2| over the batch (single workgroup, any bs)
+__global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) {
+    __shared__ int32_t part[2][1024];
+    const int tid = threadIdx.x;
+    const int per = (bs + 1023) / 1024;
+    const int lo = min(tid * per, bs), hi = min(lo + per, bs);
+    int32_t s1 = 0, s2 = 0;
+    for (int b = lo; b < hi; ++b) {
+        s1 += p.cnt[b];
+        s2 += p.cnt[bs + b];
+    }
+    part[0][tid] = s1;
+    part[1][tid] = s2;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int32_t a1 = 0, a2 = 0;
+        if (tid >= d) {
+            a1 = part[0][tid - d];
+            a2 = part[1][tid - d];
+        }
+        __syncthreads();
+        part[0][tid] += a1;
+        part[1][tid] += a2;
+        __syncthreads();
+    }
+    int32_t o1 = part[0][tid] - s1, o2 = part[1][tid] - s2;
+    for (int b = lo; b < hi; ++b) {
+        p.off1[b] = o1;
+        p.off2[b] = o2;
+        o1 += p.cnt[b];
+        o2 += p.cnt[bs + b];
+    }
+    if (tid == 1023) {
+        p.off1[bs] = part[0][1023];
+        p.off2[bs] = part[1][1023];
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
+                                                         int obs_width, int node_cols, PlanBuffers p) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    const int lane = lane_id();
+    const uint64_t s1 = p.s1[b], s2 = p.s2[b];
+    const int o1 = p.off1[b], o2 = p.off2[b];
+    const float* row = obs + (size_t)b * obs_width;
+    if ((s2 >> lane) & 1ull) p.nid2[o2 + rank_below(s2, lane)] = b * n + lane;
+    if ((s1 >> lane) & 1ull) {
+        const int r1 = o1 + rank_below(s1, lane);
+        p.arow1[r1] = o2 + rank_below(s2, lane);
+        p.dm1[r1] = row[lane * node_cols + node_cols - 1];
+    }
+    if (lane == 0) {
+        const int g = p.gidx[b];
+        p.arow_g[b] = o1 + rank_below(s1, g);
+        p.dm_g[b] = row[g * node_cols + node_cols - 1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GATv2 edge softmax + aggregation.  One wavefront per target node; the 64 lanes
+// span the heads*C output channels (VPL contiguous channels per lane, so a head is C/VPL adjacent
+// lanes and the per-head score reduction is a few xor-shuffles).  Sources are streamed once with an
+// online softmax: out = sum_j exp(e_j - m) x_l[j] / (sum_j exp(e_j - m) + 1e-16).
+// ------------------------------------------------------------------------------------------------
+enum { ATT_ROWS = 0, ATT_POOL = 1, ATT_SINGLE = 2 };
+
+struct AttArgs {
+    const float* xl;        // source rows
+    int ld_l;
+    const float* xr;        // target rows
+    int ld_r;
+    const float* att;       // [heads*C]
+    const float* bias;      // [heads*C]
+    const uint64_t* adj;    // [bs*N]
+    const int32_t* gidx;    // [bs]
+    const uint64_t* tmask;  // [bs] targets (ATT_ROWS with receptive field) or null = all nodes
+    const uint64_t* smask;  // [bs] set the source rows are packed by, or null = all nodes
+    const int32_t* toff;    // [bs] first target row, or null = b*N
+    const int32_t* soff;    // [bs] first source row, or null = b*N
+    int bs, n, lanes_per_head;
+    // ATT_ROWS
+    float* out;             // [rows, ldo] relu(out + bias)
+    int ldo;
+    float* xcat;            // [bs, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
+    int ld_cat, hidden;
+    const float* h0;        // encoder rows (packed by smask), [*, hidden]
+    // ATT_POOL
+    const float* obs;       // dm flag source
+    int obs_width, node_cols, aggregator;
+    float* pooled;          // [bs, heads*C]
+    // ATT_SINGLE
+    int cat_off;
+};
+
+template <int VPL>
+struct Vec {
+    float v[VPL];
+};
+
+template <int VPL>
+__device__ __forceinline__ Vec<VPL> load_vec(const float* p) {
+    Vec<VPL> r;
+    if constexpr (VPL >= 4) {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(p)[i];
+            r.v[4 * i] = t.x, r.v[4 * i + 1] = t.y, r.v[4 * i + 2] = t.z, r.v[4 * i + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) r.v[i] = p[i];
+    }
+    return r;
+}
+
+template <int VPL>
+__device__ __forceinline__ void store_vec(float* p, const Vec<VPL>& r) {
+    if constexpr (VPL >= 4) {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i)
+            reinterpret_cast<float4*>(p)[i] = make_float4(r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) p[i] = r.v[i];
+    }
+}
+
+// attention output of one target for this lane's VPL channels: relu(out + bias)
+template <int VPL>
+__device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float* xr_row, uint64_t sources,
+                                                  uint64_t smask, int soff, const Vec<VPL>& att,
+                                                  const Vec<VPL>& bias, int lane) {
+    const Vec<VPL> xr = load_vec<VPL>(xr_row + lane * VPL);
+    float m = -INFINITY, l = 0.f;
+    Vec<VPL> acc;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
+    while (sources) {
+        const int j = lowest_bit(sources);
+        sources &= sources - 1;
+        const float* xl_row = a.xl + (size_t)(soff + rank_below(smask, j)) * a.ld_l + lane * VPL;
+        const Vec<VPL> xl = load_vec<VPL>(xl_row);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float z = xr.v[i] + xl.v[i];
+            z = z > 0.f ? z : 0.2f * z;          // leaky_relu(negative_slope=0.2)
+            s = fmaf(att.v[i], z, s);
+        }
+        for (int o = a.lanes_per_head >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mn = fmaxf(m, s);
+        const float sc = expf(m - mn), pe = expf(s - mn);
+        l = l * sc + pe;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc.v[i] = acc.v[i] * sc + pe * xl.v[i];
+        m = mn;
+    }
+    const float inv = 1.f / (l + 1e-16f);
+    Vec<VPL> out;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) out.v[i] = fmaxf(acc.v[i] * inv + bias.v[i], 0.f);
+    return out;
+}
+
+template <int VPL, int MODE>
+__global__ __launch_bounds__(256) void gat_attend_kernel(AttArgs a) {
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const Vec<VPL> att = load_vec<VPL>(a.att + lane * VPL);
+    const Vec<VPL> bias = load_vec<VPL>(a.bias + lane * VPL);
+    const uint64_t full = (a.n == 64) ? ~0ull : ((1ull << a.n) - 1ull);
+
+    if constexpr (MODE == ATT_SINGLE) {
+        // conv2 of L-DGN: only the controlling agent's row can reach the logits (l_dgn.py:135)
+        const int b = blockIdx.x * 4 + wave;
+        if (b >= a.bs) return;
+        const int g = a.gidx[b];
+        const uint64_t sources = a.adj[(size_t)b * a.n + g] | (1ull << g);
+        const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)b * a.ld_r, sources, a.smask[b], a.soff[b],
+                                              att, bias, lane);
+        store_vec<VPL>(a.xcat + (size_t)b * a.ld_cat + a.cat_off + lane * VPL, o);
+        return;
+    } else {
+        const int b = blockIdx.x;
+        const uint64_t tmask = a.tmask ? a.tmask[b] : full;
+        const uint64_t smask = a.smask ? a.smask[b] : full;
+        const int toff = a.toff ? a.toff[b] : b * a.n;
+        const int soff = a.soff ? a.soff[b] : b * a.n;
+        const int g = a.gidx[b];
+        Vec<VPL> pool;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
+        uint64_t rest = tmask;
+        for (int k = 0; rest; ++k) {
+            const int t = lowest_bit(rest);
+            rest &= rest - 1;
+            if ((k & 3) != wave) continue;
+            const int trow = toff + rank_below(tmask, t);
+            const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
+            const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)trow * a.ld_r, sources, smask, soff, att,
+                                                  bias, lane);
+            if constexpr (MODE == ATT_ROWS) {
+                store_vec<VPL>(a.out + (size_t)trow * a.ldo + lane * VPL, o);
+                if (t == g) {
+                    // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
+                    store_vec<VPL>(a.xcat + (size_t)b * a.ld_cat + a.hidden + lane * VPL, o);
+                    // x_1: its encoder row (l_dgn.py:122)
+                    const float* h0 = a.h0 + (size_t)(soff + rank_below(smask, g)) * a.hidden;
+                    for (int c = lane; c < a.hidden; c += 64) a.xcat[(size_t)b * a.ld_cat + c] = h0[c];
+                }
+            } else {
+                // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
+                const float dm = a.obs[(size_t)b * a.obs_width + t * a.node_cols + a.node_cols - 1];
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const float v = o.v[i] * dm;
+                    pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? fmaxf(pool.v[i], v) : pool.v[i] + v;
+                }
+            }
+        }
+        if constexpr (MODE == ATT_POOL) {
+            __shared__ float part[4][64 * VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) part[wave][lane * VPL + i] = pool.v[i];
+            __syncthreads();
+            for (int c = threadIdx.x; c < 64 * VPL; c += 256) {
+                float v;
+                if (a.aggregator == MEL_AGG_MAX) {
+                    v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
+                } else {
+                    v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+                    if (a.aggregator == MEL_AGG_MEAN) v /= (float)a.n;
+                }
+                a.pooled[(size_t)b * (64 * VPL) + c] = v;
+            }
+        }
+    }
+}
+
+template <int MODE>
+static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const char* what) {
+    const int grid = (MODE == ATT_SINGLE) ? (a.bs + 3) / 4 : a.bs;
+    switch (hc / 64) {
+        case 2: hipLaunchKernelGGL((gat_attend_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((gat_attend_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((gat_attend_kernel<8, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((gat_attend_kernel<16, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+        default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
+    }
+    return check_launch(what);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dueling tail: last Linear of Q and V + q - mean(q) + v  (l_dgn.py:142-147); one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dueling_tail_kernel(const float* __restrict__ hq, int ldq, int kq,
+                                                           const float* __restrict__ hv, int ldv, int kv,
+                                                           mel_linear q_last, mel_linear v_last, int bs,
+                                                           int dueling, float* __restrict__ logits) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    const int lane = lane_id();
+    const int na = q_last.out_dim;
+    float q[8];
+    float qsum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        q[a] = 0.f;
+        if (a < na) {
+            float s = 0.f;
+            for (int k = lane; k < kq; k += 64) s = fmaf(hq[(size_t)b * ldq + k], q_last.weight[(size_t)a * kq + k], s);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            q[a] = s + q_last.bias[a];
+            qsum += q[a];
+        }
+    }
+    float v = 0.f, mean = 0.f;
+    if (dueling) {
+        for (int k = lane; k < kv; k += 64) v = fmaf(hv[(size_t)b * ldv + k], v_last.weight[k], v);
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        v += v_last.bias[0];
+        mean = qsum / (float)na;
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (a < na && lane == a) logits[(size_t)b * na + a] = q[a] - mean + v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// [3P] DQNPolicy.forward / exploration_noise
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ x, long count, float* out) {
+    __shared__ float smin[16], smax[16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (long i = threadIdx.x; i < count; i += 1024) {
+        lo = fminf(lo, x[i]);
+        hi = fmaxf(hi, x[i]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = lo, smax[threadIdx.x >> 6] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) lo = fminf(lo, smin[w]), hi = fmaxf(hi, smax[w]);
+        out[0] = lo;
+        out[1] = hi;
+    }
+}
+
+__global__ __launch_bounds__(256) void select_action_kernel(const float* __restrict__ logits,
+                                                            const uint8_t* __restrict__ mask, long bs, int na,
+                                                            float eps, const float* __restrict__ rand_u,
+                                                            const float* __restrict__ rand_q,
+                                                            const float* __restrict__ minmax,
+                                                            int32_t* __restrict__ act) {
+    const long b = (long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= bs) return;
+    const float shift = mask ? (minmax[0] - minmax[1] - 1.0f) : 0.f;
+    int best = 0;
+    float bv = -INFINITY;
+    for (int a = 0; a < na; ++a) {
+        float q = logits[b * na + a];
+        if (mask) q = q + (1.0f - (float)mask[b * na + a]) * shift;
+        if (q > bv) bv = q, best = a;          // first maximum, as argmax
+    }
+    if (rand_u && rand_q && rand_u[b] < eps) {
+        best = 0, bv = -INFINITY;
+        for (int a = 0; a < na; ++a) {
+            float q = rand_q[b * na + a];
+            if (mask) q += (float)mask[b * na + a];
+            if (q > bv) bv = q, best = a;
+        }
+    }
+    act[b] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------------
+struct FwdLayout {
+    PlanBuffers plan;
+    float* h0;      // encoder rows
+    float* xl1;     // conv1 lin_l rows (HL-DGN: xl | xr in one [M, 2*HC] matrix)
+    float* xr1;
+    float* h1;      // conv1 output rows
+    float* xl2;
+    float* xr2;
+    float* xcat;    // head input [bs, latent]
+    float* hq[2];   // head hidden ping-pong [bs, qw + vw]
+    float* minmax;
+    size_t bytes;
+};
+
+static int head_hidden_width(const mel_mlp& m) {
+    int w = 0;
+    for (int i = 0; i + 1 < m.n_layers; ++i) w = w > m.layer[i].out_dim ? w : m.layer[i].out_dim;
+    return w;
+}
+
+static FwdLayout carve(const mel_weights* w, int64_t bs, int n, void* ws) {
+    FwdLayout L{};
+    Carver c(ws);
+    const int hidden = w->encoder.layer[1].out_dim;
+    const int hc = w->conv1.heads * w->conv1.channels;
+    const size_t M = (size_t)bs * n;
+    const int cap1 = n < 34 ? n : 34;                 // |s1| <= 33 sources + self
+    L.plan.adj = c.take<uint64_t>(M);
+    L.plan.gidx = c.take<int32_t>(bs);
+    const int latent = w->q_head.layer[0].in_dim;
+    if (w->model == MEL_MODEL_LDGN) {
+        const size_t R1 = (size_t)bs * cap1;
+        L.plan.s1 = c.take<uint64_t>(bs);
+        L.plan.s2 = c.take<uint64_t>(bs);
+        L.plan.cnt = c.take<int32_t>(2 * bs);
+        L.plan.off1 = c.take<int32_t>(bs + 1);
+        L.plan.off2 = c.take<int32_t>(bs + 1);
+        L.plan.nid2 = c.take<int32_t>(M);
+        L.plan.arow1 = c.take<int32_t>(R1);
+        L.plan.dm1 = c.take<float>(R1);
+        L.plan.arow_g = c.take<int32_t>(bs);
+        L.plan.dm_g = c.take<float>(bs);
+        L.h0 = c.take<float>(M * hidden);
+        L.xl1 = c.take<float>(M * hc);
+        L.xr1 = c.take<float>(R1 * hc);
+        L.h1 = c.take<float>(R1 * hc);
+        L.xl2 = c.take<float>(R1 * hc);
+        L.xr2 = c.take<float>((size_t)bs * hc);
+    } else {
+        L.h0 = c.take<float>(M * hidden);
+        L.xl1 = c.take<float>(M * 2 * hc);
+    }
+    L.xcat = c.take<float>((size_t)bs * latent);
+    const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
+    L.hq[0] = c.take<float>((size_t)bs * (hw > 0 ? hw : 1));
+    L.hq[1] = c.take<float>((size_t)bs * (hw > 0 ? hw : 1));
+    L.minmax = c.take<float>(64);
+    L.bytes = c.off;
+    return L;
+}
+
+static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, int obs_width) {
+    if (!w) return fail(MEL_ERR_INVALID_ARG, "weights pointer is null");
+    if (w->model != model) return fail(MEL_ERR_INVALID_ARG, "weights are for model %d, entry point is for %d", w->model, model);
+    if (bs <= 0 || bs > (1 << 24)) return fail(MEL_ERR_INVALID_ARG, "bs=%ld out of range", (long)bs);
+    if (n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, %d]", n, MEL_MAX_NODES);
+    if (w->in_dim < 1 || w->in_dim > 8) return fail(MEL_ERR_UNSUPPORTED, "in_dim=%d outside [1, 8]", w->in_dim);
+    const int expected = n * (w->in_dim + 3);
+    if (obs_width - 1 != expected)      // networks/common.py:24-29
+        return fail(MEL_ERR_SHAPE, "Expected %d feature cols for nodes, got %d", expected, obs_width - 1);
+    if (w->encoder.n_layers != 2) return fail(MEL_ERR_UNSUPPORTED, "encoder must be a 2-layer MLP");
+    const int hidden = w->encoder.layer[1].out_dim;
+    if (w->encoder.layer[0].in_dim != w->in_dim || w->encoder.layer[1].in_dim != w->encoder.layer[0].out_dim)
+        return fail(MEL_ERR_INVALID_ARG, "encoder layer shapes inconsistent");
+    if (w->encoder.layer[0].out_dim % 32 || hidden % 64)
+        return fail(MEL_ERR_UNSUPPORTED, "encoder widths must be multiples of 64 (got %d, %d)", w->encoder.layer[0].out_dim, hidden);
+    const int hc = w->conv1.heads * w->conv1.channels;
+    if (hc != 128 && hc != 256 && hc != 512 && hc != 1024)
+        return fail(MEL_ERR_UNSUPPORTED, "heads*channels = %d not in {128,256,512,1024}", hc);
+    const int lph = hc / 64 ? w->conv1.channels / (hc / 64) : 0;
+    if (lph < 1 || (lph & (lph - 1)) || lph * (hc / 64) != w->conv1.channels)
+        return fail(MEL_ERR_UNSUPPORTED, "channels per head (%d) must be a power-of-two multiple of %d", w->conv1.channels, hc / 64);
+    if (w->conv1.lin_l.in_dim != hidden || w->conv1.lin_l.out_dim != hc || w->conv1.lin_r.out_dim != hc)
+        return fail(MEL_ERR_INVALID_ARG, "conv1 projection shapes inconsistent");
+    int latent = hc;
+    if (model == MEL_MODEL_LDGN) {
+        if (w->conv2.heads != w->conv1.heads || w->conv2.channels != w->conv1.channels ||
+            w->conv2.lin_l.in_dim != hc || w->conv2.lin_l.out_dim != hc || w->conv2.lin_r.out_dim != hc)
+            return fail(MEL_ERR_INVALID_ARG, "conv2 projection shapes inconsistent");
+        latent = hidden + 2 * hc;                    // l_dgn.py:44
+    }
+    const mel_mlp* heads[2] = {&w->q_head, &w->v_head};
+    for (int k = 0; k < 2; ++k) {
+        const mel_mlp& m = *heads[k];
+        if (m.n_layers < 1 || m.n_layers > MEL_MAX_HEAD_LAYERS) return fail(MEL_ERR_UNSUPPORTED, "dueling head depth %d", m.n_layers);
+        if (m.layer[0].in_dim != latent) return fail(MEL_ERR_INVALID_ARG, "dueling head expects %d inputs, network produces %d", m.layer[0].in_dim, latent);
+        for (int i = 0; i + 1 < m.n_layers; ++i)
+            if (m.layer[i].out_dim % 64 || m.layer[i].in_dim % 32 || m.layer[i + 1].in_dim != m.layer[i].out_dim)
+                return fail(MEL_ERR_UNSUPPORTED, "dueling hidden layer %d shape %dx%d unsupported", i, m.layer[i].out_dim, m.layer[i].in_dim);
+    }
+    if (w->q_head.n_layers != w->v_head.n_layers) return fail(MEL_ERR_UNSUPPORTED, "Q and V heads must have equal depth");
+    if (w->q_head.layer[w->q_head.n_layers - 1].out_dim != w->n_actions || w->n_actions > 8 || w->n_actions < 1)
+        return fail(MEL_ERR_UNSUPPORTED, "n_actions=%d outside [1, 8] or inconsistent", w->n_actions);
+    if (w->v_head.layer[w->v_head.n_layers - 1].out_dim != 1) return fail(MEL_ERR_INVALID_ARG, "V head must end in 1 output");
+    return MEL_OK;
+}
+
+// dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail
+static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t bs, float* logits, hipStream_t s) {
+    const int nl = w->q_head.n_layers;
+    const float* in_q = L.xcat;
+    const float* in_v = L.xcat;
+    int ld_q = w->q_head.layer[0].in_dim, ld_v = ld_q;
+    for (int i = 0; i + 1 < nl; ++i) {
+        const mel_linear& q = w->q_head.layer[i];
+        const mel_linear& v = w->v_head.layer[i];
+        float* out = L.hq[i & 1];
+        const int ldo = q.out_dim + v.out_dim;
+        if (i == 0 && q.in_dim == v.in_dim) {       // shared input: one launch, weights split along n
+            GemmArgs g;
+            g.A = in_q, g.lda = ld_q;
+            g.W = q.weight, g.W_hi = v.weight, g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
+            g.Y = out, g.ldy = ldo, g.M = (int)bs, g.N = ldo, g.K = q.in_dim, g.relu = 1;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)")) return st;
+        } else {
+            GemmArgs g;
+            g.A = in_q, g.lda = ld_q, g.W = q.weight, g.bias = q.bias;
+            g.Y = out, g.ldy = ldo, g.M = (int)bs, g.N = q.out_dim, g.K = q.in_dim, g.relu = 1;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "Q hidden")) return st;
+            GemmArgs h;
+            h.A = in_v, h.lda = ld_v, h.W = v.weight, h.bias = v.bias;
+            h.Y = out + q.out_dim, h.ldy = ldo, h.M = (int)bs, h.N = v.out_dim, h.K = v.in_dim, h.relu = 1;
+            if (mel_status st = launch_gemm(h, GEMM_MODE_PLAIN, s, "V hidden")) return st;
+        }
+        in_q = out, in_v = out + q.out_dim, ld_q = ld_v = ldo;
+    }
+    const mel_linear& ql = w->q_head.layer[nl - 1];
+    const mel_linear& vl = w->v_head.layer[nl - 1];
+    hipLaunchKernelGGL(dueling_tail_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
+                       vl.in_dim, ql, vl, (int)bs, w->dueling, logits);
+    return check_launch("dueling tail");
+}
+
+}  // namespace mel
+
+using namespace mel;
+
+extern "C" {
+
+const char* mel_last_error(void) { return g_err; }
+const char* mel_version(void) { return "melissa_hip 0.1 (gfx950)"; }
+
+size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {
+    if (!w || bs <= 0 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return 0;
+    return carve(w, bs, n_nodes, nullptr).bytes;
+}
+
+mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_width,
+                            float* logits, void* workspace, size_t ws_bytes, void* stream) {
+    if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_width)) return st;
+    if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
+    const FwdLayout L = carve(w, bs, n, workspace);
+    if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int node_cols = w->in_dim + 3;
+    const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
+    const int M = (int)(bs * n);
+    const int cap1 = n < 34 ? n : 34;
+    const int R1 = (int)bs * cap1;
+    const int latent = hidden + 2 * hc;
+
+    hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 1);
+    if (mel_status st = check_launch("plan_masks")) return st;
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
+    if (mel_status st = check_launch("plan_scan")) return st;
+    hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan);
+    if (mel_status st = check_launch("plan_lists")) return st;
+
+    {   // encoder on the closed two-hop rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
+        GemmArgs g;
+        g.obs = obs, g.obs_width = obs_width, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
+        g.nid = L.plan.nid2, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
+        g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
+        g.Y = L.h0, g.ldy = hidden, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hidden;
+        g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
+    }
+    {   // conv1.lin_l on the two-hop rows, conv1.lin_r on the one-hop rows
+        GemmArgs g;
+        g.A = L.h0, g.lda = hidden, g.W = w->conv1.lin_l.weight, g.bias = w->conv1.lin_l.bias;
+        g.Y = L.xl1, g.ldy = hc, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hc, g.K = hidden;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l")) return st;
+        GemmArgs r;
+        r.A = L.h0, r.lda = hidden, r.arow = L.plan.arow1, r.W = w->conv1.lin_r.weight, r.bias = w->conv1.lin_r.bias;
+        r.Y = L.xr1, r.ldy = hc, r.M = R1, r.M_dev = L.plan.off1 + bs, r.N = hc, r.K = hidden;
+        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r")) return st;
+    }
+    {   // conv1 attention for the one-hop targets; also drops x_1 and x_2 into the head input
+        AttArgs a{};
+        a.xl = L.xl1, a.ld_l = hc, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
+        a.adj = L.plan.adj, a.gidx = L.plan.gidx, a.tmask = L.plan.s1, a.smask = L.plan.s2;
+        a.toff = L.plan.off1, a.soff = L.plan.off2, a.bs = (int)bs, a.n = n;
+        a.lanes_per_head = w->conv1.channels / (hc / 64);
+        a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
+        if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
+    }
+    {   // conv2 projections; the decision-maker mask (l_dgn.py:128) rides along as a row scale
+        GemmArgs g;
+        g.A = L.h1, g.lda = hc, g.rscale = L.plan.dm1, g.W = w->conv2.lin_l.weight, g.bias = w->conv2.lin_l.bias;
+        g.Y = L.xl2, g.ldy = hc, g.M = R1, g.M_dev = L.plan.off1 + bs, g.N = hc, g.K = hc;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l")) return st;
+        GemmArgs r;
+        r.A = L.h1, r.lda = hc, r.arow = L.plan.arow_g, r.rscale = L.plan.dm_g;
+        r.W = w->conv2.lin_r.weight, r.bias = w->conv2.lin_r.bias;
+        r.Y = L.xr2, r.ldy = hc, r.M = (int)bs, r.N = hc, r.K = hc;
+        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv2.lin_r")) return st;
+    }
+    {   // conv2 attention for the controlling agent only -> x_3
+        AttArgs a{};
+        a.xl = L.xl2, a.ld_l = hc, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
+        a.adj = L.plan.adj, a.gidx = L.plan.gidx, a.smask = L.plan.s1, a.soff = L.plan.off1;
+        a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
+        a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
+        if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
+    }
+    return run_heads(w, L, bs, logits, s);
+}
+
+mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
+                             int32_t obs_width, float* logits, void* workspace, size_t ws_bytes, void* stream) {
+    if (mel_status st = validate(w, MEL_MODEL_HLDGN, bs, n, obs_width)) return st;
+    if (aggregator < MEL_AGG_MAX || aggregator > MEL_AGG_ADD) return fail(MEL_ERR_INVALID_ARG, "aggregator %d", aggregator);
+    if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
+    const FwdLayout L = carve(w, bs, n, workspace);
+    if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int node_cols = w->in_dim + 3;
+    const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
+    const int M = (int)(bs * n);
+
+    hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 0);
+    if (mel_status st = check_launch("plan_masks")) return st;
+    {
+        GemmArgs g;
+        g.obs = obs, g.obs_width = obs_width, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
+        g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
+        g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
+        g.Y = L.h0, g.ldy = hidden, g.M = M, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
+    }
+    {   // x_l | x_r for every node in one GEMM (weights split along n)
+        GemmArgs g;
+        g.A = L.h0, g.lda = hidden;
+        g.W = w->conv1.lin_l.weight, g.W_hi = w->conv1.lin_r.weight;
+        g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
+        g.Y = L.xl1, g.ldy = 2 * hc, g.M = M, g.N = 2 * hc, g.K = hidden;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l|lin_r")) return st;
+    }
+    {
+        AttArgs a{};
+        a.xl = L.xl1, a.ld_l = 2 * hc, a.xr = L.xl1 + hc, a.ld_r = 2 * hc;
+        a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj, a.gidx = L.plan.gidx;
+        a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
+        a.obs = obs, a.obs_width = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
+        a.pooled = L.xcat;
+        if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
+    }
+    return run_heads(w, L, bs, logits, s);
+}
+
+mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n, const void* workspace,
+                           void* out, void* stream) {
+    if (!w || !workspace || !out || bs <= 0 || n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "bad tap arguments");
+    const FwdLayout L = carve(w, bs, n, const_cast<void*>(workspace));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (kind == 0)
+        e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+    else if (kind == 1)
+        e = hipMemcpyAsync(out, L.xcat, (size_t)bs * w->q_head.layer[0].in_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+    else
+        return fail(MEL_ERR_INVALID_ARG, "unknown tap kind %d", kind);
+    if (e != hipSuccess) return fail(MEL_ERR_LAUNCH, "tap copy: %s", hipGetErrorString(e));
+    return MEL_OK;
+}
+
+mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t bs, int32_t na, float eps,
+                             const float* rand_u, const float* rand_q, int32_t* act, void* scratch, void* stream) {
+    if (!logits || !act || bs <= 0 || na < 1) return fail(MEL_ERR_INVALID_ARG, "bad select_action arguments");
+    if (mask && !scratch) return fail(MEL_ERR_INVALID_ARG, "masking needs 8 bytes of scratch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mask) {
+        hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, s, logits, (long)bs * na, static_cast<float*>(scratch));
+        if (mel_status st = check_launch("minmax")) return st;
+    }
+    hipLaunchKernelGGL(select_action_kernel, dim3((bs + 255) / 256), dim3(256), 0, s, logits, mask, (long)bs, na, eps,
+                       rand_u, rand_q, static_cast<const float*>(scratch), act);
+    return check_launch("select_action");
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// Row GEMM on the exact-fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32):
+//
+//     Y[m, n] = act( rscale[m] * sum_k A(m, k) * W[n, k] + bias[n] )
+//
+// This is every dense projection of the hot path: the encoder MLP (l_dgn.py:49-54,117), lin_l / lin_r
+// of both GATv2Conv layers (l_dgn.py:56-65) and the hidden layers of the dueling heads
+// (l_dgn.py:85-86).  Both operands are K-contiguous exactly as PyTorch stores them (activations
+// [rows, K], nn.Linear.weight [out, K]), so no transposed copies exist anywhere.
+//
+// Layout / mapping:
+//   * one wavefront owns a 64x64 output sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs);
+//     a workgroup is WM x WN wavefronts -> BM = 64*WM rows by BN = 64*WN columns, K step 32;
+//   * tiles are staged global -> registers -> LDS with 16-byte accesses; LDS rows are padded to 36
+//     floats (144 B) so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B slots;
+//   * the k order inside a K step is permuted identically for A and W (lane half h takes k = 8q+4h..+3
+//     of sub-step q), which lets one ds_read_b128 per operand feed four MFMAs;
+//   * the next K step's global loads are issued before the current step's MFMAs (register prefetch);
+//   * optional A-row gather (arow), per-row scale (the decision-maker mask of l_dgn.py:128 commutes
+//     with the projection), split weight/bias pointers (lin_l | lin_r, Q | V stacked along n), and an
+//     on-the-fly producer for the first encoder layer (K = in_dim is far too short for an MFMA).
+//   * the row count may live on the device (M_dev): ragged receptive-field row lists are sized by a
+//     device-side scan, the grid is sized for the worst case and surplus workgroups exit at once.
+#pragma once
+#include "common.hpp"
+
+namespace mel {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    // A operand
+    const float* A = nullptr;      // [rows, lda]
+    int lda = 0;
+    const int32_t* arow = nullptr;  // optional: A row of output row m (identity when null)
+    const float* rscale = nullptr;  // optional: per output row scale (applied before the bias)
+    // encoder-layer-0 producer (MODE_ENC): A(m, k) = relu(enc_b[k] + sum_f enc_w[k, f] * x_f(node m))
+    const float* obs = nullptr;     // [bs, obs_width]
+    int obs_width = 0, n_nodes = 0, in_dim = 0, node_cols = 0;
+    const int32_t* nid = nullptr;   // optional: global node id (b*N + i) of row m (identity when null)
+    const float* enc_w = nullptr;   // [K, in_dim]
+    const float* enc_b = nullptr;   // [K]
+    // W operand, rows [0, split_n) from W / bias, rows [split_n, N) from W_hi / bias_hi
+    const float* W = nullptr;
+    const float* W_hi = nullptr;
+    const float* bias = nullptr;
+    const float* bias_hi = nullptr;
+    int split_n = 0;
+    // output
+    float* Y = nullptr;
+    int ldy = 0;
+    int M = 0;                      // rows the grid covers
+    const int32_t* M_dev = nullptr; // optional device-side row count (<= M)
+    int N = 0, K = 0;
+    int relu = 0;
+};
+
+constexpr int GEMM_BK = 32;
+constexpr int GEMM_LDS_STRIDE = GEMM_BK + 4;   // floats; 144-byte rows
+
+enum { GEMM_MODE_PLAIN = 0, GEMM_MODE_ENC = 1 };
+
+template <int WM, int WN, int MODE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, T = 64 * WM * WN;
+    constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;   // float4 chunks per thread per K step
+    constexpr int W_CHUNKS = BN * (GEMM_BK / 4) / T;
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * GEMM_LDS_STRIDE];
+    float* As = lds;
+    float* Ws = lds + BM * GEMM_LDS_STRIDE;
+
+    // XCD-aware tile order: workgroups that share an A row panel (same m tile, different n tile)
+    // get consecutive ids on one XCD so the panel is fetched into one L2 only.
+    const int nbn = g.N / BN;
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+    const int m0 = (wg / nbn) * BM;
+    const int n0 = (wg % nbn) * BN;
+    const int M = g.M_dev ? min(*g.M_dev, g.M) : g.M;
+    if (m0 >= M) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int r = lane & 31, h = lane >> 5;
+
+    // per-thread staging chunk coordinates (constant across K steps)
+    const float* a_src[A_CHUNKS];
+    bool a_ok[A_CHUNKS];
+    float enc_x[MODE == GEMM_MODE_ENC ? A_CHUNKS : 1][8];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+        const int c = tid + i * T;
+        const int row = m0 + (c >> 3);
+        a_ok[i] = row < M;
+        a_src[i] = nullptr;
+        if (MODE == GEMM_MODE_PLAIN) {
+            if (a_ok[i]) {
+                const int ar = g.arow ? g.arow[row] : row;
+                a_src[i] = g.A + (size_t)ar * g.lda + (c & 7) * 4;
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) enc_x[i][f] = 0.f;
+            if (a_ok[i]) {
+                const int id = g.nid ? g.nid[row] : row;
+                const int b = id / g.n_nodes, node = id - b * g.n_nodes;
+                const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+                    if (f < g.in_dim) enc_x[i][f] = x[f];
+            }
+        }
+    }
+    const float* w_src[W_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i) {
+        const int c = tid + i * T;
+        const int n = n0 + (c >> 3);
+        const float* base = (g.W_hi && n >= g.split_n) ? g.W_hi + (size_t)(n - g.split_n) * g.K
+                                                        : g.W + (size_t)n * g.K;
+        w_src[i] = base + (c & 7) * 4;
+    }
+
+    float4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            if (MODE == GEMM_MODE_PLAIN) {
+                a_reg[i] = a_ok[i] ? *reinterpret_cast<const float4*>(a_src[i] + k0)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int kc = k0 + ((tid + i * T) & 7) * 4;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float s = g.enc_b[kc + e];
+                    const float* wrow = g.enc_w + (size_t)(kc + e) * g.in_dim;
+#pragma unroll
+                    for (int f = 0; f < 8; ++f)
+                        if (f < g.in_dim) s = fmaf(wrow[f], enc_x[i][f], s);
+                    v[e] = a_ok[i] ? fmaxf(s, 0.f) : 0.f;
+                }
+                a_reg[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const float4*>(w_src[i] + k0);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int c = tid + i * T;
+            *reinterpret_cast<float4*>(As + (c >> 3) * GEMM_LDS_STRIDE + (c & 7) * 4) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) {
+            const int c = tid + i * T;
+            *reinterpret_cast<float4*>(Ws + (c >> 3) * GEMM_LDS_STRIDE + (c & 7) * 4) = w_reg[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const float* a_frag = As + (wm * 64 + r) * GEMM_LDS_STRIDE + 4 * h;
+    const float* w_frag = Ws + (wn * 64 + r) * GEMM_LDS_STRIDE + 4 * h;
+
+    const int KT = g.K / GEMM_BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_tile((kt + 1) * GEMM_BK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const float4*>(a_frag + t * 32 * GEMM_LDS_STRIDE + q * 8);
+                b[t] = *reinterpret_cast<const float4*>(w_frag + t * 32 * GEMM_LDS_STRIDE + q * 8);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            reinterpret_cast<const float*>(&a[i])[kk],
+                            reinterpret_cast<const float*>(&b[j])[kk], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < KT) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n]
+                                                         : (g.bias ? g.bias[n] : 0.f);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M) {
+                    float v = acc[i][j][e];
+                    if (g.rscale) v *= g.rscale[m];
+                    v += bias;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.Y[(size_t)m * g.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what);
+
+}  // namespace mel

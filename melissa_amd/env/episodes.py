@@ -1,0 +1,146 @@
+"""Host-side episode sampling and packing.
+
+``World.reset`` (graph_env/env/utils/core.py:343-437) draws, per episode, an episode seed from the
+env's PCG64 generator, then - from ``RandomState(episode_seed)`` - the movement seed, the source node,
+the interest density and the interested set; node movement later consumes
+``RandomState(movement_seed).uniform(-1, 1)`` N x-draws then N y-draws per world step
+(core.py:316-319).  ``EpisodeSampler.sample()`` performs exactly those calls in that order and
+``pack_episodes`` lays the result out as the device-resident pool of include/melissa_hip.h
+(``mel_episode_pool``): the packed replacement of the reference's per-episode ``pickle.load`` of an
+``nx.Graph`` (core.py:450-452).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+RADIUS_OF_INFLUENCE = 0.20
+NODES_MOVEMENT_STEP = 0.06      # constants.py:4
+
+
+@dataclass
+class Graph:
+    """A graph as the env consumes it: float64 node positions + one-hop bit masks (uint64 per node)."""
+    pos: np.ndarray              # [N, 2] float64
+    one_hop: np.ndarray          # [N] uint64
+
+    @staticmethod
+    def from_positions(pos, radius: float = RADIUS_OF_INFLUENCE) -> "Graph":
+        """nx.random_geometric_graph / geometric_edges rule: edge iff dx^2 + dy^2 <= radius^2 (float64)."""
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 2)
+        dx = pos[:, None, 0] - pos[None, :, 0]
+        dy = pos[:, None, 1] - pos[None, :, 1]
+        within = (dx * dx + dy * dy) <= radius ** 2
+        np.fill_diagonal(within, False)
+        return Graph(pos, adjacency_to_masks(within))
+
+    @staticmethod
+    def from_edges(n: int, edges, pos=None) -> "Graph":
+        adj = np.zeros((n, n), dtype=bool)
+        for u, v in edges:
+            adj[u, v] = adj[v, u] = True
+        return Graph(np.zeros((n, 2)) if pos is None else np.asarray(pos, dtype=np.float64), adjacency_to_masks(adj))
+
+    @staticmethod
+    def from_networkx(g) -> "Graph":
+        n = g.number_of_nodes()
+        pos = np.array([g.nodes[i]["pos"] for i in range(n)], dtype=np.float64)
+        return Graph.from_edges(n, list(g.edges()), pos)
+
+    def is_connected(self) -> bool:
+        n = len(self.one_hop)
+        seen, frontier = 1, 1
+        masks = [int(m) for m in self.one_hop]
+        while frontier:
+            nxt = 0
+            for i in range(n):
+                if (frontier >> i) & 1:
+                    nxt |= masks[i]
+            frontier = nxt & ~seen
+            seen |= nxt
+        return seen == (1 << n) - 1
+
+
+def adjacency_to_masks(adj: np.ndarray) -> np.ndarray:
+    n = adj.shape[0]
+    weights = (np.uint64(1) << np.arange(n, dtype=np.uint64))
+    return (adj.astype(np.uint64) * weights[None, :]).sum(axis=1, dtype=np.uint64)
+
+
+def synthetic_graph_pool(n: int, count: int, first_seed: int = 0, radius: float = RADIUS_OF_INFLUENCE):
+    """Connected random geometric graphs in the unit square (recipe of core.py:440-447).
+    Positions follow ``nx.random_geometric_graph(n, radius, seed=s)`` when networkx is importable
+    (python ``random.Random(s)``: x then y per node), which is what the recipe names."""
+    import random
+    out, s = [], first_seed
+    while len(out) < count:
+        rng = random.Random(s)
+        pos = np.array([[rng.random(), rng.random()] for _ in range(n)], dtype=np.float64)
+        g = Graph.from_positions(pos, radius)
+        if g.is_connected():
+            out.append(g)
+        s += 1
+    return out
+
+
+@dataclass
+class Episode:
+    graph_index: int
+    origin: int
+    interested: int              # bit mask
+    movement_seed: int
+
+
+class EpisodeSampler:
+    """The RNG protocol of World.reset in training mode (core.py:371-395), one instance per env."""
+
+    def __init__(self, n: int, np_random: np.random.Generator, pool_size: int, fixed_graph: bool,
+                 fixed_interest_density=None):
+        self.n, self.np_random, self.pool_size, self.fixed_graph = n, np_random, pool_size, fixed_graph
+        self.fixed_interest_density = fixed_interest_density
+
+    def seed(self, seed=None):
+        self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))   # graph.py:145-146
+
+    def sample(self) -> Episode:
+        n = self.n
+        episode_seed = self.np_random.integers(0, 1e9)                                  # core.py:372
+        ep_rng = np.random.RandomState(episode_seed)                                    # :373
+        graph_index = 0
+        if not self.fixed_graph:                                                        # :377-379
+            graph_index = int(self.np_random.choice(self.pool_size, replace=True))
+        movement_seed = ep_rng.randint(0, 1e9)                                          # :381
+        origin = int(ep_rng.randint(0, n))                                              # :384
+        density = (ep_rng.uniform(0.1, 1.0) if self.fixed_interest_density is None
+                   else self.fixed_interest_density)                                    # :385
+        chosen = ep_rng.choice(n, size=int(density * n), replace=False)                 # :393-394
+        self.np_random.choice(n, size=0, replace=False)                                 # :395 (scripted ratio 0)
+        mask = 0
+        for i in chosen:
+            mask |= 1 << int(i)
+        return Episode(graph_index, origin, mask, int(movement_seed))
+
+
+def movement_offsets(movement_seed: int, n: int, max_moves: int) -> np.ndarray:
+    """[max_moves, 2, N] float64: per world step N x-offsets then N y-offsets, each
+    ``0.06 * RandomState(seed).uniform(-1, 1)`` (core.py:316-319)."""
+    rs = np.random.RandomState(movement_seed)
+    return NODES_MOVEMENT_STEP * rs.uniform(-1, 1, size=(max_moves, 2, n))
+
+
+def pack_episodes(episodes, graphs, n: int, max_moves: int, dynamic: bool):
+    """-> dict of numpy arrays in mel_episode_pool layout."""
+    e = len(episodes)
+    pos = np.zeros((e, n, 2), dtype=np.float64)
+    one_hop = np.zeros((e, n), dtype=np.uint64)
+    interested = np.zeros(e, dtype=np.uint64)
+    origin = np.zeros(e, dtype=np.int32)
+    moves = np.zeros((e, max_moves if dynamic else 1, 2, n), dtype=np.float64)
+    for k, ep in enumerate(episodes):
+        g = graphs[ep.graph_index]
+        pos[k], one_hop[k] = g.pos, g.one_hop
+        interested[k], origin[k] = np.uint64(ep.interested), ep.origin
+        if dynamic:
+            moves[k] = movement_offsets(ep.movement_seed, n, max_moves)
+    return dict(pos=pos, one_hop=one_hop, interested=interested, origin=origin, moves=moves)

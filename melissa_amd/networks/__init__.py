@@ -1,0 +1,4 @@
+from .hl_dgn import HLDGNNetwork
+from .l_dgn import LDGNNetwork
+
+__all__ = ["LDGNNetwork", "HLDGNNetwork"]

@@ -1,0 +1,238 @@
+"""Host-side pieces shared by the network drop-ins.
+
+Mirrors graph_env/env/utils/networks/common.py (``build_pyg_batch_time``: shape checks, unpack) and
+the [3P] modules the reference networks are assembled from (tianshou ``MLP``, PyG ``GATv2Conv``) -
+only as *parameter containers with the same state_dict keys*; inference arithmetic is in the HIP
+library.  ``torch_forward`` is the autograd formulation used on the learn path (policy.learn needs
+gradients; backward kernels are a later round).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+RADIUS_OF_INFLUENCE = 0.20      # graph_env/env/utils/constants.py:1
+MAX_NUM_NEIGHBORS = 32
+
+
+class MLP(nn.Module):
+    """Parameter-compatible with tianshou 1.0.0 ``MLP`` (state_dict keys ``model.{0,2,4}.*``):
+    Linear, ReLU, ..., Linear with no activation after the last layer."""
+
+    def __init__(self, input_dim: int, output_dim: int = 0, hidden_sizes: Sequence[int] = (),
+                 device="cpu", **_ignored):
+        super().__init__()
+        self.device = device
+        sizes = [input_dim, *hidden_sizes]
+        layers = []
+        for i, o in zip(sizes[:-1], sizes[1:]):
+            layers += [nn.Linear(i, o), nn.ReLU()]
+        if output_dim > 0:
+            layers += [nn.Linear(sizes[-1], output_dim)]
+        self.output_dim = output_dim or sizes[-1]
+        self.model = nn.Sequential(*layers)
+
+    def linears(self):
+        return [m for m in self.model if isinstance(m, nn.Linear)]
+
+    def forward(self, obs):
+        obs = torch.as_tensor(obs, device=self.device, dtype=torch.float32)
+        return self.model(obs.flatten(1))
+
+
+class GATv2Conv(nn.Module):
+    """Parameter container with PyG 2.2 ``GATv2Conv`` names/shapes/initialisation:
+    ``att [1,H,C]``, ``bias [H*C]``, ``lin_l`` / ``lin_r`` Linear(in, H*C) with bias."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.lin_l = nn.Linear(in_channels, heads * out_channels)
+        self.lin_r = nn.Linear(in_channels, heads * out_channels)
+        self.att = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.empty(heads * out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in (self.lin_l, self.lin_r):      # glorot weight, PyG Linear default bias
+            a = math.sqrt(6.0 / (lin.in_features + lin.out_features))
+            nn.init.uniform_(lin.weight, -a, a)
+            nn.init.uniform_(lin.bias, -1.0 / math.sqrt(lin.in_features), 1.0 / math.sqrt(lin.in_features))
+        a = math.sqrt(6.0 / (self.heads + self.out_channels))
+        nn.init.uniform_(self.att, -a, a)
+        nn.init.zeros_(self.bias)
+
+
+def check_obs(obs: torch.Tensor, input_dim: int, agents_num: int):
+    """The two shape errors of build_pyg_batch_time (networks/common.py:20-29)."""
+    if obs.ndim != 2:
+        raise ValueError(f"Expected obs to be 2D, but got shape {obs.shape}")
+    expected = agents_num * (input_dim + 2 + 1)
+    if obs.shape[1] - 1 != expected:
+        raise ValueError(f"Expected {expected} feature cols for nodes, got {obs.shape[1] - 1}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# ctypes views of the parameters (borrowed pointers: optimizer steps / load_state_dict are seen with
+# no copy; the struct is rebuilt only if a storage moved)
+# ---------------------------------------------------------------------------------------------------
+def _lin(struct: _lib.MelLinear, lin: nn.Linear):
+    struct.weight = lin.weight.data_ptr()
+    struct.bias = lin.bias.data_ptr()
+    struct.in_dim, struct.out_dim = lin.in_features, lin.out_features
+
+
+def _mlp(struct: _lib.MelMlp, linears):
+    if len(linears) > _lib.MAX_HEAD_LAYERS:
+        raise RuntimeError(f"MLP depth {len(linears)} > {_lib.MAX_HEAD_LAYERS}")
+    struct.n_layers = len(linears)
+    for k, lin in enumerate(linears):
+        _lin(struct.layer[k], lin)
+
+
+def _gat(struct: _lib.MelGatv2, conv: GATv2Conv):
+    _lin(struct.lin_l, conv.lin_l)
+    _lin(struct.lin_r, conv.lin_r)
+    struct.att, struct.bias = conv.att.data_ptr(), conv.bias.data_ptr()
+    struct.heads, struct.channels = conv.heads, conv.out_channels
+
+
+class HipForwardMixin:
+    """Shared machinery of the two network drop-ins: parameter views, workspace, dispatch."""
+
+    _MODEL = None          # set by subclasses
+
+    def _param_key(self):
+        return tuple((p.data_ptr(), p.dtype, p.is_contiguous()) for p in self.parameters())
+
+    def _weights(self) -> _lib.MelWeights:
+        key = self._param_key()
+        cached = getattr(self, "_w_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        for name, p in self.named_parameters():
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be contiguous float32 for the HIP path")
+        w = _lib.MelWeights()
+        w.model, w.in_dim, w.n_actions = self._MODEL, self.input_dim, self.output_dim
+        _mlp(w.encoder, self.encoder.linears())
+        _gat(w.conv1, self.conv1)
+        if self._MODEL == _lib.MODEL_LDGN:
+            _gat(w.conv2, self.conv2)
+        if self.use_dueling:
+            w.dueling = 1
+            _mlp(w.q_head, self.Q.linears())
+            _mlp(w.v_head, self.V.linears())
+        else:
+            w.dueling = 0
+            _mlp(w.q_head, [self.out_linear])
+            _mlp(w.v_head, [self.out_linear])     # ignored by the kernels when dueling == 0
+            w.v_head.layer[0].out_dim = 1
+        self._w_cache = (key, w)
+        return w
+
+    def _workspace(self, w, bs: int, device) -> torch.Tensor:
+        lib = _lib.load()
+        need = int(lib.mel_workspace_bytes(C.byref(w), bs, self.agents_num))
+        if need == 0:
+            raise RuntimeError("mel_workspace_bytes rejected the configuration")
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws = ws
+        return ws
+
+    def hip_forward(self, obs: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Inference through libmelissa_hip.so on the current HIP stream.  obs: CUDA float32 [bs, 8N+1]."""
+        lib = _lib.load()
+        if not obs.is_cuda:
+            raise RuntimeError("the HIP forward needs the observation on a ROCm device; there is no CPU "
+                               "fallback (use torch_forward for autograd on any device)")
+        obs = obs.contiguous()
+        if obs.dtype != torch.float32:
+            obs = obs.float()
+        bs = obs.shape[0]
+        w = self._weights()
+        ws = self._workspace(w, bs, obs.device)
+        if out is None:
+            out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs.device)
+        stream = _lib.current_stream_ptr(obs.device)
+        if self._MODEL == _lib.MODEL_LDGN:
+            st = lib.mel_ldgn_forward(C.byref(w), obs.data_ptr(), bs, self.agents_num, obs.shape[1],
+                                      out.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        else:
+            st = lib.mel_hldgn_forward(C.byref(w), _lib.AGG[self.aggregator_name], obs.data_ptr(), bs,
+                                       self.agents_num, obs.shape[1], out.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), stream)
+        _lib.check(st, type(self).__name__ + ".forward")
+        return out
+
+    def hip_tap(self, kind: int, bs: int) -> torch.Tensor:
+        """Parity tap after hip_forward: 0 = adjacency masks [bs, N] int64 bit patterns, 1 = head input."""
+        lib = _lib.load()
+        w = self._weights()
+        ws = self._ws
+        if kind == 0:
+            out = torch.empty(bs, self.agents_num, dtype=torch.int64, device=ws.device)
+        else:
+            out = torch.empty(bs, w.q_head.layer[0].in_dim, dtype=torch.float32, device=ws.device)
+        _lib.check(lib.mel_forward_tap(C.byref(w), kind, bs, self.agents_num, ws.data_ptr(), out.data_ptr(),
+                                       _lib.current_stream_ptr(ws.device)), "mel_forward_tap")
+        return out
+
+    def _prepare_obs(self, obs):
+        if isinstance(obs, np.ndarray):                       # l_dgn.py:103-104
+            obs = torch.as_tensor(obs, device=self.device)
+        check_obs(obs, self.input_dim, self.agents_num)
+        return obs
+
+    def _dispatch(self, obs: torch.Tensor) -> torch.Tensor:
+        """HIP kernels for inference; the autograd formulation when a gradient is required."""
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.backend == "torch" or (self.backend == "auto" and needs_grad):
+            return self.torch_forward(obs)
+        return self.hip_forward(obs.to(self.device))
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd formulation (learn path).  Dense per-graph masked attention in plain torch ops.
+# ---------------------------------------------------------------------------------------------------
+def radius_adjacency(pos: torch.Tensor) -> torch.Tensor:
+    """adj[b, i, j]: edge j -> i.  fp32, strict <, first 33 hits per target."""
+    r2 = torch.tensor(RADIUS_OF_INFLUENCE * RADIUS_OF_INFLUENCE, dtype=torch.float64).to(torch.float32).to(pos.device)
+    dx = pos[:, :, None, 0] - pos[:, None, :, 0]
+    dy = pos[:, :, None, 1] - pos[:, None, :, 1]
+    within = (dx * dx + dy * dy) < r2
+    within = within & (torch.cumsum(within.to(torch.int32), dim=2) <= MAX_NUM_NEIGHBORS + 1)
+    eye = torch.eye(pos.shape[1], dtype=torch.bool, device=pos.device)
+    return within & ~eye
+
+
+def gatv2_dense(conv: GATv2Conv, x: torch.Tensor, adj: torch.Tensor) -> torch.Tensor:
+    bs, n, _ = adj.shape
+    h, c = conv.heads, conv.out_channels
+    x_l = conv.lin_l(x).view(bs, n, h, c)
+    x_r = conv.lin_r(x).view(bs, n, h, c)
+    mask = adj | torch.eye(n, dtype=torch.bool, device=adj.device)[None]
+    e = (F.leaky_relu(x_r[:, :, None] + x_l[:, None, :], 0.2) * conv.att[0]).sum(-1)     # [bs, i, j, H]
+    e = e.masked_fill(~mask[..., None], -float("inf"))
+    p = torch.exp(e - e.max(dim=2, keepdim=True).values)
+    p = torch.where(mask[..., None], p, torch.zeros((), device=p.device))
+    alpha = p / (p.sum(dim=2, keepdim=True) + 1e-16)
+    out = torch.einsum("bijh,bjhc->bihc", alpha, x_l)
+    return out.reshape(bs * n, h * c) + conv.bias
+
+
+def unpack(obs: torch.Tensor, input_dim: int, n: int):
+    bs = obs.shape[0]
+    node = obs[:, :-1].reshape(bs, n, input_dim + 3).float()
+    g = obs[:, -1].clamp(0, n - 1).long()
+    return node[:, :, :2], node[:, :, 2:2 + input_dim], node[:, :, -1:], g

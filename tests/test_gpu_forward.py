@@ -1,0 +1,154 @@
+"""GPU parity of the HIP forward (through the C ABI) against the network oracle and the committed
+golden vectors.  Tolerance: 1e-4 absolute on fp32 logits (BASELINE.json north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDENS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "net_golden_*.npz")))
+TOL = 1e-4
+DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
+
+
+def make_net(model, n, seed, agg="max", dueling=True):
+    from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
+    from oracle import net_oracle as no
+    sd = no.init_weights(model, seed=seed, random_conv_bias=True)
+    if model == "l_dgn":
+        net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    else:
+        net = HLDGNNetwork(5, 128, 2, 4, n, aggregator=agg, dueling_param=DUEL(), device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    return net, sd
+
+
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[11:-4] for p in GOLDENS])
+def test_ldgn_matches_golden(path):
+    g = np.load(path)
+    n, obs = int(g["n"]), g["obs"]
+    net, _ = make_net("l_dgn", n, int(g["weight_seed"]))
+    with torch.no_grad():
+        logits, state = net(obs)                       # numpy in, like the reference collector
+    assert state is None and logits.is_cuda and logits.dtype == torch.float32
+    np.testing.assert_allclose(logits.cpu().numpy(), g["ldgn_logits"], atol=TOL, rtol=0)
+    # intermediates: adjacency bit-exact, head input (x_1 | x_2 | x_3) within tolerance
+    adj = net.hip_tap(0, obs.shape[0]).cpu().numpy().view(np.uint64)
+    want = np.unpackbits(g["adj"], axis=-1, bitorder="little")[..., :n].astype(np.uint64)
+    want = (want << np.arange(n, dtype=np.uint64)).sum(axis=-1, dtype=np.uint64)
+    np.testing.assert_array_equal(adj, want)
+    xcat = net.hip_tap(1, obs.shape[0]).cpu().numpy()
+    np.testing.assert_allclose(xcat, np.concatenate([g["ldgn_x_1"], g["ldgn_x_2"], g["ldgn_x_3"]], axis=1),
+                               atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("agg", ["max", "mean", "add"])
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[11:-4] for p in GOLDENS])
+def test_hldgn_matches_golden(path, agg):
+    g = np.load(path)
+    n, obs = int(g["n"]), g["obs"]
+    net, _ = make_net("hl_dgn", n, int(g["weight_seed"]) + 1, agg=agg)
+    with torch.no_grad():
+        logits, state = net(torch.from_numpy(obs).cuda(), state="kept")
+    assert state == "kept"
+    np.testing.assert_allclose(logits.cpu().numpy(), g[f"hldgn_{agg}_logits"], atol=TOL, rtol=0)
+    pooled = net.hip_tap(1, obs.shape[0]).cpu().numpy()
+    np.testing.assert_allclose(pooled, g[f"hldgn_{agg}_pooled"], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn"])
+@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (1, 5), (7, 1)])
+def test_matches_oracle_on_random_batches(model, n, bs):
+    """Fresh seeded inputs at sizes the oracle finishes in seconds (incl. ragged / tiny / max-N cases)."""
+    from oracle import net_oracle as no
+    rng = np.random.RandomState(100 + n + bs)
+    obs = np.zeros((bs, 8 * n + 1), dtype=np.float32)
+    m = obs[:, :-1].reshape(bs, n, 8)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2] = rng.randint(0, 9, size=(bs, n))
+    m[:, :, 3] = rng.randint(0, 4, size=(bs, n))
+    m[:, :, 4:7] = rng.randint(0, 2, size=(bs, n, 3))
+    m[:, :, 7] = (rng.uniform(size=(bs, n)) > 0.1)
+    obs[:, -1] = rng.randint(-1, n + 1, size=bs)        # also exercises the clamp (common.py:63)
+    net, sd = make_net(model, n, seed=31)
+    with torch.no_grad():
+        got = net(obs)[0].cpu().numpy()
+        torch.set_num_threads(8)
+        want = (no.ldgn_forward(sd, obs, n) if model == "l_dgn" else no.hldgn_forward(sd, obs, n)).numpy()
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
+def test_full_size_linearity_property():
+    """BASELINE size (N=50, 1024 rows): property checks that need no oracle run - row independence
+    (a row's logits do not depend on its batch mates / position) and determinism."""
+    n, bs = 50, 1024
+    rng = np.random.RandomState(3)
+    obs = np.zeros((bs, 8 * n + 1), dtype=np.float32)
+    m = obs[:, :-1].reshape(bs, n, 8)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2:7] = rng.randint(0, 3, size=(bs, n, 5))
+    m[:, :, 7] = 1
+    obs[:, -1] = rng.randint(0, n, size=bs)
+    for model in ("l_dgn", "hl_dgn"):
+        net, _ = make_net(model, n, seed=9)
+        t = torch.from_numpy(obs).cuda()
+        with torch.no_grad():
+            a = net(t)[0].clone()
+            b = net(t)[0].clone()
+            perm = torch.randperm(bs, device="cuda")
+            c = net(t[perm])[0]
+            d = net(t[:77])[0]
+        assert torch.equal(a, b)
+        assert torch.equal(a[perm], c)
+        assert torch.equal(a[:77], d)
+        assert torch.isfinite(a).all()
+
+
+def test_shape_errors_and_no_fallback():
+    from melissa_amd.networks import LDGNNetwork
+    net = LDGNNetwork(5, 128, 2, 4, 20, dueling_param=DUEL(), device="cuda", backend="hip")
+    with pytest.raises(ValueError, match="Expected obs to be 2D"):
+        net(np.zeros(161, np.float32))
+    with pytest.raises(ValueError, match="feature cols for nodes"):
+        net(np.zeros((2, 160), np.float32))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        net.hip_forward(torch.zeros(2, 161))
+
+
+def test_non_dueling_head_and_select_action():
+    import ctypes as C
+    from melissa_amd import _lib
+    from melissa_amd.networks import HLDGNNetwork
+    from oracle import net_oracle as no
+    n = 20
+    g = np.load(GOLDENS[1] if "n20" in GOLDENS[1] else GOLDENS[0])
+    obs = g["obs"] if int(g["n"]) == n else None
+    if obs is None:
+        pytest.skip("n20 golden missing")
+    torch.manual_seed(0)
+    net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=None, device="cuda", backend="hip")
+    with torch.no_grad():
+        got = net(obs)[0]
+        want = net.torch_forward(torch.from_numpy(obs).cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=TOL, rtol=0)
+    # DQN masking + argmax + eps-greedy
+    lib = _lib.load()
+    bs = got.shape[0]
+    mask = torch.ones(bs, 2, dtype=torch.uint8, device="cuda")
+    mask[::3] = 0
+    act = torch.empty(bs, dtype=torch.int32, device="cuda")
+    scratch = torch.empty(64, dtype=torch.float32, device="cuda")
+    _lib.check(lib.mel_select_action(got.data_ptr(), mask.data_ptr(), bs, 2, C.c_float(0.0), None, None,
+                                     act.data_ptr(), scratch.data_ptr(), _lib.current_stream_ptr()))
+    want_act = no.dqn_act(got.cpu(), mask.cpu().numpy())
+    assert act.cpu().tolist() == want_act.tolist()
+    ru = torch.rand(bs, device="cuda")
+    rq = torch.rand(bs, 2, device="cuda")
+    _lib.check(lib.mel_select_action(got.data_ptr(), None, bs, 2, C.c_float(0.5), ru.data_ptr(), rq.data_ptr(),
+                                     act.data_ptr(), scratch.data_ptr(), _lib.current_stream_ptr()))
+    base = got.argmax(1)
+    expect = torch.where(ru < 0.5, rq.argmax(1), base)
+    assert act.cpu().tolist() == expect.cpu().tolist()
