@@ -70,8 +70,7 @@ def test_hip_env_trace_in_a_busy_batch():
     venv = build_venv(tr, env_num=9, slot=5)        # env k is seeded seed+k -> slot 5 gets the trace's seed
     n = int(tr["n"])
     rng = np.random.RandomState(0)
-    venv.reset()
-    pz = OneEnvAdapter(venv, 5)
+    venv.reset([i for i in range(9) if i != 5])
 
     class Busy(OneEnvAdapter):
         def step(self, a):
