@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py - agent-decisions/s of the Melissa hot path on MI355X.
+
+One "step" = one collector iteration over one GPU's shard of envs (multi_agent_collector.py:150-308):
+L-DGN forward over B observation rows -> mask/argmax -> env.step (+ last(), + on-device episode reset).
+Workload = BASELINE.json's metric config: L-DGN, 50-node graphs, 1024 vectorised envs per GPU
+(weak scaling: each rank owns its own 1024 envs, no data-path collective), fp32, dynamic graph (the
+reference CLI default, common.py:51), synthetic connected RGGs + seeded random-init weights.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - dominant kernel (by HIP-event time inside the step) vs the fp32 MFMA peak
+  cpu_baseline - the CPU oracle (torch restatement + Python env restatement) on the host cores, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
+HC = HIDDEN * HEADS
+
+
+def dueling():
+    return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
+
+
+def build_workload(device, rank, envs, n_nodes, model_name, seed=9):
+    import torch
+    from melissa_amd.collect import DecisionLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    torch.manual_seed(seed)                                   # default --seed 9, common.py:20
+    if model_name == "l_dgn":
+        net = LDGNNetwork(5, HIDDEN, 2, HEADS, n_nodes, dueling_param=dueling(), device=device, backend="hip")
+    else:
+        net = HLDGNNetwork(5, HIDDEN, 2, HEADS, n_nodes, aggregator="max", dueling_param=dueling(),
+                           device=device, backend="hip")
+    net.eval()
+    graphs = synthetic_graph_pool(n_nodes, 64, first_seed=0)
+    venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device,
+                             max_moves=48, seed=1000 + rank * envs, construct_like_reference=False)
+    policy = DQNPolicy(net)
+    loop = DecisionLoop(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001)   # test eps
+    return net, venv, loop
+
+
+def stage_flops(totals, bs):
+    """ALGORITHMIC FLOPs (2*MAC) per launch of each GEMM stage, from the receptive-field row counts the
+    launch actually processed (pruned work is priced at the pruned count)."""
+    s1, s2 = totals
+    return {
+        "encoder": s2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
+        "conv1_lin": 2.0 * s2 * HC * HIDDEN,
+        "conv1_lin_r": 2.0 * s1 * HC * HIDDEN,
+        "conv2_lin": 2.0 * s1 * HC * HC,
+        "conv2_lin_r": 2.0 * bs * HC * HC,
+        "head_hidden": 2.0 * bs * ((HIDDEN + 2 * HC) * 256 + 2 * 128 * 128),
+    }
+
+
+def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
+    """The CPU oracle timed on the host cores: torch fp32 restatement of the forward (all cores) +
+    step-for-step Python restatement of the env loop, 40 envs (the reference's --training-num)."""
+    import torch
+    from oracle import env_oracle as eo
+    from oracle import net_oracle as no
+    from melissa_amd.env import synthetic_graph_pool
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
+    workers = [eo.OraclePettingZooEnv(eo.OracleGraphEnv(
+        n_nodes, graph_pool=pool, dynamic_graph=True,
+        np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(1000 + k))))) for k in range(envs)]
+    sd = no.init_weights("l_dgn", seed=9)
+    obs = [w.reset()[0] for w in workers]
+    decisions, iters = 0, 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t0 < budget_s:
+            batch = np.stack([o["obs"] for o in obs])
+            act = no.dqn_act(no.ldgn_forward(sd, batch, n_nodes), np.stack([o["mask"] for o in obs])).numpy()
+            for k, w in enumerate(workers):
+                live = bool(obs[k]["mask"][0])
+                o, _r, term, _tr, info = w.step(int(act[k]))
+                decisions += int(live)
+                if term and info.get("explicit_reset"):
+                    o, _ = w.reset()
+                obs[k] = o
+            iters += 1
+    dt = time.perf_counter() - t0
+    return {"value": decisions / dt, "unit": "agent-decisions/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} collector iterations over {envs} envs ({decisions} live decisions, {dt:.1f} s): "
+                      f"oracle L-DGN forward (torch CPU fp32, {cores} threads) + Python env restatement, "
+                      f"N={n_nodes}, dynamic graph"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
+    ap.add_argument("--nodes", type=int, default=N_NODES)
+    ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from melissa_amd import _lib, parallel
+    rank, local_rank, world = parallel.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model)
+    lib = _lib.load()
+
+    loop.run(args.warmup)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    c0 = loop.counters()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    loop.run(args.steps)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    c1 = loop.counters()
+    dt = parallel.all_reduce_max(dt, device)
+    decisions = parallel.all_reduce_sum(float(c1["decisions"] - c0["decisions"]), device)
+    episodes = parallel.all_reduce_sum(float(c1["episodes"] - c0["episodes"]), device)
+    errors = parallel.all_reduce_sum(float(c1["errors"]), device)
+
+    # ---- per-stage HIP-event timing of the same step (separate, untimed pass) ----------------------
+    roofline, stages = None, None
+    if not args.no_profile and rank == 0:
+        prof = lib.mel_prof_create(args.steps * 16)
+        totals = torch.zeros(args.steps, 2, dtype=torch.int32, device=device)
+        lib.mel_prof_attach(prof)
+        for k in range(args.steps):
+            loop.step()
+            if args.model == "l_dgn":
+                _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, net._ws.data_ptr(),
+                                               totals[k].data_ptr(), _lib.current_stream_ptr(device)))
+        lib.mel_prof_attach(None)
+        torch.cuda.synchronize()
+        ms = (C.c_double * _lib.N_STAGES)()
+        cnt = (C.c_int64 * _lib.N_STAGES)()
+        lib.mel_prof_read(prof, ms, cnt)
+        lib.mel_prof_destroy(prof)
+        stages = {name: (ms[i] / cnt[i] * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}   # us
+        mean_tot = totals.double().mean(dim=0).cpu().numpy() if args.model == "l_dgn" else (0.0, float(args.envs * args.nodes))
+        if args.model == "hl_dgn":
+            fl = {"encoder": args.envs * args.nodes * 34048.0, "conv1_lin": 2.0 * args.envs * args.nodes * 2 * HC * HIDDEN,
+                  "head_hidden": 2.0 * args.envs * (HC * 256 + 2 * 128 * 128)}
+        else:
+            fl = stage_flops(mean_tot, args.envs)
+        dom = max(fl, key=lambda k: stages.get(k, 0.0))
+        achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": f"gemm_f32_kernel ({dom})", "achieved": round(achieved, 3),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": None, "avg_launch_us": round(stages[dom], 2),
+                    "algorithmic_flops_per_launch": fl[dom],
+                    "rows_per_launch": {"sum_S1": float(mean_tot[0]), "sum_S2": float(mean_tot[1])}}
+
+    parallel.barrier()
+    if rank != 0:
+        return
+    value = decisions / dt
+    line = {
+        "metric": "env-steps/s (agent-decisions/s) L-DGN 50-node" if args.model == "l_dgn" and args.nodes == 50
+                  else f"env-steps/s (agent-decisions/s) {args.model} {args.nodes}-node",
+        "value": value, "unit": "agent-decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs "
+                               f"per GPU, fp32, dynamic graph, eps=0.001",
+                   "envs_per_gpu": args.envs, "n_nodes": args.nodes, "global_envs": args.envs * world,
+                   "parallelism": f"env-shard x{world} (no data-path collective)",
+                   "rows_per_step": args.envs * world, "live_decisions": decisions, "episodes_finished": episodes,
+                   "env_error_flags": errors},
+        "roofline": roofline,
+        "stage_us": {k: round(v, 2) for k, v in (stages or {}).items() if v > 0},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.nodes)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

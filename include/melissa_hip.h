@@ -107,7 +107,8 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 
 /* Debug/parity taps: copies of intermediates after a forward with the same workspace.
  * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
- *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108).
+ *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),
+ *       2 = int32 [2]: rows of the L-DGN receptive-field lists (sum |S1|, sum |S2|) the GEMMs processed.
  * `out` is a device pointer with room for the requested tensor. */
 mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n_nodes,
                            const void* workspace, void* out, void* stream);
@@ -236,6 +237,35 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
 /* last() only (mutates is_new_round exactly like GraphEnv.observe, graph.py:205-211). */
 mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n,
                            const mel_env_obs* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optional stage timer: while a profiler is attached to the calling thread, every launch group of the
+ * entry points above is bracketed by a pair of HIP events recorded on the caller's stream
+ * (measurement only - bench.py uses it for the live per-kernel roofline; nothing else in the library
+ * creates events or synchronises).  mel_prof_read synchronises on the recorded events.
+ * ------------------------------------------------------------------------------------------------ */
+#define MEL_STAGE_PLAN          0   /* plan_masks + plan_scan + plan_lists                       */
+#define MEL_STAGE_ENCODER       1   /* encoder GEMM (layer 0 fused into the A-tile producer)     */
+#define MEL_STAGE_CONV1_LIN     2   /* conv1.lin_l (+ lin_r for HL-DGN, one launch)              */
+#define MEL_STAGE_CONV1_LIN_R   3   /* conv1.lin_r (L-DGN one-hop rows)                          */
+#define MEL_STAGE_CONV1_ATT     4   /* conv1 edge-softmax / aggregate (+ pool for HL-DGN)        */
+#define MEL_STAGE_CONV2_LIN     5   /* conv2.lin_l                                               */
+#define MEL_STAGE_CONV2_LIN_R   6   /* conv2.lin_r                                               */
+#define MEL_STAGE_CONV2_ATT     7   /* conv2 attention for the controlling agent                 */
+#define MEL_STAGE_HEAD_HIDDEN   8   /* dueling hidden layers                                     */
+#define MEL_STAGE_HEAD_TAIL     9   /* last Linear + q - mean(q) + v                             */
+#define MEL_STAGE_SELECT       10   /* mask + argmax + eps-greedy                                */
+#define MEL_STAGE_ENV_STEP     11   /* env step (+ observe, + auto reset)                        */
+#define MEL_STAGE_ENV_RESET    12
+#define MEL_STAGE_ENV_OBSERVE  13
+#define MEL_N_STAGES           14
+
+void*      mel_prof_create(int32_t capacity);            /* capacity = max recorded launch groups */
+void       mel_prof_destroy(void* prof);
+void       mel_prof_attach(void* prof);                   /* NULL detaches                         */
+void       mel_prof_reset(void* prof);
+/* ms_sum / count: host arrays [MEL_N_STAGES]; returns number of records read (negative on error). */
+int32_t    mel_prof_read(void* prof, double* ms_sum, int64_t* count);
 
 const char* mel_last_error(void);
 const char* mel_version(void);

@@ -21,7 +21,11 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
 # every symbol include/melissa_hip.h declares
 EXPORTS = ("mel_workspace_bytes", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
-           "mel_env_observe", "mel_last_error", "mel_version")
+           "mel_env_observe", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
+           "mel_prof_read", "mel_last_error", "mel_version")
+N_STAGES = 14
+STAGE_NAMES = ("plan", "encoder", "conv1_lin", "conv1_lin_r", "conv1_att", "conv2_lin", "conv2_lin_r", "conv2_att",
+               "head_hidden", "head_tail", "select", "env_step", "env_reset", "env_observe")
 
 
 class MelLinear(C.Structure):
@@ -112,6 +116,16 @@ def load(build_if_missing: bool = True):
     lib.mel_env_step.argtypes = [E, P, vp, vp, i64, O, vp, i32, vp]
     lib.mel_env_observe.restype = i32
     lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
+    lib.mel_prof_create.restype = vp
+    lib.mel_prof_create.argtypes = [i32]
+    lib.mel_prof_destroy.restype = None
+    lib.mel_prof_destroy.argtypes = [vp]
+    lib.mel_prof_attach.restype = None
+    lib.mel_prof_attach.argtypes = [vp]
+    lib.mel_prof_reset.restype = None
+    lib.mel_prof_reset.argtypes = [vp]
+    lib.mel_prof_read.restype = i32
+    lib.mel_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 

@@ -1,0 +1,78 @@
+"""The collector hot loop, device resident.
+
+Reference: ``MultiAgentCollector.collect``'s ``while True`` loop (multi_agent_collector.py:150-308):
+one iteration = policy forward over the ready envs -> eps-greedy -> ``env.step`` -> next obs, with a
+host<->device round trip and O(envs) Python bookkeeping per iteration.  ``DecisionLoop`` runs the same
+iteration as a fixed sequence of HIP launches on one stream with no host synchronisation:
+
+    obs [B, 8N+1] (HBM) -> mel_{l,hl}dgn_forward -> logits -> mel_select_action -> act
+        -> mel_env_step (+ last() + on-device episode reset) -> obs (same buffer)
+
+Finished episodes are re-seeded on the device from a pre-sampled episode pool (the packed replacement
+of the reference's per-reset pickle.load + RNG draws).  Replay-buffer routing
+(multi_agent_collector.py:229-271) is not part of this loop.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .env.episodes import EpisodeSampler, pack_episodes
+from .env.vector_env import HipGraphVectorEnv, ObsBuffers
+
+
+def sample_episode_table(venv: HipGraphVectorEnv, episodes_per_env: int, seed: int = 0):
+    """Pre-draw ``episodes_per_env`` episodes for every env with the reference's RNG protocol (env k's
+    generator seeded ``seed + k``) -> (packed pool dict, episode_table int32 [B, K])."""
+    episodes, table = [], np.zeros((venv.env_num, episodes_per_env), dtype=np.int32)
+    for b in range(venv.env_num):
+        sampler = EpisodeSampler(venv.n, np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))),
+                                 len(venv.graphs), venv.fixed_graph)
+        for k in range(episodes_per_env):
+            table[b, k] = len(episodes)
+            episodes.append(sampler.sample())
+    packed = pack_episodes(episodes, venv.graphs, venv.n, venv.max_moves, venv.dynamic_graph)
+    return packed, table
+
+
+class DecisionLoop:
+    def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
+                 eps: float = 0.0):
+        self.venv, self.policy, self.eps = venv, policy, eps
+        dev = venv.device
+        packed, table = sample_episode_table(venv, episodes_per_env, seed)
+        self.pool = venv.load_pool(packed)
+        self.table = torch.from_numpy(table).to(dev)
+        self.n_actions = policy.model.output_dim
+        self.obs = torch.empty(venv.env_num, 8 * venv.n + 1, dtype=torch.float32, device=dev)
+        self.out = ObsBuffers(venv.env_num, venv.n, dev, obs=self.obs)
+        self.logits = torch.empty(venv.env_num, self.n_actions, dtype=torch.float32, device=dev)
+        self.act = torch.empty(venv.env_num, dtype=torch.int32, device=dev)
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.iterations = 0
+        venv.reset_device(self.pool, self.table[:, 0].contiguous(), self.out)
+
+    def step(self):
+        """One collector iteration for every env (one agent decision per env)."""
+        net = self.policy.model
+        net.hip_forward(self.obs, out=self.logits)
+        if self.eps > 0.0:
+            rand_u = torch.rand(self.venv.env_num, device=self.obs.device, generator=self.gen)
+            rand_q = torch.rand(self.venv.env_num, self.n_actions, device=self.obs.device, generator=self.gen)
+            self.policy.select_action(self.logits, self.out.action_mask, self.eps, rand_u, rand_q, out=self.act)
+        else:
+            self.policy.select_action(self.logits, self.out.action_mask, out=self.act)
+        self.venv.step_device(self.pool, self.act, self.out, self.table)
+        self.iterations += 1
+
+    def run(self, iterations: int):
+        for _ in range(iterations):
+            self.step()
+
+    def counters(self) -> dict:
+        """Host read of the per-env counters (synchronises)."""
+        sc = self.venv.scalars().cpu().numpy()
+        return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
+                    errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)

@@ -28,6 +28,31 @@ inline mel_status check_launch(const char* what) {
     return MEL_OK;
 }
 
+// ---- optional stage timer (HIP events around each launch group; see mel_prof_* in melissa_hip.h) ----
+struct Profiler {
+    int capacity = 0;
+    int count = 0;
+    hipEvent_t* ev = nullptr;     // 2 per record: begin, end
+    int* stage = nullptr;
+};
+Profiler* current_profiler();
+
+struct StageScope {
+    Profiler* p;
+    hipStream_t s;
+    int idx = -1;
+    StageScope(int stage, hipStream_t stream) : p(current_profiler()), s(stream) {
+        if (p && p->count < p->capacity) {
+            idx = p->count++;
+            p->stage[idx] = stage;
+            (void)hipEventRecord(p->ev[2 * idx], s);
+        }
+    }
+    ~StageScope() {
+        if (idx >= 0) (void)hipEventRecord(p->ev[2 * idx + 1], s);
+    }
+};
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Bump allocator over the caller-provided workspace (256-byte granules).

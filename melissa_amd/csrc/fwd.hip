@@ -15,6 +15,9 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local Profiler* g_prof = nullptr;
+Profiler* current_profiler() { return g_prof; }
+
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------------
@@ -565,6 +568,7 @@ static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t bs
     const float* in_v = L.xcat;
     int ld_q = w->q_head.layer[0].in_dim, ld_v = ld_q;
     for (int i = 0; i + 1 < nl; ++i) {
+        StageScope t(MEL_STAGE_HEAD_HIDDEN, s);
         const mel_linear& q = w->q_head.layer[i];
         const mel_linear& v = w->v_head.layer[i];
         float* out = L.hq[i & 1];
@@ -589,6 +593,7 @@ static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t bs
     }
     const mel_linear& ql = w->q_head.layer[nl - 1];
     const mel_linear& vl = w->v_head.layer[nl - 1];
+    StageScope t(MEL_STAGE_HEAD_TAIL, s);
     hipLaunchKernelGGL(dueling_tail_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
                        vl.in_dim, ql, vl, (int)bs, w->dueling, logits);
     return check_launch("dueling tail");
@@ -622,12 +627,15 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
     const int R1 = (int)bs * cap1;
     const int latent = hidden + 2 * hc;
 
-    hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 1);
-    if (mel_status st = check_launch("plan_masks")) return st;
-    hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
-    if (mel_status st = check_launch("plan_scan")) return st;
-    hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan);
-    if (mel_status st = check_launch("plan_lists")) return st;
+    {
+        StageScope t(MEL_STAGE_PLAN, s);
+        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 1);
+        if (mel_status st = check_launch("plan_masks")) return st;
+        hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
+        if (mel_status st = check_launch("plan_scan")) return st;
+        hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan);
+        if (mel_status st = check_launch("plan_lists")) return st;
+    }
 
     {   // encoder on the closed two-hop rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
         GemmArgs g;
@@ -636,16 +644,21 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
         g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hidden;
         g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        StageScope t(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
     }
     {   // conv1.lin_l on the two-hop rows, conv1.lin_r on the one-hop rows
         GemmArgs g;
         g.A = L.h0, g.lda = hidden, g.W = w->conv1.lin_l.weight, g.bias = w->conv1.lin_l.bias;
         g.Y = L.xl1, g.ldy = hc, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hc, g.K = hidden;
-        if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l")) return st;
+        {
+            StageScope t(MEL_STAGE_CONV1_LIN, s);
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l")) return st;
+        }
         GemmArgs r;
         r.A = L.h0, r.lda = hidden, r.arow = L.plan.arow1, r.W = w->conv1.lin_r.weight, r.bias = w->conv1.lin_r.bias;
         r.Y = L.xr1, r.ldy = hc, r.M = R1, r.M_dev = L.plan.off1 + bs, r.N = hc, r.K = hidden;
+        StageScope t(MEL_STAGE_CONV1_LIN_R, s);
         if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r")) return st;
     }
     {   // conv1 attention for the one-hop targets; also drops x_1 and x_2 into the head input
@@ -655,17 +668,22 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
         a.toff = L.plan.off1, a.soff = L.plan.off2, a.bs = (int)bs, a.n = n;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
+        StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
     }
     {   // conv2 projections; the decision-maker mask (l_dgn.py:128) rides along as a row scale
         GemmArgs g;
         g.A = L.h1, g.lda = hc, g.rscale = L.plan.dm1, g.W = w->conv2.lin_l.weight, g.bias = w->conv2.lin_l.bias;
         g.Y = L.xl2, g.ldy = hc, g.M = R1, g.M_dev = L.plan.off1 + bs, g.N = hc, g.K = hc;
-        if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l")) return st;
+        {
+            StageScope t(MEL_STAGE_CONV2_LIN, s);
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l")) return st;
+        }
         GemmArgs r;
         r.A = L.h1, r.lda = hc, r.arow = L.plan.arow_g, r.rscale = L.plan.dm_g;
         r.W = w->conv2.lin_r.weight, r.bias = w->conv2.lin_r.bias;
         r.Y = L.xr2, r.ldy = hc, r.M = (int)bs, r.N = hc, r.K = hc;
+        StageScope t(MEL_STAGE_CONV2_LIN_R, s);
         if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv2.lin_r")) return st;
     }
     {   // conv2 attention for the controlling agent only -> x_3
@@ -674,6 +692,7 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
         a.adj = L.plan.adj, a.gidx = L.plan.gidx, a.smask = L.plan.s1, a.soff = L.plan.off1;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
         a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
+        StageScope t(MEL_STAGE_CONV2_ATT, s);
         if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
     }
     return run_heads(w, L, bs, logits, s);
@@ -691,14 +710,18 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int M = (int)(bs * n);
 
-    hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 0);
-    if (mel_status st = check_launch("plan_masks")) return st;
+    {
+        StageScope t(MEL_STAGE_PLAN, s);
+        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 0);
+        if (mel_status st = check_launch("plan_masks")) return st;
+    }
     {
         GemmArgs g;
         g.obs = obs, g.obs_width = obs_width, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
         g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
         g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        StageScope t(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
     }
     {   // x_l | x_r for every node in one GEMM (weights split along n)
@@ -707,6 +730,7 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
         g.W = w->conv1.lin_l.weight, g.W_hi = w->conv1.lin_r.weight;
         g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
         g.Y = L.xl1, g.ldy = 2 * hc, g.M = M, g.N = 2 * hc, g.K = hidden;
+        StageScope t(MEL_STAGE_CONV1_LIN, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l|lin_r")) return st;
     }
     {
@@ -716,6 +740,7 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.obs = obs, a.obs_width = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
         a.pooled = L.xcat;
+        StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
     return run_heads(w, L, bs, logits, s);
@@ -731,10 +756,62 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
         e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
     else if (kind == 1)
         e = hipMemcpyAsync(out, L.xcat, (size_t)bs * w->q_head.layer[0].in_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
-    else
+    else if (kind == 2 && w->model == MEL_MODEL_LDGN) {
+        e = hipMemcpyAsync(out, L.plan.off1 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(static_cast<int32_t*>(out) + 1, L.plan.off2 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    } else
         return fail(MEL_ERR_INVALID_ARG, "unknown tap kind %d", kind);
     if (e != hipSuccess) return fail(MEL_ERR_LAUNCH, "tap copy: %s", hipGetErrorString(e));
     return MEL_OK;
+}
+
+void* mel_prof_create(int32_t capacity) {
+    if (capacity < 1) return nullptr;
+    Profiler* p = new Profiler();
+    p->capacity = capacity;
+    p->ev = new hipEvent_t[2 * (size_t)capacity];
+    p->stage = new int[capacity];
+    for (int i = 0; i < 2 * capacity; ++i)
+        if (hipEventCreate(&p->ev[i]) != hipSuccess) {
+            for (int k = 0; k < i; ++k) (void)hipEventDestroy(p->ev[k]);
+            delete[] p->ev;
+            delete[] p->stage;
+            delete p;
+            set_error("hipEventCreate failed");
+            return nullptr;
+        }
+    return p;
+}
+
+void mel_prof_destroy(void* prof) {
+    Profiler* p = static_cast<Profiler*>(prof);
+    if (!p) return;
+    if (g_prof == p) g_prof = nullptr;
+    for (int i = 0; i < 2 * p->capacity; ++i) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev;
+    delete[] p->stage;
+    delete p;
+}
+
+void mel_prof_attach(void* prof) { g_prof = static_cast<Profiler*>(prof); }
+
+void mel_prof_reset(void* prof) {
+    if (prof) static_cast<Profiler*>(prof)->count = 0;
+}
+
+int32_t mel_prof_read(void* prof, double* ms_sum, int64_t* count) {
+    Profiler* p = static_cast<Profiler*>(prof);
+    if (!p || !ms_sum || !count) return fail(MEL_ERR_INVALID_ARG, "bad profiler arguments");
+    for (int k = 0; k < MEL_N_STAGES; ++k) ms_sum[k] = 0.0, count[k] = 0;
+    for (int i = 0; i < p->count; ++i) {
+        if (hipEventSynchronize(p->ev[2 * i + 1]) != hipSuccess) return fail(MEL_ERR_LAUNCH, "event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev[2 * i], p->ev[2 * i + 1]) != hipSuccess) return fail(MEL_ERR_LAUNCH, "event elapsed failed");
+        const int st = p->stage[i];
+        if (st >= 0 && st < MEL_N_STAGES) ms_sum[st] += ms, count[st] += 1;
+    }
+    return p->count;
 }
 
 mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t bs, int32_t na, float eps,
@@ -742,6 +819,7 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
     if (!logits || !act || bs <= 0 || na < 1) return fail(MEL_ERR_INVALID_ARG, "bad select_action arguments");
     if (mask && !scratch) return fail(MEL_ERR_INVALID_ARG, "masking needs 8 bytes of scratch");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    StageScope t(MEL_STAGE_SELECT, s);
     if (mask) {
         hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, s, logits, (long)bs * na, static_cast<float*>(scratch));
         if (mel_status st = check_launch("minmax")) return st;

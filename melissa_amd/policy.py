@@ -1,0 +1,152 @@
+"""Policy side of the drop-in boundary.
+
+* ``DQNPolicy``  - counterpart of [3P] tianshou 1.0.0 ``DQNPolicy`` as the reference uses it
+  (l_dgn.py:70-78): ``forward`` = model -> mask illegal actions -> argmax,
+  ``exploration_noise`` (eps-greedy), target network ``model_old`` (state_dict holds ``model.*`` and
+  ``model_old.*`` like tianshou's), ``learn`` = n-step TD regression with Adam.
+* ``MultiAgentSharedPolicy`` - counterpart of policies/multi_agent_managers/shared_policy.py:14-216.
+  The reference fans the batch out per agent id (N python iterations, shared_policy.py:125-163) and
+  stitches the actions back; all agents share ONE policy, so the result equals one forward over the
+  whole batch - which is what this class does (same ``forward(batch) -> act`` contract).
+
+Inference goes through the HIP kernels (network.hip_forward + mel_select_action); ``learn`` uses the
+autograd formulation of the networks (backward kernels: SURVEY.md 8(f) #4).
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class Batch(dict):
+    """Tiny attribute-dict standing in for tianshou's ``Batch`` at this boundary."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class DQNPolicy(nn.Module):
+    def __init__(self, model: nn.Module, optim: Optional[torch.optim.Optimizer] = None, discount_factor: float = 0.99,
+                 estimation_step: int = 1, target_update_freq: int = 0, is_double: bool = True,
+                 clip_loss_grad: bool = False):
+        super().__init__()
+        self.model = model
+        self.optim = optim
+        self.eps = 0.0
+        self._gamma, self._n_step = discount_factor, estimation_step
+        self._target = target_update_freq > 0
+        self._freq, self._iter = target_update_freq, 0
+        self._is_double, self._clip_loss_grad = is_double, clip_loss_grad
+        if self._target:
+            self.model_old = copy.deepcopy(model)
+            self.model_old.eval()
+        self._scratch = None
+        self.max_action_num = None
+
+    def set_eps(self, eps: float):
+        self.eps = eps
+
+    def sync_weight(self):
+        self.model_old.load_state_dict(self.model.state_dict())
+
+    # ------------------------------------------------------------------ inference
+    def compute_logits(self, obs) -> torch.Tensor:
+        logits, _ = self.model(obs)
+        return logits
+
+    def select_action(self, logits: torch.Tensor, mask: torch.Tensor | None = None, eps: float = 0.0,
+                      rand_u: torch.Tensor | None = None, rand_q: torch.Tensor | None = None,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+        """Device-side mask + argmax (+ eps-greedy when rand_u / rand_q are given)."""
+        lib = _lib.load()
+        bs, na = logits.shape
+        if out is None:
+            out = torch.empty(bs, dtype=torch.int32, device=logits.device)
+        if self._scratch is None or self._scratch.device != logits.device:
+            self._scratch = torch.empty(64, dtype=torch.float32, device=logits.device)
+        _lib.check(lib.mel_select_action(
+            logits.data_ptr(), mask.data_ptr() if mask is not None else None, bs, na, C.c_float(eps),
+            rand_u.data_ptr() if rand_u is not None else None, rand_q.data_ptr() if rand_q is not None else None,
+            out.data_ptr(), self._scratch.data_ptr(), _lib.current_stream_ptr(logits.device)), "mel_select_action")
+        return out
+
+    def forward(self, batch, state=None, model: str = "model", **kwargs) -> Batch:
+        """batch.obs is either a dict/Batch with ``obs`` (+ ``mask``) or the raw observation array."""
+        net = getattr(self, model)
+        obs = batch["obs"] if isinstance(batch, dict) else batch.obs
+        obs_next = obs["obs"] if isinstance(obs, dict) and "obs" in obs else obs
+        logits, hidden = net(obs_next, state=state)
+        mask = obs.get("mask") if isinstance(obs, dict) else None
+        if logits.is_cuda:
+            mask_t = None
+            if mask is not None:
+                mask_t = torch.as_tensor(np.asarray(mask), device=logits.device).to(torch.uint8).contiguous()
+            act = self.select_action(logits, mask_t)
+        else:                                            # learn-path helper on CPU tensors
+            q = logits
+            if mask is not None:
+                m = torch.as_tensor(np.asarray(mask), dtype=q.dtype)
+                q = q + (1 - m) * (q.min() - q.max() - 1.0)
+            act = q.argmax(dim=1).to(torch.int32)
+        return Batch(logits=logits, act=act, state=hidden)
+
+    def exploration_noise(self, act: np.ndarray, batch) -> np.ndarray:
+        """[3P] DQNPolicy.exploration_noise: numpy RNG, same call order as tianshou (A.5)."""
+        if isinstance(act, np.ndarray) and not np.isclose(self.eps, 0.0):
+            bsz = len(act)
+            rand_mask = np.random.rand(bsz) < self.eps
+            q = np.random.rand(bsz, self.max_action_num or 2)
+            obs = batch["obs"] if isinstance(batch, dict) else batch.obs
+            if isinstance(obs, dict) and obs.get("mask") is not None:
+                q += np.asarray(obs["mask"])
+            act[rand_mask] = q.argmax(axis=1)[rand_mask]
+        return act
+
+    # ------------------------------------------------------------------ learning (autograd path)
+    def learn(self, batch, grad_hook=None) -> dict:
+        """One DQN update on ``batch`` = dict(obs, act, returns[, weight]).  ``grad_hook(model)`` runs
+        between backward and the optimizer step (the RCCL gradient all-reduce plugs in here)."""
+        if self._target and self._iter % self._freq == 0:
+            self.sync_weight()
+        self.optim.zero_grad()
+        logits, _ = self.model(batch["obs"])
+        act = torch.as_tensor(batch["act"], device=logits.device, dtype=torch.long)
+        q = logits[torch.arange(len(act), device=logits.device), act]
+        returns = torch.as_tensor(batch["returns"], device=logits.device, dtype=q.dtype).flatten()
+        td = returns - q
+        loss = torch.nn.functional.huber_loss(q, returns) if self._clip_loss_grad else td.pow(2).mean()
+        loss.backward()
+        if grad_hook is not None:
+            grad_hook(self.model)
+        self.optim.step()
+        self._iter += 1
+        return {"loss": float(loss.detach())}
+
+
+class MultiAgentSharedPolicy(nn.Module):
+    """One shared policy for every agent id (shared_policy.py:14-31): ``forward`` returns the actions
+    in the batch's original order, exactly what the reference's split / stitch produces."""
+
+    def __init__(self, policy: DQNPolicy, agents, **_):
+        super().__init__()
+        self.policy = policy
+        self.agents = list(agents)
+        self.agent_idx = {a: i for i, a in enumerate(self.agents)}
+
+    def forward(self, batch, state=None, **kwargs) -> Batch:
+        out = self.policy(batch, state=state, **kwargs)
+        return Batch(act=out.act, state=out.state, out=out)
+
+    def exploration_noise(self, act, batch):
+        return self.policy.exploration_noise(act, batch)
+
+    def learn(self, batch, **kwargs):
+        return self.policy.learn(batch, **kwargs)
