@@ -79,7 +79,9 @@ def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
     from oracle import env_oracle as eo
     from oracle import net_oracle as no
     from melissa_amd.env import synthetic_graph_pool
-    cores = os.cpu_count() or 1
+    # torch's CPU ops on these small tensors get slower past a few dozen threads, so the port uses at most
+    # 32 of the host cores (the count actually used is what is reported)
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     pool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
     workers = [eo.OraclePettingZooEnv(eo.OracleGraphEnv(
@@ -88,6 +90,8 @@ def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
     sd = no.init_weights("l_dgn", seed=9)
     obs = [w.reset()[0] for w in workers]
     decisions, iters = 0, 0
+    with torch.no_grad():                        # warm-up (thread pool, allocator), not timed
+        no.ldgn_forward(sd, np.stack([o["obs"] for o in obs]), n_nodes)
     t0 = time.perf_counter()
     with torch.no_grad():
         while time.perf_counter() - t0 < budget_s:

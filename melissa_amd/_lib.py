@@ -82,6 +82,12 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Device pointers and streams
+    # borrowed from torch tensors are only meaningful inside THAT runtime instance, so torch must be
+    # loaded first: our library's libamdhip64.so.7 dependency then resolves to the copy already mapped
+    # (loading in the other order leaves two runtimes in the process and every launch fails with
+    # "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     path = lib_path()
     if build_if_missing and _build.is_stale():
         try:

@@ -22,6 +22,10 @@ inline mel_status fail(mel_status code, const char* fmt, ...) {
     return code;
 }
 
+// hipGetLastError() is sticky per thread: an error left behind by somebody else's HIP call (e.g. a
+// device-count probe) must not be blamed on our launch, so every entry point clears it first.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline mel_status check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(MEL_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));

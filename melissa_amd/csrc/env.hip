@@ -514,6 +514,7 @@ mel_status mel_env_reset(mel_env_batch* env, const mel_episode_pool* pool, const
     if (!episode_ids) return fail(MEL_ERR_INVALID_ARG, "episode_ids is null");
     if (!keep_graph && (!pool->pos || !pool->one_hop)) return fail(MEL_ERR_INVALID_ARG, "pool has no graphs");
     if (n == 0) return MEL_OK;
+    clear_stale_error();
     StepArgs a{};
     a.env = *env, a.pool = *pool, a.env_ids = env_ids, a.episode_ids = episode_ids, a.n = n, a.keep_graph = keep_graph;
     if (out) a.out = *out, a.has_out = 1;
@@ -530,6 +531,7 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
     if (!actions) return fail(MEL_ERR_INVALID_ARG, "actions is null");
     if (episode_table && (table_stride < 1 || !out)) return fail(MEL_ERR_INVALID_ARG, "auto-reset needs table_stride >= 1 and an output block");
     if (n == 0) return MEL_OK;
+    clear_stale_error();
     StepArgs a{};
     a.env = *env, a.pool = *pool, a.actions = actions, a.env_ids = env_ids, a.n = n;
     a.episode_table = episode_table, a.table_stride = table_stride;
@@ -544,6 +546,7 @@ mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n
     if (mel_status st = check_env(env, n)) return st;
     if (!out) return fail(MEL_ERR_INVALID_ARG, "output block is null");
     if (n == 0) return MEL_OK;
+    clear_stale_error();
     StepArgs a{};
     a.env = *env, a.env_ids = env_ids, a.n = n, a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_OBSERVE, static_cast<hipStream_t>(stream));

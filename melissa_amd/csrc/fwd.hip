@@ -21,23 +21,25 @@ Profiler* current_profiler() { return g_prof; }
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN>
+template <int TM, int TN>
 static void gemm_launch_t(const GemmArgs& g, int mode, hipStream_t s) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 64 * TM, BN = 64 * TN;      // 2 x 2 wavefronts
     const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, GEMM_MODE_ENC>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, TM, TN, GEMM_MODE_ENC>), dim3(grid), dim3(256), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, GEMM_MODE_PLAIN>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, TM, TN, GEMM_MODE_PLAIN>), dim3(grid), dim3(256), 0, s, g);
 }
 
-mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what) {
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint) {
     if (g.M <= 0) return MEL_OK;
     if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
         return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
-    // 128x128 tiles when they still give >= 2 workgroups per CU, else 64x64 single-wave tiles.
-    const long big = (long)((g.M + 127) / 128) * (g.N / 128);
-    if (g.N % 128 == 0 && big >= 512)
+    if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
+    // 128x128 tiles once they give every CU about two workgroups, else 64x64 tiles (4x the workgroups,
+    // a quarter of the per-wave MFMA chain).
+    const long big = ((m_hint + 127) / 128) * (g.N / 128);
+    if (g.N % 128 == 0 && big >= 448)
         gemm_launch_t<2, 2>(g, mode, stream);
     else
         gemm_launch_t<1, 1>(g, mode, stream);
@@ -620,12 +622,17 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
     const FwdLayout L = carve(w, bs, n, workspace);
     if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    clear_stale_error();
     const int node_cols = w->in_dim + 3;
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int M = (int)(bs * n);
     const int cap1 = n < 34 ? n : 34;
     const int R1 = (int)bs * cap1;
     const int latent = hidden + 2 * hc;
+    // expected sizes of the ragged row lists, for tile selection only (mean degree of the r = 0.2 disc
+    // graph is about 0.126 N; the closed two-hop ball covers about a quarter of the unit square)
+    const long hint1 = bs * (long)(n < 8 ? n : 2 + n / 8);
+    const long hint2 = bs * (long)(n < 8 ? n : 1 + n / 4);
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -645,7 +652,7 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hidden;
         g.K = w->encoder.layer[0].out_dim, g.relu = 1;
         StageScope t(MEL_STAGE_ENCODER, s);
-        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", hint2)) return st;
     }
     {   // conv1.lin_l on the two-hop rows, conv1.lin_r on the one-hop rows
         GemmArgs g;
@@ -653,13 +660,13 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
         g.Y = L.xl1, g.ldy = hc, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hc, g.K = hidden;
         {
             StageScope t(MEL_STAGE_CONV1_LIN, s);
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l")) return st;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l", hint2)) return st;
         }
         GemmArgs r;
         r.A = L.h0, r.lda = hidden, r.arow = L.plan.arow1, r.W = w->conv1.lin_r.weight, r.bias = w->conv1.lin_r.bias;
         r.Y = L.xr1, r.ldy = hc, r.M = R1, r.M_dev = L.plan.off1 + bs, r.N = hc, r.K = hidden;
         StageScope t(MEL_STAGE_CONV1_LIN_R, s);
-        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r")) return st;
+        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r", hint1)) return st;
     }
     {   // conv1 attention for the one-hop targets; also drops x_1 and x_2 into the head input
         AttArgs a{};
@@ -677,7 +684,7 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
         g.Y = L.xl2, g.ldy = hc, g.M = R1, g.M_dev = L.plan.off1 + bs, g.N = hc, g.K = hc;
         {
             StageScope t(MEL_STAGE_CONV2_LIN, s);
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l")) return st;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l", hint1)) return st;
         }
         GemmArgs r;
         r.A = L.h1, r.lda = hc, r.arow = L.plan.arow_g, r.rscale = L.plan.dm_g;
@@ -706,6 +713,7 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
     const FwdLayout L = carve(w, bs, n, workspace);
     if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    clear_stale_error();
     const int node_cols = w->in_dim + 3;
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int M = (int)(bs * n);
@@ -751,6 +759,7 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
     if (!w || !workspace || !out || bs <= 0 || n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "bad tap arguments");
     const FwdLayout L = carve(w, bs, n, const_cast<void*>(workspace));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    clear_stale_error();
     hipError_t e;
     if (kind == 0)
         e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
@@ -819,6 +828,7 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
     if (!logits || !act || bs <= 0 || na < 1) return fail(MEL_ERR_INVALID_ARG, "bad select_action arguments");
     if (mask && !scratch) return fail(MEL_ERR_INVALID_ARG, "masking needs 8 bytes of scratch");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    clear_stale_error();
     StageScope t(MEL_STAGE_SELECT, s);
     if (mask) {
         hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, s, logits, (long)bs * na, static_cast<float*>(scratch));

@@ -8,8 +8,11 @@
 // [rows, K], nn.Linear.weight [out, K]), so no transposed copies exist anywhere.
 //
 // Layout / mapping:
-//   * one wavefront owns a 64x64 output sub-tile = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs);
-//     a workgroup is WM x WN wavefronts -> BM = 64*WM rows by BN = 64*WN columns, K step 32;
+//   * one wavefront owns TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each); a workgroup is
+//     WM x WN wavefronts -> BM = 32*TM*WM rows by BN = 32*TN*WN columns, K step 32.  Two shapes are
+//     built: 128x128 (2x2 waves of 64x64) for the big row lists, 64x64 (2x2 waves of 32x32) when the
+//     big tile would leave CUs idle (fp32 MFMA is slow enough - 64 cycles per 32x32x2 - that the short
+//     per-wave MFMA chain of the small tile, not operand re-use, sets the latency of small problems);
 //   * tiles are staged global -> registers -> LDS with 16-byte accesses; LDS rows are padded to 36
 //     floats (144 B) so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B slots;
 //   * the k order inside a K step is permuted identically for A and W (lane half h takes k = 8q+4h..+3
@@ -59,25 +62,30 @@ constexpr int GEMM_LDS_STRIDE = GEMM_BK + 4;   // floats; 144-byte rows
 
 enum { GEMM_MODE_PLAIN = 0, GEMM_MODE_ENC = 1 };
 
-template <int WM, int WN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
-    constexpr int BM = 64 * WM, BN = 64 * WN, T = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN;
     constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;   // float4 chunks per thread per K step
     constexpr int W_CHUNKS = BN * (GEMM_BK / 4) / T;
     __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * GEMM_LDS_STRIDE];
     float* As = lds;
     float* Ws = lds + BM * GEMM_LDS_STRIDE;
 
-    // XCD-aware tile order: workgroups that share an A row panel (same m tile, different n tile)
-    // get consecutive ids on one XCD so the panel is fetched into one L2 only.
+    // Tile order.  The row count may be ragged and device-side: only the first `active` workgroup ids
+    // have work (the dispatcher deals consecutive ids round-robin over the 8 XCDs, so they are spread
+    // evenly) and the rest exit at once.  Inside the active range ids are remapped (bijectively) so that
+    // the workgroups sharing an A row panel (same m tile, different n tile) sit on one XCD's L2.
     const int nbn = g.N / BN;
-    const int nwg = gridDim.x;
+    const int M = g.M_dev ? min(*g.M_dev, g.M) : g.M;
+    const int active = ((M + BM - 1) / BM) * nbn;
     int wg = blockIdx.x;
-    if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+    if (wg >= active) return;
+    {
+        const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
+        wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+    }
     const int m0 = (wg / nbn) * BM;
     const int n0 = (wg % nbn) * BN;
-    const int M = g.M_dev ? min(*g.M_dev, g.M) : g.M;
-    if (m0 >= M) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,16 +169,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const float* a_frag = As + (wm * 64 + r) * GEMM_LDS_STRIDE + 4 * h;
-    const float* w_frag = Ws + (wn * 64 + r) * GEMM_LDS_STRIDE + 4 * h;
+    const float* a_frag = As + (wm * 32 * TM + r) * GEMM_LDS_STRIDE + 4 * h;
+    const float* w_frag = Ws + (wn * 32 * TN + r) * GEMM_LDS_STRIDE + 4 * h;
 
     const int KT = g.K / GEMM_BK;
     load_tile(0);
@@ -180,18 +188,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
         if (kt + 1 < KT) load_tile((kt + 1) * GEMM_BK);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 a[2], b[2];
+            float4 a[TM], b[TN];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TM; ++t)
                 a[t] = *reinterpret_cast<const float4*>(a_frag + t * 32 * GEMM_LDS_STRIDE + q * 8);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
                 b[t] = *reinterpret_cast<const float4*>(w_frag + t * 32 * GEMM_LDS_STRIDE + q * 8);
-            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             reinterpret_cast<const float*>(&a[i])[kk],
                             reinterpret_cast<const float*>(&b[j])[kk], acc[i][j], 0, 0, 0);
@@ -205,15 +214,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + r;
         const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n]
                                                          : (g.bias ? g.bias[n] : 0.f);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < M) {
                     float v = acc[i][j][e];
                     if (g.rscale) v *= g.rscale[m];
@@ -226,7 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.
-mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what);
+// Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.  `m_hint` is the row
+// count the caller expects (ragged lists are sized on the device; the grid still covers g.M rows).
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1);
 
 }  // namespace mel

@@ -66,15 +66,12 @@ def geometric_adjacency(pos: np.ndarray, radius: float = RADIUS_OF_INFLUENCE) ->
     ``radius**2``).  Returns one bitmask per node."""
     n = pos.shape[0]
     r2 = radius ** 2
-    adj = [0] * n
-    for i in range(n):
-        for j in range(i + 1, n):
-            dx = pos[i, 0] - pos[j, 0]
-            dy = pos[i, 1] - pos[j, 1]
-            if dx * dx + dy * dy <= r2:
-                adj[i] |= 1 << j
-                adj[j] |= 1 << i
-    return adj
+    dx = pos[:, None, 0] - pos[None, :, 0]
+    dy = pos[:, None, 1] - pos[None, :, 1]
+    within = (dx * dx + dy * dy) <= r2          # elementwise float64: identical to the scalar expression
+    np.fill_diagonal(within, False)
+    weights = [1 << j for j in range(n)]
+    return [sum(w for w, hit in zip(weights, row) if hit) for row in within.tolist()]
 
 
 def two_hop_masks(adj: list) -> list:
