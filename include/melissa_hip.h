@@ -105,6 +105,12 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
                              int32_t n_nodes, int32_t obs_width, float* logits, void* workspace,
                              size_t ws_bytes, void* stream);
 
+/* The dense projection used by every layer above, exposed for tests and tuning:
+ *   Y[m, n] = act(sum_k A[m, k] * W[n, k] + bias[n]),  A [M, lda], W [N, K] (nn.Linear layout), Y [M, ldy],
+ * all device fp32; K % 32 == 0, N % 64 == 0.  tile: 0 = automatic, 1 = 64x64, 2 = 128x128 workgroup tile. */
+mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
+                        int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
+
 /* Debug/parity taps: copies of intermediates after a forward with the same workspace.
  * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
  *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),

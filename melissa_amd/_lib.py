@@ -19,7 +19,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_workspace_bytes", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
+EXPORTS = ("mel_gemm_f32", "mel_workspace_bytes", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
@@ -108,6 +108,8 @@ def load(build_if_missing: bool = True):
     lib.mel_ldgn_forward.argtypes = [W, vp, i64, i32, i32, vp, vp, sz, vp]
     lib.mel_hldgn_forward.restype = i32
     lib.mel_hldgn_forward.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_gemm_f32.restype = i32
+    lib.mel_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]
     lib.mel_forward_tap.restype = i32
     lib.mel_forward_tap.argtypes = [W, i32, i64, i32, vp, vp, vp]
     lib.mel_select_action.restype = i32

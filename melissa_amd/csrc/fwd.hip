@@ -31,11 +31,16 @@ static void gemm_launch_t(const GemmArgs& g, int mode, hipStream_t s) {
         hipLaunchKernelGGL((gemm_f32_kernel<2, 2, TM, TN, GEMM_MODE_PLAIN>), dim3(grid), dim3(256), 0, s, g);
 }
 
-mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint) {
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint, int force_tile) {
     if (g.M <= 0) return MEL_OK;
     if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
         return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
+    if (force_tile == 1 || (force_tile == 2 && g.N % 128 == 0)) {
+        if (force_tile == 1) gemm_launch_t<1, 1>(g, mode, stream);
+        else gemm_launch_t<2, 2>(g, mode, stream);
+        return check_launch(what);
+    }
     // 128x128 tiles once they give every CU about two workgroups, else 64x64 tiles (4x the workgroups,
     // a quarter of the per-wave MFMA chain).
     const long big = ((m_hint + 127) / 128) * (g.N / 128);
@@ -752,6 +757,16 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
     return run_heads(w, L, bs, logits, s);
+}
+
+mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
+                        int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream) {
+    if (!A || !W || !Y || M < 0 || M > (1ll << 30) || lda < K || ldy < N)
+        return fail(MEL_ERR_INVALID_ARG, "bad gemm arguments");
+    clear_stale_error();
+    GemmArgs g;
+    g.A = A, g.lda = lda, g.W = W, g.bias = bias, g.Y = Y, g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K, g.relu = relu;
+    return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_f32", -1, tile);
 }
 
 mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n, const void* workspace,

@@ -13,8 +13,9 @@
 //     built: 128x128 (2x2 waves of 64x64) for the big row lists, 64x64 (2x2 waves of 32x32) when the
 //     big tile would leave CUs idle (fp32 MFMA is slow enough - 64 cycles per 32x32x2 - that the short
 //     per-wave MFMA chain of the small tile, not operand re-use, sets the latency of small problems);
-//   * tiles are staged global -> registers -> LDS with 16-byte accesses; LDS rows are padded to 36
-//     floats (144 B) so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B slots;
+//   * tiles are staged global -> registers -> LDS with 16-byte accesses into a two-stage LDS ring (one
+//     barrier per K step); LDS rows are padded to 36 floats (144 B) so the 16 lanes of a ds_read_b128
+//     group hit 16 distinct 16-B slots;
 //   * the k order inside a K step is permuted identically for A and W (lane half h takes k = 8q+4h..+3
 //     of sub-step q), which lets one ds_read_b128 per operand feed four MFMAs;
 //   * the next K step's global loads are issued before the current step's MFMAs (register prefetch);
@@ -29,6 +30,8 @@
 namespace mel {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // first-class SSA value: HIP's float4 struct
+                                                           // made the staging arrays land in scratch
 
 struct GemmArgs {
     // A operand
@@ -62,14 +65,42 @@ constexpr int GEMM_LDS_STRIDE = GEMM_BK + 4;   // floats; 144-byte rows
 
 enum { GEMM_MODE_PLAIN = 0, GEMM_MODE_ENC = 1 };
 
+// Per-thread staging coordinates of one 16-byte chunk (constant across K steps).
+struct AChunk {
+    const float* src;    // PLAIN: &A[arow(row)][chunk*4]  (null when the row is beyond M)
+    float x[8];          // ENC:   node features
+    bool ok;
+};
+
+template <int MODE>
+__device__ __forceinline__ f32x4 fetch_a(const GemmArgs& g, const AChunk& c, int k0, int kc) {
+    if constexpr (MODE == GEMM_MODE_PLAIN) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        return c.ok ? *reinterpret_cast<const f32x4*>(c.src + k0) : zero;
+    } else {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + kc + e;
+            float s = g.enc_b[k];
+            const float* wrow = g.enc_w + (size_t)k * g.in_dim;
+#pragma unroll
+            for (int f = 0; f < 8; ++f)
+                if (f < g.in_dim) s = fmaf(wrow[f], c.x[f], s);
+            v[e] = c.ok ? fmaxf(s, 0.f) : 0.f;
+        }
+        const f32x4 out = {v[0], v[1], v[2], v[3]};
+        return out;
+    }
+}
+
 template <int WM, int WN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN;
     constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;   // float4 chunks per thread per K step
     constexpr int W_CHUNKS = BN * (GEMM_BK / 4) / T;
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * GEMM_LDS_STRIDE];
-    float* As = lds;
-    float* Ws = lds + BM * GEMM_LDS_STRIDE;
+    constexpr int BUF = (BM + BN) * GEMM_LDS_STRIDE;   // floats per LDS stage
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     // Tile order.  The row count may be ragged and device-side: only the first `active` workgroup ids
     // have work (the dispatcher deals consecutive ids round-robin over the 8 XCDs, so they are spread
@@ -92,82 +123,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
     const int wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int r = lane & 31, h = lane >> 5;
+    const int crow = tid >> 3;            // staging: 8 threads per 128-byte row slice
+    const int kc = (tid & 7) * 4;
 
-    // per-thread staging chunk coordinates (constant across K steps)
-    const float* a_src[A_CHUNKS];
-    bool a_ok[A_CHUNKS];
-    float enc_x[MODE == GEMM_MODE_ENC ? A_CHUNKS : 1][8];
+    AChunk ac[A_CHUNKS];
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
-        const int c = tid + i * T;
-        const int row = m0 + (c >> 3);
-        a_ok[i] = row < M;
-        a_src[i] = nullptr;
-        if (MODE == GEMM_MODE_PLAIN) {
-            if (a_ok[i]) {
-                const int ar = g.arow ? g.arow[row] : row;
-                a_src[i] = g.A + (size_t)ar * g.lda + (c & 7) * 4;
-            }
-        } else {
+        const int row = m0 + crow + i * (T / 8);
+        ac[i].ok = row < M;
+        ac[i].src = nullptr;
 #pragma unroll
-            for (int f = 0; f < 8; ++f) enc_x[i][f] = 0.f;
-            if (a_ok[i]) {
+        for (int f = 0; f < 8; ++f) ac[i].x[f] = 0.f;
+        if (ac[i].ok) {
+            if constexpr (MODE == GEMM_MODE_PLAIN) {
+                const int ar = g.arow ? g.arow[row] : row;
+                ac[i].src = g.A + (size_t)ar * g.lda + kc;
+            } else {
                 const int id = g.nid ? g.nid[row] : row;
                 const int b = id / g.n_nodes, node = id - b * g.n_nodes;
                 const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
 #pragma unroll
                 for (int f = 0; f < 8; ++f)
-                    if (f < g.in_dim) enc_x[i][f] = x[f];
+                    if (f < g.in_dim) ac[i].x[f] = x[f];
             }
         }
     }
     const float* w_src[W_CHUNKS];
 #pragma unroll
     for (int i = 0; i < W_CHUNKS; ++i) {
-        const int c = tid + i * T;
-        const int n = n0 + (c >> 3);
+        const int n = n0 + crow + i * (T / 8);
         const float* base = (g.W_hi && n >= g.split_n) ? g.W_hi + (size_t)(n - g.split_n) * g.K
                                                         : g.W + (size_t)n * g.K;
-        w_src[i] = base + (c & 7) * 4;
+        w_src[i] = base + kc;
     }
-
-    float4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            if (MODE == GEMM_MODE_PLAIN) {
-                a_reg[i] = a_ok[i] ? *reinterpret_cast<const float4*>(a_src[i] + k0)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int kc = k0 + ((tid + i * T) & 7) * 4;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float s = g.enc_b[kc + e];
-                    const float* wrow = g.enc_w + (size_t)(kc + e) * g.in_dim;
-#pragma unroll
-                    for (int f = 0; f < 8; ++f)
-                        if (f < g.in_dim) s = fmaf(wrow[f], enc_x[i][f], s);
-                    v[e] = a_ok[i] ? fmaxf(s, 0.f) : 0.f;
-                }
-                a_reg[i] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const float4*>(w_src[i] + k0);
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) {
-            const int c = tid + i * T;
-            *reinterpret_cast<float4*>(As + (c >> 3) * GEMM_LDS_STRIDE + (c & 7) * 4) = a_reg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < W_CHUNKS; ++i) {
-            const int c = tid + i * T;
-            *reinterpret_cast<float4*>(Ws + (c >> 3) * GEMM_LDS_STRIDE + (c & 7) * 4) = w_reg[i];
-        }
-    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -177,24 +165,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const float* a_frag = As + (wm * 32 * TM + r) * GEMM_LDS_STRIDE + 4 * h;
-    const float* w_frag = Ws + (wn * 32 * TN + r) * GEMM_LDS_STRIDE + 4 * h;
+    const int st_off = crow * GEMM_LDS_STRIDE + kc;                       // this thread's staging slot
+    const int a_off = (wm * 32 * TM + r) * GEMM_LDS_STRIDE + 4 * h;       // this lane's fragment rows
+    const int w_off = BM * GEMM_LDS_STRIDE + (wn * 32 * TN + r) * GEMM_LDS_STRIDE + 4 * h;
+
+    f32x4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(g, ac[i], 0, kc);
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i]);
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i)
+        *reinterpret_cast<f32x4*>(lds + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i)
+        *reinterpret_cast<f32x4*>(lds + BM * GEMM_LDS_STRIDE + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = w_reg[i];
+    __syncthreads();
 
     const int KT = g.K / GEMM_BK;
-    load_tile(0);
-    store_tile();
-    __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) load_tile((kt + 1) * GEMM_BK);
+        const float* cur = lds + (kt & 1) * BUF;
+        float* nxt = lds + ((kt + 1) & 1) * BUF;
+        const bool more = kt + 1 < KT;
+        if (more) {                       // next K step: global loads stay in flight under the MFMAs
+            const int k0 = (kt + 1) * GEMM_BK;
+#pragma unroll
+            for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(g, ac[i], k0, kc);
+#pragma unroll
+            for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i] + k0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 a[TM], b[TN];
+            f32x4 a[TM], b[TN];
 #pragma unroll
             for (int t = 0; t < TM; ++t)
-                a[t] = *reinterpret_cast<const float4*>(a_frag + t * 32 * GEMM_LDS_STRIDE + q * 8);
+                a[t] = *reinterpret_cast<const f32x4*>(cur + a_off + t * 32 * GEMM_LDS_STRIDE + q * 8);
 #pragma unroll
             for (int t = 0; t < TN; ++t)
-                b[t] = *reinterpret_cast<const float4*>(w_frag + t * 32 * GEMM_LDS_STRIDE + q * 8);
+                b[t] = *reinterpret_cast<const f32x4*>(cur + w_off + t * 32 * GEMM_LDS_STRIDE + q * 8);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -202,14 +210,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            reinterpret_cast<const float*>(&a[i])[kk],
-                            reinterpret_cast<const float*>(&b[j])[kk], acc[i][j], 0, 0, 0);
+                            a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        }
+        if (more) {                       // the other LDS stage was last read one barrier ago
+#pragma unroll
+            for (int i = 0; i < A_CHUNKS; ++i)
+                *reinterpret_cast<f32x4*>(nxt + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = a_reg[i];
+#pragma unroll
+            for (int i = 0; i < W_CHUNKS; ++i)
+                *reinterpret_cast<f32x4*>(nxt + BM * GEMM_LDS_STRIDE + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = w_reg[i];
         }
         __syncthreads();
-        if (kt + 1 < KT) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 
 // Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.  `m_hint` is the row
 // count the caller expects (ragged lists are sized on the device; the grid still covers g.M rows).
-mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1);
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1,
+                       int force_tile = 0);
 
 }  // namespace mel

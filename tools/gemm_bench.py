@@ -1,0 +1,58 @@
+"""Microbenchmark of the fp32-MFMA row GEMM at the shapes of the L-DGN step (interleaved rounds in one
+process, torch events on the launch stream).  python tools/gemm_bench.py [--rounds 30]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from melissa_amd import _lib  # noqa: E402
+
+SHAPES = [("conv2_lin", 6630, 512, 512), ("conv1_lin", 12962, 512, 128), ("conv1_lin_r", 6630, 512, 128),
+          ("conv2_lin_r", 1024, 512, 512), ("head0", 1024, 256, 1152), ("head1", 1024, 128, 128),
+          ("encoder", 12962, 128, 128), ("hl_conv1", 51200, 1024, 128), ("big", 65536, 512, 512)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=30)
+    ap.add_argument("--tiles", default="1,2")
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    tiles = [int(t) for t in args.tiles.split(",")]
+    torch.manual_seed(0)
+    for name, M, N, K in SHAPES:
+        A = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev)
+        Y = torch.empty(M, N, device=dev)
+        ref = torch.addmm(b, A, W.t())
+        res = {}
+        for t in tiles:
+            _lib.check(lib.mel_gemm_f32(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
+                                        _lib.current_stream_ptr()))
+            err = (Y - ref).abs().max().item()
+            res[t] = [err, []]
+        for _ in range(args.rounds):
+            for t in tiles:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    lib.mel_gemm_f32(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
+                                     _lib.current_stream_ptr())
+                e1.record()
+                e1.synchronize()
+                res[t][1].append(e0.elapsed_time(e1) / 4 * 1e3)
+        flops = 2.0 * M * N * K
+        line = f"{name:12s} M={M:6d} N={N:5d} K={K:5d} {flops/1e9:7.2f} GF |"
+        for t in tiles:
+            ts = sorted(res[t][1])
+            med = ts[len(ts) // 2]
+            line += f" tile{t}: {med:7.1f} us {flops/med/1e6:6.1f} TF (min {ts[0]:6.1f}) err {res[t][0]:.1e} |"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
