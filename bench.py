@@ -61,7 +61,7 @@ def build_workload(device, rank, envs, n_nodes, model_name, seed=9):
 def stage_flops(totals, bs):
     """ALGORITHMIC FLOPs (2*MAC) per launch of each GEMM stage, from the receptive-field row counts the
     launch actually processed (pruned work is priced at the pruned count)."""
-    s1, s2 = totals
+    s1, s2 = totals[0], totals[1]
     return {
         "encoder": s2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
         "conv1_lin": 2.0 * s2 * HC * HIDDEN,
@@ -155,12 +155,12 @@ def main():
     roofline, stages = None, None
     if not args.no_profile and rank == 0:
         prof = lib.mel_prof_create(args.steps * 16)
-        totals = torch.zeros(args.steps, 2, dtype=torch.int32, device=device)
+        totals = torch.zeros(args.steps, 3, dtype=torch.int32, device=device)
         lib.mel_prof_attach(prof)
         for k in range(args.steps):
             loop.step()
             if args.model == "l_dgn":
-                _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, net._ws.data_ptr(),
+                _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, 0, net._ws.data_ptr(),
                                                totals[k].data_ptr(), _lib.current_stream_ptr(device)))
         lib.mel_prof_attach(None)
         torch.cuda.synchronize()

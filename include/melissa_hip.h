@@ -101,6 +101,21 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
                             int32_t obs_width, float* logits, void* workspace, size_t ws_bytes,
                             void* stream);
 
+/* L-DGN for a SET of controlling agents per env (the round-batched loop): within one env round every
+ * active agent observes the same obs_matrix (graph.py:186-188 - rows differ only in the index column), so
+ * all of a round's agents are evaluated together and the encoder / conv1 work on the union of their
+ * receptive fields is shared.  obs: device fp32 [bs, obs_stride], row b = obs_matrix of env b (the index
+ * column is not read; obs_stride >= n_nodes*(in_dim+3)); agent_mask: device uint64 [bs], bit i = agent i
+ * is evaluated.  logits: device fp32 [rows_cap, n_actions], rows ordered by env then agent id; only the
+ * first sum(popcount(agent_mask)) rows are written (rows_cap >= that sum, <= bs*n_nodes).
+ * row_offsets (optional, device int32 [bs+1]): first logits row of each env, total at [bs].
+ * Each row equals mel_ldgn_forward on (obs_matrix, agent) within fp32 rounding. */
+size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap);
+mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
+                                   int32_t obs_stride, const uint64_t* agent_mask, int64_t rows_cap,
+                                   float* logits, int32_t* row_offsets, void* workspace, size_t ws_bytes,
+                                   void* stream);
+
 mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs,
                              int32_t n_nodes, int32_t obs_width, float* logits, void* workspace,
                              size_t ws_bytes, void* stream);
@@ -114,9 +129,10 @@ mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float
 /* Debug/parity taps: copies of intermediates after a forward with the same workspace.
  * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
  *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),
- *       2 = int32 [2]: rows of the L-DGN receptive-field lists (sum |S1|, sum |S2|) the GEMMs processed.
- * `out` is a device pointer with room for the requested tensor. */
-mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n_nodes,
+ *       2 = int32 [3]: rows the L-DGN GEMMs processed (sum |U1|, sum |U2|, agent rows).
+ * rows_cap: 0 for a workspace used by mel_ldgn_forward / mel_hldgn_forward, else the rows_cap given to
+ * mel_ldgn_forward_agents.  `out` is a device pointer with room for the requested tensor. */
+mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n_nodes, int64_t rows_cap,
                            const void* workspace, void* out, void* stream);
 
 /* [3P] DQNPolicy.forward + exploration_noise:
@@ -127,6 +143,14 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
 mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t bs, int32_t n_actions,
                              float eps, const float* rand_u, const float* rand_q, int32_t* act,
                              void* scratch, void* stream);
+
+/* Row-wise argmax + eps-greedy for the round-batched loop: the row count lives on the device
+ * (rows_dev, may be NULL = rows_cap) and the exploration stream is a counter-based hash of
+ * (seed, step, row) instead of host numpy draws.  logit_row (optional, device int32 [rows_cap]) maps an
+ * action row to its logits row (HL-DGN: all agents of an env share the env's logits). */
+mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row, int64_t rows_cap,
+                                  const int32_t* rows_dev, int32_t n_actions, float eps, uint32_t seed,
+                                  uint32_t step, int32_t* act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Environment half.  State of B independent envs lives in caller-owned device memory laid out as
@@ -239,6 +263,19 @@ mel_status mel_env_reset(mel_env_batch* env, const mel_episode_pool* pool, const
 mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
                         const int32_t* env_ids, int64_t n, const mel_env_obs* out,
                         const int32_t* episode_table, int32_t table_stride, void* stream);
+
+/* One whole env ROUND per launch for every env of the batch (round-batched loop): replays, in the
+ * reference's AEC order, the dead-agent steps and one GraphEnv.step per active agent with that agent's
+ * action until the world step fires or the episode ends (then the env is reset to
+ * episode_table[b, ep_cursor % table_stride]).  State after the call is identical to issuing the same
+ * steps one at a time through mel_env_step.
+ *   actions     device int32 [rows], one per (env, active agent), ordered by env then agent id
+ *   row_offsets device int32 [B+1], first action row of each env (from mel_ldgn_forward_agents)
+ *   live        device uint64 [B]; in: the active sets the actions belong to, out: the next round's
+ *   first != 0  only publishes the current active sets (call once after mel_env_reset). */
+mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
+                         const int32_t* row_offsets, uint64_t* live, const int32_t* episode_table,
+                         int32_t table_stride, int32_t first, void* stream);
 
 /* last() only (mutates is_new_round exactly like GraphEnv.observe, graph.py:205-211). */
 mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n,

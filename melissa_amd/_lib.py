@@ -19,9 +19,10 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_gemm_f32", "mel_workspace_bytes", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
+EXPORTS = ("mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+           "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
-           "mel_env_observe", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
+           "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
 N_STAGES = 14
 STAGE_NAMES = ("plan", "encoder", "conv1_lin", "conv1_lin_r", "conv1_att", "conv2_lin", "conv2_lin_r", "conv2_att",
@@ -111,7 +112,13 @@ def load(build_if_missing: bool = True):
     lib.mel_gemm_f32.restype = i32
     lib.mel_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]
     lib.mel_forward_tap.restype = i32
-    lib.mel_forward_tap.argtypes = [W, i32, i64, i32, vp, vp, vp]
+    lib.mel_forward_tap.argtypes = [W, i32, i64, i32, i64, vp, vp, vp]
+    lib.mel_workspace_bytes_agents.restype = sz
+    lib.mel_workspace_bytes_agents.argtypes = [W, i64, i32, i64]
+    lib.mel_ldgn_forward_agents.restype = i32
+    lib.mel_ldgn_forward_agents.argtypes = [W, vp, i64, i32, i32, vp, i64, vp, vp, vp, sz, vp]
+    lib.mel_select_action_rows.restype = i32
+    lib.mel_select_action_rows.argtypes = [vp, vp, i64, vp, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
     lib.mel_select_action.restype = i32
     lib.mel_select_action.argtypes = [vp, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
     lib.mel_env_state_bytes.restype = sz
@@ -122,6 +129,8 @@ def load(build_if_missing: bool = True):
     lib.mel_env_reset.argtypes = [E, P, vp, vp, i64, i32, O, vp]
     lib.mel_env_step.restype = i32
     lib.mel_env_step.argtypes = [E, P, vp, vp, i64, O, vp, i32, vp]
+    lib.mel_env_round.restype = i32
+    lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp]
     lib.mel_env_observe.restype = i32
     lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
     lib.mel_prof_create.restype = vp

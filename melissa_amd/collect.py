@@ -37,11 +37,13 @@ def sample_episode_table(venv: HipGraphVectorEnv, episodes_per_env: int, seed: i
 
 
 class DecisionLoop:
+    """AEC-order loop: one agent decision per env per iteration (the reference collector's granularity)."""
+
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
-                 eps: float = 0.0):
+                 eps: float = 0.0, episodes=None):
         self.venv, self.policy, self.eps = venv, policy, eps
         dev = venv.device
-        packed, table = sample_episode_table(venv, episodes_per_env, seed)
+        packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
         self.pool = venv.load_pool(packed)
         self.table = torch.from_numpy(table).to(dev)
         self.n_actions = policy.model.output_dim
@@ -73,6 +75,59 @@ class DecisionLoop:
 
     def counters(self) -> dict:
         """Host read of the per-env counters (synchronises)."""
+        sc = self.venv.scalars().cpu().numpy()
+        return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
+                    errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)
+
+
+class RoundLoop:
+    """Round-batched loop: one iteration = one whole env ROUND for every env.
+
+    Within a round every active agent observes the same ``obs_matrix`` (graph.py:186-188: the rows differ
+    only in the controlling-agent column) and no agent's action is visible to another before the world
+    step (graph.py:324-347), so all of a round's decisions are taken by ONE forward
+    (``mel_ldgn_forward_agents``: shared encoder / conv1 over the union of the receptive fields) and applied
+    by ONE env launch (``mel_env_round``) that replays the reference's AEC order - pending dead agents first,
+    then each active agent with its own action, then the world step.  Per-env trajectories are identical to
+    the AEC-order loop under the same actions; an iteration yields ~N/6 decisions per env instead of one.
+    """
+
+    def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
+                 eps: float = 0.0, episodes=None, rows_cap: int | None = None):
+        self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
+        dev = venv.device
+        packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
+        self.pool = venv.load_pool(packed)
+        self.table = torch.from_numpy(table).to(dev)
+        self.n_actions = policy.model.output_dim
+        self.rows_cap = int(rows_cap or venv.env_num * venv.n)
+        self.live = torch.zeros(venv.env_num, dtype=torch.int64, device=dev)
+        self.offsets = torch.zeros(venv.env_num + 1, dtype=torch.int32, device=dev)
+        self.logits = torch.zeros(self.rows_cap, self.n_actions, dtype=torch.float32, device=dev)
+        self.act = torch.zeros(self.rows_cap, dtype=torch.int32, device=dev)
+        self.iterations = 0
+        venv.reset_device(self.pool, self.table[:, 0].contiguous(), None)
+        venv.round_device(self.pool, None, None, self.live, None, first=True)
+
+    def step(self):
+        lib = _lib.load()
+        net = self.policy.model
+        dev = self.venv.device
+        net.hip_forward_agents(self.venv.obs_matrix(), self.live, self.rows_cap, out=self.logits,
+                               row_offsets=self.offsets)
+        rows_dev = self.offsets.data_ptr() + 4 * self.venv.env_num
+        _lib.check(lib.mel_select_action_rows(self.logits.data_ptr(), None, self.rows_cap, rows_dev, self.n_actions,
+                                              float(self.eps), self.seed & 0xFFFFFFFF, self.iterations & 0xFFFFFFFF,
+                                              self.act.data_ptr(), _lib.current_stream_ptr(dev)),
+                   "mel_select_action_rows")
+        self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table)
+        self.iterations += 1
+
+    def run(self, iterations: int):
+        for _ in range(iterations):
+            self.step()
+
+    def counters(self) -> dict:
         sc = self.venv.scalars().cpu().numpy()
         return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
                     errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)

@@ -343,7 +343,8 @@ __device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_epis
     s.ep_cursor += 1;
 }
 
-// GraphEnv.observe / last() graph.py:181-216 + PettingZooEnv packing; returns (terminated, explicit_reset)
+// GraphEnv.observe / last() graph.py:181-216 + PettingZooEnv packing; returns bit0 terminated,
+// bit1 explicit_reset, bit2 environment_step
 __device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s, const mel_env_obs& o,
                                            int64_t row, int lane) {
     const int n = e.n_nodes;
@@ -384,7 +385,65 @@ __device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s
         }
         if (o.active_nb) o.active_nb[row] = valid ? (nb & ~(s.truncated & ~s.agents)) : 0ull;   // :198-203
     }
-    return dead | (explicit_reset << 1);
+    return dead | (explicit_reset << 1) | (environment_step << 2);
+}
+
+// One whole env round per launch (round-batched loop): the AEC steps of GraphEnv.step are replayed in the
+// reference's order - pending dead agents first (graph.py:304-310,359), then every active agent in id
+// order with ITS action (selector.py:25-34) - until the world step fires (graph.py:324-347) or the episode
+// ends.  State evolution is identical to calling env_step + env_observe once per agent.
+struct RoundArgs {
+    mel_env_batch env;
+    mel_episode_pool pool;
+    const int32_t* actions;        // [rows] one action per (env, active agent), rows ordered by env, agent id
+    const int32_t* row_offsets;    // [B+1] first row of each env (as mel_ldgn_forward_agents wrote them)
+    uint64_t* live;                // [B] in: the active set the actions were computed for; out: next round's
+    const int32_t* episode_table;
+    int table_stride;
+    int first;                     // 1: only publish the active set (no step) - used right after a reset
+};
+
+__global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.env.n_envs) return;
+    const int lane = lane_id();
+    const int n = a.env.n_nodes;
+    Env s;
+    env_load(a.env, b, lane, s);
+    const mel_env_obs none{};
+    if (!a.first) {
+        const uint64_t live_in = a.live[b];
+        const int base = a.row_offsets[b];
+        for (int it = 0; it < 3 * n + 4; ++it) {
+            const int sel = s.sel;
+            if (sel < 0) {
+                s.error |= 2;
+                break;
+            }
+            int action = 0;
+            if (!((s.terminated >> sel) & 1ull)) {
+                if (!((live_in >> sel) & 1ull)) {          // an agent acts that the forward did not cover
+                    s.error |= 4;
+                    break;
+                }
+                action = a.actions[base + rank_below(live_in, sel)];
+            }
+            env_step(a.env, a.pool, b, s, action, lane);
+            const int r = env_observe(a.env, b, s, none, 0, lane);
+            if (r & 1) s.done_count += 1;
+            if ((r & 1) && ((r & 2) || s.done_count == n)) {                  // episode over
+                s.episodes_done += 1;
+                const int ep = a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)];
+                env_reset(a.env, a.pool, b, s, ep, 0, lane);
+                env_observe(a.env, b, s, none, 0, lane);
+                break;
+            }
+            if (r & 4) break;                                                  // world step done: new round
+        }
+    }
+    // agents that will act in the coming round: exactly the selector's active set (selector.py:22-34,43-44)
+    if (lane == 0) a.live[b] = s.sel_active;
+    env_store(a.env, b, lane, s);
 }
 
 struct StepArgs {
@@ -539,6 +598,23 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(env_kernel<OP_STEP>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_step");
+}
+
+mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
+                         const int32_t* row_offsets, uint64_t* live, const int32_t* episode_table,
+                         int32_t table_stride, int32_t first, void* stream) {
+    if (mel_status st = check_env(env, env->n_envs)) return st;
+    if (mel_status st = check_pool(env, pool)) return st;
+    if (!live) return fail(MEL_ERR_INVALID_ARG, "live mask buffer is null");
+    if (!first && (!actions || !row_offsets || !episode_table || table_stride < 1))
+        return fail(MEL_ERR_INVALID_ARG, "round step needs actions, row offsets and an episode table");
+    clear_stale_error();
+    RoundArgs a{};
+    a.env = *env, a.pool = *pool, a.actions = actions, a.row_offsets = row_offsets, a.live = live;
+    a.episode_table = episode_table, a.table_stride = table_stride, a.first = first;
+    StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("env_round");
 }
 
 mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n, const mel_env_obs* out,

@@ -52,21 +52,32 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
 }
 
 // ------------------------------------------------------------------------------------------------
-// plan: one wavefront per observation row, lane = node
+// plan: one wavefront per env (= observation row), lane = node
+//
+// The forward is evaluated for a SET of controlling agents per env (mask L).  The reference's collector
+// presents one agent per observation row (L = {obs[:, -1]}, common.py:63); within one env round every
+// active agent sees the same obs_matrix (graph.py:186-188: rows differ only in the last column), so the
+// round-batched loop passes all of a round's agents at once and the encoder / conv1 work is shared:
+//   U1 = union over g in L of closed one-hop(g)   - conv1 targets that can reach some agent's logits
+//   U2 = union over t in U1 of closed one-hop(t)  - their sources
+// Rows are packed per env in id order, so the packed position of node j is popcount(mask below j).
 // ------------------------------------------------------------------------------------------------
 struct PlanBuffers {
     uint64_t* adj;      // [bs*N] sources of target i (radius rule, self excluded)
-    int32_t* gidx;      // [bs]   controlling agent (common.py:63)
-    uint64_t* s1;       // [bs]   closed one-hop set of g   (targets of conv1 that reach the logits)
-    uint64_t* s2;       // [bs]   closed two-hop set of g   (sources of those targets)
-    int32_t* cnt;       // [2*bs] |s1|, |s2|
-    int32_t* off1;      // [bs+1] exclusive scan of |s1| (off1[bs] = total)
+    uint64_t* live;     // [bs]   L: controlling agents of the env
+    uint64_t* u1;       // [bs]
+    uint64_t* u2;       // [bs]
+    int32_t* cnt;       // [3*bs] |L|, |U1|, |U2|
+    int32_t* offL;      // [bs+1] exclusive scans (last entry = total)
+    int32_t* off1;      // [bs+1]
     int32_t* off2;      // [bs+1]
-    int32_t* nid2;      // [sum|s2|] global node id of packed row
-    int32_t* arow1;     // [sum|s1|] row of the |s2| list holding the same node
-    float* dm1;         // [sum|s1|] decision-maker flag of the node (l_dgn.py:128)
-    int32_t* arow_g;    // [bs] row of the |s1| list holding g
-    float* dm_g;        // [bs]
+    int32_t* nid2;      // [sum|U2|] global node id (b*N + i) of packed row
+    int32_t* arow1;     // [sum|U1|] row of the U2 list holding the same node
+    float* dm1;         // [sum|U1|] decision-maker flag of the node (l_dgn.py:128)
+    int32_t* row_env;   // [R] env of agent row r
+    int32_t* row_agent; // [R] agent (node id) of agent row r
+    int32_t* arow_g;    // [R] row of the U1 list holding the agent
+    float* dm_g;        // [R]
 };
 
 // [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
@@ -85,13 +96,15 @@ __device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, i
     return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
 }
 
+// agent_mask == null: one agent per row, taken from the index column (common.py:63)
 __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict__ obs, int bs, int n,
-                                                         int obs_width, int node_cols, PlanBuffers p,
+                                                         int obs_stride, int node_cols,
+                                                         const uint64_t* __restrict__ agent_mask, PlanBuffers p,
                                                          int want_receptive) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
-    const float* row = obs + (size_t)b * obs_width;
+    const float* row = obs + (size_t)b * obs_stride;
     float x = 0.f, y = 0.f;
     if (lane < n) {
         x = row[lane * node_cols];
@@ -99,82 +112,92 @@ __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict
     }
     const uint64_t src = radius_sources(x, y, lane, n);
     if (lane < n) p.adj[(size_t)b * n + lane] = src;
-    // common.py:63: obs[:, -1].clamp(0, N-1).long()
-    float gf = row[obs_width - 1];
-    gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
-    const int g = (int)gf;
+    const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+    uint64_t live;
+    if (agent_mask) {
+        live = agent_mask[b] & full;
+    } else {                               // obs[:, -1].clamp(0, N-1).long()
+        float gf = row[n * node_cols];
+        gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
+        live = 1ull << (int)gf;
+    }
     if (!want_receptive) {
-        if (lane == 0) p.gidx[b] = g;
+        if (lane == 0) p.live[b] = live;
         return;
     }
     const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
-    const uint64_t s1 = readlane_u64(closed, g);
-    const uint64_t s2 = wave_or_u64(((s1 >> lane) & 1ull) ? closed : 0ull);
+    const uint64_t u1 = wave_or_u64(((live >> lane) & 1ull) ? closed : 0ull);
+    const uint64_t u2 = wave_or_u64(((u1 >> lane) & 1ull) ? closed : 0ull);
     if (lane == 0) {
-        p.gidx[b] = g;
-        p.s1[b] = s1;
-        p.s2[b] = s2;
-        p.cnt[b] = __popcll(s1);
-        p.cnt[bs + b] = __popcll(s2);
+        p.live[b] = live;
+        p.u1[b] = u1;
+        p.u2[b] = u2;
+        p.cnt[b] = __popcll(live);
+        p.cnt[bs + b] = __popcll(u1);
+        p.cnt[2 * bs + b] = __popcll(u2);
     }
 }
 
-// exclusive scans of |s1| and |s2| over the batch (single workgroup, any bs)
+// exclusive scans of |L|, |U1|, |U2| over the batch (single workgroup, any bs)
 __global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) {
-    __shared__ int32_t part[2][1024];
+    __shared__ int32_t part[3][1024];
     const int tid = threadIdx.x;
     const int per = (bs + 1023) / 1024;
     const int lo = min(tid * per, bs), hi = min(lo + per, bs);
-    int32_t s1 = 0, s2 = 0;
-    for (int b = lo; b < hi; ++b) {
-        s1 += p.cnt[b];
-        s2 += p.cnt[bs + b];
-    }
-    part[0][tid] = s1;
-    part[1][tid] = s2;
+    int32_t s[3] = {0, 0, 0};
+    for (int b = lo; b < hi; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += p.cnt[k * bs + b];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[k][tid] = s[k];
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        int32_t a1 = 0, a2 = 0;
-        if (tid >= d) {
-            a1 = part[0][tid - d];
-            a2 = part[1][tid - d];
-        }
+        int32_t a[3] = {0, 0, 0};
+        if (tid >= d)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[k] = part[k][tid - d];
         __syncthreads();
-        part[0][tid] += a1;
-        part[1][tid] += a2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) part[k][tid] += a[k];
         __syncthreads();
     }
-    int32_t o1 = part[0][tid] - s1, o2 = part[1][tid] - s2;
+    int32_t o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = part[k][tid] - s[k];
     for (int b = lo; b < hi; ++b) {
-        p.off1[b] = o1;
-        p.off2[b] = o2;
-        o1 += p.cnt[b];
-        o2 += p.cnt[bs + b];
+        p.offL[b] = o[0], p.off1[b] = o[1], p.off2[b] = o[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] += p.cnt[k * bs + b];
     }
-    if (tid == 1023) {
-        p.off1[bs] = part[0][1023];
-        p.off2[bs] = part[1][1023];
-    }
+    if (tid == 1023) p.offL[bs] = part[0][1023], p.off1[bs] = part[1][1023], p.off2[bs] = part[2][1023];
 }
 
 __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
-                                                         int obs_width, int node_cols, PlanBuffers p) {
+                                                         int obs_stride, int node_cols, PlanBuffers p,
+                                                         int32_t* __restrict__ row_offsets_out) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
-    const uint64_t s1 = p.s1[b], s2 = p.s2[b];
-    const int o1 = p.off1[b], o2 = p.off2[b];
-    const float* row = obs + (size_t)b * obs_width;
-    if ((s2 >> lane) & 1ull) p.nid2[o2 + rank_below(s2, lane)] = b * n + lane;
-    if ((s1 >> lane) & 1ull) {
-        const int r1 = o1 + rank_below(s1, lane);
-        p.arow1[r1] = o2 + rank_below(s2, lane);
-        p.dm1[r1] = row[lane * node_cols + node_cols - 1];
+    const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
+    const int oL = p.offL[b], o1 = p.off1[b], o2 = p.off2[b];
+    const float* row = obs + (size_t)b * obs_stride;
+    const float dm = (lane < n) ? row[lane * node_cols + node_cols - 1] : 0.f;
+    if ((u2 >> lane) & 1ull) p.nid2[o2 + rank_below(u2, lane)] = b * n + lane;
+    if ((u1 >> lane) & 1ull) {
+        const int r1 = o1 + rank_below(u1, lane);
+        p.arow1[r1] = o2 + rank_below(u2, lane);
+        p.dm1[r1] = dm;
     }
-    if (lane == 0) {
-        const int g = p.gidx[b];
-        p.arow_g[b] = o1 + rank_below(s1, g);
-        p.dm_g[b] = row[g * node_cols + node_cols - 1];
+    if ((live >> lane) & 1ull) {
+        const int r = oL + rank_below(live, lane);
+        p.row_env[r] = b;
+        p.row_agent[r] = lane;
+        p.arow_g[r] = o1 + rank_below(u1, lane);
+        p.dm_g[r] = dm;
+    }
+    if (row_offsets_out && lane == 0) {
+        row_offsets_out[b] = oL;
+        if (b == bs - 1) row_offsets_out[bs] = p.offL[bs];
     }
 }
 
@@ -194,24 +217,27 @@ struct AttArgs {
     const float* att;       // [heads*C]
     const float* bias;      // [heads*C]
     const uint64_t* adj;    // [bs*N]
-    const int32_t* gidx;    // [bs]
-    const uint64_t* tmask;  // [bs] targets (ATT_ROWS with receptive field) or null = all nodes
+    const uint64_t* live;   // [bs] controlling agents (ATT_ROWS: whose x_1 / x_2 go to the head input)
+    const uint64_t* tmask;  // [bs] targets, or null = all nodes
     const uint64_t* smask;  // [bs] set the source rows are packed by, or null = all nodes
     const int32_t* toff;    // [bs] first target row, or null = b*N
     const int32_t* soff;    // [bs] first source row, or null = b*N
+    const int32_t* loff;    // [bs+1] first agent row of the env (ATT_ROWS) / row count at [bs] (ATT_SINGLE)
     int bs, n, lanes_per_head;
     // ATT_ROWS
     float* out;             // [rows, ldo] relu(out + bias)
     int ldo;
-    float* xcat;            // [bs, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
+    float* xcat;            // [R, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
     int ld_cat, hidden;
     const float* h0;        // encoder rows (packed by smask), [*, hidden]
     // ATT_POOL
     const float* obs;       // dm flag source
-    int obs_width, node_cols, aggregator;
+    int obs_stride, node_cols, aggregator;
     float* pooled;          // [bs, heads*C]
-    // ATT_SINGLE
-    int cat_off;
+    // ATT_SINGLE: one target per agent row
+    const int32_t* row_env;
+    const int32_t* row_agent;
+    int rows_cap, cat_off;
 };
 
 template <int VPL>
@@ -293,14 +319,14 @@ __global__ __launch_bounds__(256) void gat_attend_kernel(AttArgs a) {
     const uint64_t full = (a.n == 64) ? ~0ull : ((1ull << a.n) - 1ull);
 
     if constexpr (MODE == ATT_SINGLE) {
-        // conv2 of L-DGN: only the controlling agent's row can reach the logits (l_dgn.py:135)
-        const int b = blockIdx.x * 4 + wave;
-        if (b >= a.bs) return;
-        const int g = a.gidx[b];
+        // conv2 of L-DGN: only the controlling agent's row can reach its logits (l_dgn.py:135)
+        const int r = blockIdx.x * 4 + wave;
+        if (r >= a.rows_cap || r >= a.loff[a.bs]) return;
+        const int b = a.row_env[r], g = a.row_agent[r];
         const uint64_t sources = a.adj[(size_t)b * a.n + g] | (1ull << g);
-        const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)b * a.ld_r, sources, a.smask[b], a.soff[b],
+        const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)r * a.ld_r, sources, a.smask[b], a.soff[b],
                                               att, bias, lane);
-        store_vec<VPL>(a.xcat + (size_t)b * a.ld_cat + a.cat_off + lane * VPL, o);
+        store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
         return;
     } else {
         const int b = blockIdx.x;
@@ -308,7 +334,9 @@ __global__ __launch_bounds__(256) void gat_attend_kernel(AttArgs a) {
         const uint64_t smask = a.smask ? a.smask[b] : full;
         const int toff = a.toff ? a.toff[b] : b * a.n;
         const int soff = a.soff ? a.soff[b] : b * a.n;
-        const int g = a.gidx[b];
+        uint64_t live = 0;
+        int loff = 0;
+        if constexpr (MODE == ATT_ROWS) live = a.live[b], loff = a.loff[b];
         Vec<VPL> pool;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
@@ -323,16 +351,17 @@ __global__ __launch_bounds__(256) void gat_attend_kernel(AttArgs a) {
                                                   bias, lane);
             if constexpr (MODE == ATT_ROWS) {
                 store_vec<VPL>(a.out + (size_t)trow * a.ldo + lane * VPL, o);
-                if (t == g) {
+                if ((live >> t) & 1ull) {
+                    float* cat = a.xcat + (size_t)(loff + rank_below(live, t)) * a.ld_cat;
                     // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
-                    store_vec<VPL>(a.xcat + (size_t)b * a.ld_cat + a.hidden + lane * VPL, o);
+                    store_vec<VPL>(cat + a.hidden + lane * VPL, o);
                     // x_1: its encoder row (l_dgn.py:122)
-                    const float* h0 = a.h0 + (size_t)(soff + rank_below(smask, g)) * a.hidden;
-                    for (int c = lane; c < a.hidden; c += 64) a.xcat[(size_t)b * a.ld_cat + c] = h0[c];
+                    const float* h0 = a.h0 + (size_t)(soff + rank_below(smask, t)) * a.hidden;
+                    for (int c = lane; c < a.hidden; c += 64) cat[c] = h0[c];
                 }
             } else {
                 // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
-                const float dm = a.obs[(size_t)b * a.obs_width + t * a.node_cols + a.node_cols - 1];
+                const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) {
                     const float v = o.v[i] * dm;
@@ -361,7 +390,7 @@ __global__ __launch_bounds__(256) void gat_attend_kernel(AttArgs a) {
 
 template <int MODE>
 static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const char* what) {
-    const int grid = (MODE == ATT_SINGLE) ? (a.bs + 3) / 4 : a.bs;
+    const int grid = (MODE == ATT_SINGLE) ? (a.rows_cap + 3) / 4 : a.bs;
     switch (hc / 64) {
         case 2: hipLaunchKernelGGL((gat_attend_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a); break;
         case 4: hipLaunchKernelGGL((gat_attend_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a); break;
@@ -378,9 +407,10 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
 __global__ __launch_bounds__(256) void dueling_tail_kernel(const float* __restrict__ hq, int ldq, int kq,
                                                            const float* __restrict__ hv, int ldv, int kv,
                                                            mel_linear q_last, mel_linear v_last, int bs,
-                                                           int dueling, float* __restrict__ logits) {
+                                                           const int32_t* __restrict__ rows_dev, int dueling,
+                                                           float* __restrict__ logits) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= bs) return;
+    if (b >= bs || (rows_dev && b >= *rows_dev)) return;
     const int lane = lane_id();
     const int na = q_last.out_dim;
     float q[8];
@@ -459,8 +489,61 @@ __global__ __launch_bounds__(256) void select_action_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-wise action selection with a counter-based RNG (round-batched loop: row count lives on the device)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {     // lowbias32 integer hash
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ logits,
+                                                          const int32_t* __restrict__ logit_row, long rows_cap,
+                                                          const int32_t* __restrict__ rows_dev, int na, float eps,
+                                                          uint32_t seed, uint32_t step, int32_t* __restrict__ act) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows_cap || (rows_dev && r >= *rows_dev)) return;
+    const float* q = logits + (size_t)(logit_row ? logit_row[r] : r) * na;
+    int best = 0;
+    float bv = -INFINITY;
+    for (int a = 0; a < na; ++a)
+        if (q[a] > bv) bv = q[a], best = a;
+    if (eps > 0.f) {                                   // exploration_noise, on-device stream
+        const uint32_t base = mix32(seed ^ mix32(step * 0x9e3779b9U + (uint32_t)r));
+        if (u01(base) < eps) {
+            best = 0, bv = -1.f;
+            for (int a = 0; a < na; ++a) {
+                const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
+                if (u > bv) bv = u, best = a;
+            }
+        }
+    }
+    act[r] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------------------
+struct Dims {
+    int64_t bs;        // envs / observation rows
+    int n;
+    int64_t rows_cap;  // most agent rows (AEC: bs; round-batched: up to bs*n)
+    int64_t u1_cap;    // most conv1 targets
+    int64_t u2_cap;    // most conv1 sources
+};
+
+static Dims make_dims(int64_t bs, int n, int64_t rows_cap, bool single_agent) {
+    Dims d;
+    d.bs = bs, d.n = n, d.rows_cap = rows_cap;
+    d.u1_cap = single_agent ? bs * (n < 34 ? n : 34) : bs * n;    // |closed one-hop| <= 33 sources + self
+    d.u2_cap = bs * n;
+    return d;
+}
+
 struct FwdLayout {
     PlanBuffers plan;
     float* h0;      // encoder rows
@@ -469,8 +552,8 @@ struct FwdLayout {
     float* h1;      // conv1 output rows
     float* xl2;
     float* xr2;
-    float* xcat;    // head input [bs, latent]
-    float* hq[2];   // head hidden ping-pong [bs, qw + vw]
+    float* xcat;    // head input [rows, latent]
+    float* hq[2];   // head hidden ping-pong [rows, qw + vw]
     float* minmax;
     size_t bytes;
 };
@@ -481,56 +564,62 @@ static int head_hidden_width(const mel_mlp& m) {
     return w;
 }
 
-static FwdLayout carve(const mel_weights* w, int64_t bs, int n, void* ws) {
+static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     FwdLayout L{};
     Carver c(ws);
     const int hidden = w->encoder.layer[1].out_dim;
     const int hc = w->conv1.heads * w->conv1.channels;
-    const size_t M = (size_t)bs * n;
-    const int cap1 = n < 34 ? n : 34;                 // |s1| <= 33 sources + self
+    const size_t M = (size_t)d.bs * d.n;
+    const size_t R = (size_t)d.rows_cap;
     L.plan.adj = c.take<uint64_t>(M);
-    L.plan.gidx = c.take<int32_t>(bs);
+    L.plan.live = c.take<uint64_t>(d.bs);
     const int latent = w->q_head.layer[0].in_dim;
     if (w->model == MEL_MODEL_LDGN) {
-        const size_t R1 = (size_t)bs * cap1;
-        L.plan.s1 = c.take<uint64_t>(bs);
-        L.plan.s2 = c.take<uint64_t>(bs);
-        L.plan.cnt = c.take<int32_t>(2 * bs);
-        L.plan.off1 = c.take<int32_t>(bs + 1);
-        L.plan.off2 = c.take<int32_t>(bs + 1);
-        L.plan.nid2 = c.take<int32_t>(M);
-        L.plan.arow1 = c.take<int32_t>(R1);
-        L.plan.dm1 = c.take<float>(R1);
-        L.plan.arow_g = c.take<int32_t>(bs);
-        L.plan.dm_g = c.take<float>(bs);
-        L.h0 = c.take<float>(M * hidden);
-        L.xl1 = c.take<float>(M * hc);
-        L.xr1 = c.take<float>(R1 * hc);
-        L.h1 = c.take<float>(R1 * hc);
-        L.xl2 = c.take<float>(R1 * hc);
-        L.xr2 = c.take<float>((size_t)bs * hc);
+        L.plan.u1 = c.take<uint64_t>(d.bs);
+        L.plan.u2 = c.take<uint64_t>(d.bs);
+        L.plan.cnt = c.take<int32_t>(3 * d.bs);
+        L.plan.offL = c.take<int32_t>(d.bs + 1);
+        L.plan.off1 = c.take<int32_t>(d.bs + 1);
+        L.plan.off2 = c.take<int32_t>(d.bs + 1);
+        L.plan.nid2 = c.take<int32_t>(d.u2_cap);
+        L.plan.arow1 = c.take<int32_t>(d.u1_cap);
+        L.plan.dm1 = c.take<float>(d.u1_cap);
+        L.plan.row_env = c.take<int32_t>(R);
+        L.plan.row_agent = c.take<int32_t>(R);
+        L.plan.arow_g = c.take<int32_t>(R);
+        L.plan.dm_g = c.take<float>(R);
+        L.h0 = c.take<float>((size_t)d.u2_cap * hidden);
+        L.xl1 = c.take<float>((size_t)d.u2_cap * hc);
+        L.xr1 = c.take<float>((size_t)d.u1_cap * hc);
+        L.h1 = c.take<float>((size_t)d.u1_cap * hc);
+        L.xl2 = c.take<float>((size_t)d.u1_cap * hc);
+        L.xr2 = c.take<float>(R * hc);
     } else {
         L.h0 = c.take<float>(M * hidden);
         L.xl1 = c.take<float>(M * 2 * hc);
     }
-    L.xcat = c.take<float>((size_t)bs * latent);
+    L.xcat = c.take<float>(R * latent);
     const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
-    L.hq[0] = c.take<float>((size_t)bs * (hw > 0 ? hw : 1));
-    L.hq[1] = c.take<float>((size_t)bs * (hw > 0 ? hw : 1));
+    L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
+    L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.minmax = c.take<float>(64);
     L.bytes = c.off;
     return L;
 }
 
-static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, int obs_width) {
+static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, int obs_stride, bool index_col) {
     if (!w) return fail(MEL_ERR_INVALID_ARG, "weights pointer is null");
     if (w->model != model) return fail(MEL_ERR_INVALID_ARG, "weights are for model %d, entry point is for %d", w->model, model);
     if (bs <= 0 || bs > (1 << 24)) return fail(MEL_ERR_INVALID_ARG, "bs=%ld out of range", (long)bs);
     if (n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, %d]", n, MEL_MAX_NODES);
     if (w->in_dim < 1 || w->in_dim > 8) return fail(MEL_ERR_UNSUPPORTED, "in_dim=%d outside [1, 8]", w->in_dim);
     const int expected = n * (w->in_dim + 3);
-    if (obs_width - 1 != expected)      // networks/common.py:24-29
-        return fail(MEL_ERR_SHAPE, "Expected %d feature cols for nodes, got %d", expected, obs_width - 1);
+    if (index_col) {
+        if (obs_stride - 1 != expected)      // networks/common.py:24-29
+            return fail(MEL_ERR_SHAPE, "Expected %d feature cols for nodes, got %d", expected, obs_stride - 1);
+    } else if (obs_stride < expected) {
+        return fail(MEL_ERR_SHAPE, "Expected at least %d feature cols for nodes, got %d", expected, obs_stride);
+    }
     if (w->encoder.n_layers != 2) return fail(MEL_ERR_UNSUPPORTED, "encoder must be a 2-layer MLP");
     const int hidden = w->encoder.layer[1].out_dim;
     if (w->encoder.layer[0].in_dim != w->in_dim || w->encoder.layer[1].in_dim != w->encoder.layer[0].out_dim)
@@ -553,7 +642,7 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
         latent = hidden + 2 * hc;                    // l_dgn.py:44
     }
     const mel_mlp* heads[2] = {&w->q_head, &w->v_head};
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < (w->dueling ? 2 : 1); ++k) {
         const mel_mlp& m = *heads[k];
         if (m.n_layers < 1 || m.n_layers > MEL_MAX_HEAD_LAYERS) return fail(MEL_ERR_UNSUPPORTED, "dueling head depth %d", m.n_layers);
         if (m.layer[0].in_dim != latent) return fail(MEL_ERR_INVALID_ARG, "dueling head expects %d inputs, network produces %d", m.layer[0].in_dim, latent);
@@ -561,15 +650,17 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
             if (m.layer[i].out_dim % 64 || m.layer[i].in_dim % 32 || m.layer[i + 1].in_dim != m.layer[i].out_dim)
                 return fail(MEL_ERR_UNSUPPORTED, "dueling hidden layer %d shape %dx%d unsupported", i, m.layer[i].out_dim, m.layer[i].in_dim);
     }
-    if (w->q_head.n_layers != w->v_head.n_layers) return fail(MEL_ERR_UNSUPPORTED, "Q and V heads must have equal depth");
+    if (w->dueling && w->q_head.n_layers != w->v_head.n_layers) return fail(MEL_ERR_UNSUPPORTED, "Q and V heads must have equal depth");
     if (w->q_head.layer[w->q_head.n_layers - 1].out_dim != w->n_actions || w->n_actions > 8 || w->n_actions < 1)
         return fail(MEL_ERR_UNSUPPORTED, "n_actions=%d outside [1, 8] or inconsistent", w->n_actions);
-    if (w->v_head.layer[w->v_head.n_layers - 1].out_dim != 1) return fail(MEL_ERR_INVALID_ARG, "V head must end in 1 output");
+    if (w->dueling && w->v_head.layer[w->v_head.n_layers - 1].out_dim != 1) return fail(MEL_ERR_INVALID_ARG, "V head must end in 1 output");
     return MEL_OK;
 }
 
-// dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail
-static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t bs, float* logits, hipStream_t s) {
+// dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail.
+// rows_dev (device row count) may be null.
+static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t rows, const int32_t* rows_dev,
+                            long rows_hint, float* logits, hipStream_t s) {
     const int nl = w->q_head.n_layers;
     const float* in_q = L.xcat;
     const float* in_v = L.xcat;
@@ -584,26 +675,122 @@ static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t bs
             GemmArgs g;
             g.A = in_q, g.lda = ld_q;
             g.W = q.weight, g.W_hi = v.weight, g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
-            g.Y = out, g.ldy = ldo, g.M = (int)bs, g.N = ldo, g.K = q.in_dim, g.relu = 1;
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)")) return st;
+            g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint)) return st;
         } else {
             GemmArgs g;
             g.A = in_q, g.lda = ld_q, g.W = q.weight, g.bias = q.bias;
-            g.Y = out, g.ldy = ldo, g.M = (int)bs, g.N = q.out_dim, g.K = q.in_dim, g.relu = 1;
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "Q hidden")) return st;
+            g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = q.out_dim, g.K = q.in_dim, g.relu = 1;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "Q hidden", rows_hint)) return st;
             GemmArgs h;
             h.A = in_v, h.lda = ld_v, h.W = v.weight, h.bias = v.bias;
-            h.Y = out + q.out_dim, h.ldy = ldo, h.M = (int)bs, h.N = v.out_dim, h.K = v.in_dim, h.relu = 1;
-            if (mel_status st = launch_gemm(h, GEMM_MODE_PLAIN, s, "V hidden")) return st;
+            h.Y = out + q.out_dim, h.ldy = ldo, h.M = (int)rows, h.M_dev = rows_dev, h.N = v.out_dim, h.K = v.in_dim, h.relu = 1;
+            if (mel_status st = launch_gemm(h, GEMM_MODE_PLAIN, s, "V hidden", rows_hint)) return st;
         }
         in_q = out, in_v = out + q.out_dim, ld_q = ld_v = ldo;
     }
     const mel_linear& ql = w->q_head.layer[nl - 1];
     const mel_linear& vl = w->v_head.layer[nl - 1];
     StageScope t(MEL_STAGE_HEAD_TAIL, s);
-    hipLaunchKernelGGL(dueling_tail_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
-                       vl.in_dim, ql, vl, (int)bs, w->dueling, logits);
+    hipLaunchKernelGGL(dueling_tail_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
+                       vl.in_dim, ql, vl, (int)rows, rows_dev, w->dueling, logits);
     return check_launch("dueling tail");
+}
+
+// L-DGN for a set of controlling agents per env (agent_mask == null: the index column names one)
+static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, const Dims& d, int obs_stride,
+                                    const uint64_t* agent_mask, float* logits, int32_t* row_offsets_out,
+                                    void* workspace, size_t ws_bytes, hipStream_t s) {
+    if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
+    const FwdLayout L = carve(w, d, workspace);
+    if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
+    clear_stale_error();
+    const int64_t bs = d.bs;
+    const int n = d.n;
+    const int node_cols = w->in_dim + 3;
+    const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
+    const int latent = hidden + 2 * hc;
+    const int R = (int)d.rows_cap, U1 = (int)d.u1_cap, U2 = (int)d.u2_cap;
+    const int32_t* nL = L.plan.offL + bs;
+    const int32_t* n1 = L.plan.off1 + bs;
+    const int32_t* n2 = L.plan.off2 + bs;
+    // expected sizes of the ragged row lists, for tile selection only (mean degree of the r = 0.2 disc
+    // graph is about 0.126 N; the closed two-hop ball covers about a quarter of the unit square; a round has
+    // about N/6 active agents whose neighbourhoods overlap)
+    const bool single = agent_mask == nullptr;
+    const long hintL = single ? bs : bs * (long)(n < 6 ? n : n / 6);
+    const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : bs * (long)(n < 4 ? n : (2 * n) / 3);
+    const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : bs * (long)n;
+
+    {
+        StageScope t(MEL_STAGE_PLAN, s);
+        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
+        if (mel_status st = check_launch("plan_masks")) return st;
+        hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
+        if (mel_status st = check_launch("plan_scan")) return st;
+        hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out);
+        if (mel_status st = check_launch("plan_lists")) return st;
+    }
+    {   // encoder on the U2 rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
+        GemmArgs g;
+        g.obs = obs, g.obs_width = obs_stride, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
+        g.nid = L.plan.nid2, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
+        g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
+        g.Y = L.h0, g.ldy = hidden, g.M = U2, g.M_dev = n2, g.N = hidden;
+        g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        StageScope t(MEL_STAGE_ENCODER, s);
+        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", hint2)) return st;
+    }
+    {   // conv1.lin_l on the U2 rows, conv1.lin_r on the U1 rows
+        GemmArgs g;
+        g.A = L.h0, g.lda = hidden, g.W = w->conv1.lin_l.weight, g.bias = w->conv1.lin_l.bias;
+        g.Y = L.xl1, g.ldy = hc, g.M = U2, g.M_dev = n2, g.N = hc, g.K = hidden;
+        {
+            StageScope t(MEL_STAGE_CONV1_LIN, s);
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l", hint2)) return st;
+        }
+        GemmArgs r;
+        r.A = L.h0, r.lda = hidden, r.arow = L.plan.arow1, r.W = w->conv1.lin_r.weight, r.bias = w->conv1.lin_r.bias;
+        r.Y = L.xr1, r.ldy = hc, r.M = U1, r.M_dev = n1, r.N = hc, r.K = hidden;
+        StageScope t(MEL_STAGE_CONV1_LIN_R, s);
+        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r", hint1)) return st;
+    }
+    {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
+        AttArgs a{};
+        a.xl = L.xl1, a.ld_l = hc, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
+        a.adj = L.plan.adj, a.live = L.plan.live, a.tmask = L.plan.u1, a.smask = L.plan.u2;
+        a.toff = L.plan.off1, a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
+        a.lanes_per_head = w->conv1.channels / (hc / 64);
+        a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
+        StageScope t(MEL_STAGE_CONV1_ATT, s);
+        if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
+    }
+    {   // conv2 projections; the decision-maker mask (l_dgn.py:128) rides along as a row scale
+        GemmArgs g;
+        g.A = L.h1, g.lda = hc, g.rscale = L.plan.dm1, g.W = w->conv2.lin_l.weight, g.bias = w->conv2.lin_l.bias;
+        g.Y = L.xl2, g.ldy = hc, g.M = U1, g.M_dev = n1, g.N = hc, g.K = hc;
+        {
+            StageScope t(MEL_STAGE_CONV2_LIN, s);
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l", hint1)) return st;
+        }
+        GemmArgs r;
+        r.A = L.h1, r.lda = hc, r.arow = L.plan.arow_g, r.rscale = L.plan.dm_g;
+        r.W = w->conv2.lin_r.weight, r.bias = w->conv2.lin_r.bias;
+        r.Y = L.xr2, r.ldy = hc, r.M = R, r.M_dev = nL, r.N = hc, r.K = hc;
+        StageScope t(MEL_STAGE_CONV2_LIN_R, s);
+        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv2.lin_r", hintL)) return st;
+    }
+    {   // conv2 attention, one target per agent row -> x_3
+        AttArgs a{};
+        a.xl = L.xl2, a.ld_l = hc, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
+        a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1, a.loff = L.plan.offL;
+        a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
+        a.row_env = L.plan.row_env, a.row_agent = L.plan.row_agent, a.rows_cap = R;
+        a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
+        StageScope t(MEL_STAGE_CONV2_ATT, s);
+        if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
+    }
+    return run_heads(w, L, R, nL, hintL, logits, s);
 }
 
 }  // namespace mel
@@ -613,109 +800,42 @@ using namespace mel;
 extern "C" {
 
 const char* mel_last_error(void) { return g_err; }
-const char* mel_version(void) { return "melissa_hip 0.1 (gfx950)"; }
+const char* mel_version(void) { return "melissa_hip 0.2 (gfx950)"; }
 
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {
     if (!w || bs <= 0 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return 0;
-    return carve(w, bs, n_nodes, nullptr).bytes;
+    return carve(w, make_dims(bs, n_nodes, bs, true), nullptr).bytes;
+}
+
+size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap) {
+    if (!w || bs <= 0 || n_nodes < 1 || n_nodes > MEL_MAX_NODES || rows_cap < 1) return 0;
+    return carve(w, make_dims(bs, n_nodes, rows_cap, false), nullptr).bytes;
 }
 
 mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_width,
                             float* logits, void* workspace, size_t ws_bytes, void* stream) {
-    if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_width)) return st;
-    if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
-    const FwdLayout L = carve(w, bs, n, workspace);
-    if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    clear_stale_error();
-    const int node_cols = w->in_dim + 3;
-    const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
-    const int M = (int)(bs * n);
-    const int cap1 = n < 34 ? n : 34;
-    const int R1 = (int)bs * cap1;
-    const int latent = hidden + 2 * hc;
-    // expected sizes of the ragged row lists, for tile selection only (mean degree of the r = 0.2 disc
-    // graph is about 0.126 N; the closed two-hop ball covers about a quarter of the unit square)
-    const long hint1 = bs * (long)(n < 8 ? n : 2 + n / 8);
-    const long hint2 = bs * (long)(n < 8 ? n : 1 + n / 4);
+    if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_width, true)) return st;
+    return ldgn_forward_impl(w, obs, make_dims(bs, n, bs, true), obs_width, nullptr, logits, nullptr, workspace,
+                             ws_bytes, static_cast<hipStream_t>(stream));
+}
 
-    {
-        StageScope t(MEL_STAGE_PLAN, s);
-        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 1);
-        if (mel_status st = check_launch("plan_masks")) return st;
-        hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
-        if (mel_status st = check_launch("plan_scan")) return st;
-        hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan);
-        if (mel_status st = check_launch("plan_lists")) return st;
-    }
-
-    {   // encoder on the closed two-hop rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
-        GemmArgs g;
-        g.obs = obs, g.obs_width = obs_width, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
-        g.nid = L.plan.nid2, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-        g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
-        g.Y = L.h0, g.ldy = hidden, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hidden;
-        g.K = w->encoder.layer[0].out_dim, g.relu = 1;
-        StageScope t(MEL_STAGE_ENCODER, s);
-        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", hint2)) return st;
-    }
-    {   // conv1.lin_l on the two-hop rows, conv1.lin_r on the one-hop rows
-        GemmArgs g;
-        g.A = L.h0, g.lda = hidden, g.W = w->conv1.lin_l.weight, g.bias = w->conv1.lin_l.bias;
-        g.Y = L.xl1, g.ldy = hc, g.M = M, g.M_dev = L.plan.off2 + bs, g.N = hc, g.K = hidden;
-        {
-            StageScope t(MEL_STAGE_CONV1_LIN, s);
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l", hint2)) return st;
-        }
-        GemmArgs r;
-        r.A = L.h0, r.lda = hidden, r.arow = L.plan.arow1, r.W = w->conv1.lin_r.weight, r.bias = w->conv1.lin_r.bias;
-        r.Y = L.xr1, r.ldy = hc, r.M = R1, r.M_dev = L.plan.off1 + bs, r.N = hc, r.K = hidden;
-        StageScope t(MEL_STAGE_CONV1_LIN_R, s);
-        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r", hint1)) return st;
-    }
-    {   // conv1 attention for the one-hop targets; also drops x_1 and x_2 into the head input
-        AttArgs a{};
-        a.xl = L.xl1, a.ld_l = hc, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
-        a.adj = L.plan.adj, a.gidx = L.plan.gidx, a.tmask = L.plan.s1, a.smask = L.plan.s2;
-        a.toff = L.plan.off1, a.soff = L.plan.off2, a.bs = (int)bs, a.n = n;
-        a.lanes_per_head = w->conv1.channels / (hc / 64);
-        a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
-        StageScope t(MEL_STAGE_CONV1_ATT, s);
-        if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
-    }
-    {   // conv2 projections; the decision-maker mask (l_dgn.py:128) rides along as a row scale
-        GemmArgs g;
-        g.A = L.h1, g.lda = hc, g.rscale = L.plan.dm1, g.W = w->conv2.lin_l.weight, g.bias = w->conv2.lin_l.bias;
-        g.Y = L.xl2, g.ldy = hc, g.M = R1, g.M_dev = L.plan.off1 + bs, g.N = hc, g.K = hc;
-        {
-            StageScope t(MEL_STAGE_CONV2_LIN, s);
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l", hint1)) return st;
-        }
-        GemmArgs r;
-        r.A = L.h1, r.lda = hc, r.arow = L.plan.arow_g, r.rscale = L.plan.dm_g;
-        r.W = w->conv2.lin_r.weight, r.bias = w->conv2.lin_r.bias;
-        r.Y = L.xr2, r.ldy = hc, r.M = (int)bs, r.N = hc, r.K = hc;
-        StageScope t(MEL_STAGE_CONV2_LIN_R, s);
-        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv2.lin_r")) return st;
-    }
-    {   // conv2 attention for the controlling agent only -> x_3
-        AttArgs a{};
-        a.xl = L.xl2, a.ld_l = hc, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
-        a.adj = L.plan.adj, a.gidx = L.plan.gidx, a.smask = L.plan.s1, a.soff = L.plan.off1;
-        a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
-        a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
-        StageScope t(MEL_STAGE_CONV2_ATT, s);
-        if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
-    }
-    return run_heads(w, L, bs, logits, s);
+mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_stride,
+                                   const uint64_t* agent_mask, int64_t rows_cap, float* logits,
+                                   int32_t* row_offsets, void* workspace, size_t ws_bytes, void* stream) {
+    if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_stride, false)) return st;
+    if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "agent_mask is null");
+    if (rows_cap < 1 || rows_cap > bs * (int64_t)n) return fail(MEL_ERR_INVALID_ARG, "rows_cap=%ld outside [1, bs*n]", (long)rows_cap);
+    return ldgn_forward_impl(w, obs, make_dims(bs, n, rows_cap, false), obs_stride, agent_mask, logits, row_offsets,
+                             workspace, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
                              int32_t obs_width, float* logits, void* workspace, size_t ws_bytes, void* stream) {
-    if (mel_status st = validate(w, MEL_MODEL_HLDGN, bs, n, obs_width)) return st;
+    if (mel_status st = validate(w, MEL_MODEL_HLDGN, bs, n, obs_width, true)) return st;
     if (aggregator < MEL_AGG_MAX || aggregator > MEL_AGG_ADD) return fail(MEL_ERR_INVALID_ARG, "aggregator %d", aggregator);
     if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
-    const FwdLayout L = carve(w, bs, n, workspace);
+    const Dims d = make_dims(bs, n, bs, true);
+    const FwdLayout L = carve(w, d, workspace);
     if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     clear_stale_error();
@@ -725,7 +845,9 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
-        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, 0);
+        // hl_dgn.py:108 pools over the whole graph: the controlling index is read (and clamped) but unused
+        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
+                           (const uint64_t*)nullptr, L.plan, 0);
         if (mel_status st = check_launch("plan_masks")) return st;
     }
     {
@@ -749,14 +871,14 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
     {
         AttArgs a{};
         a.xl = L.xl1, a.ld_l = 2 * hc, a.xr = L.xl1 + hc, a.ld_r = 2 * hc;
-        a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj, a.gidx = L.plan.gidx;
+        a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
-        a.obs = obs, a.obs_width = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
+        a.obs = obs, a.obs_stride = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
         a.pooled = L.xcat;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
-    return run_heads(w, L, bs, logits, s);
+    return run_heads(w, L, bs, nullptr, bs, logits, s);
 }
 
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
@@ -769,21 +891,23 @@ mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float
     return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_f32", -1, tile);
 }
 
-mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n, const void* workspace,
-                           void* out, void* stream) {
+mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n, int64_t rows_cap,
+                           const void* workspace, void* out, void* stream) {
     if (!w || !workspace || !out || bs <= 0 || n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "bad tap arguments");
-    const FwdLayout L = carve(w, bs, n, const_cast<void*>(workspace));
+    const bool single = rows_cap <= 0;
+    const Dims d = make_dims(bs, n, single ? bs : rows_cap, single);
+    const FwdLayout L = carve(w, d, const_cast<void*>(workspace));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    clear_stale_error();
     hipError_t e;
     if (kind == 0)
         e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
     else if (kind == 1)
-        e = hipMemcpyAsync(out, L.xcat, (size_t)bs * w->q_head.layer[0].in_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+        e = hipMemcpyAsync(out, L.xcat, (size_t)d.rows_cap * w->q_head.layer[0].in_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
     else if (kind == 2 && w->model == MEL_MODEL_LDGN) {
-        e = hipMemcpyAsync(out, L.plan.off1 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(static_cast<int32_t*>(out) + 1, L.plan.off2 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        int32_t* o = static_cast<int32_t*>(out);
+        e = hipMemcpyAsync(o, L.plan.off1 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o + 1, L.plan.off2 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o + 2, L.plan.offL + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
     } else
         return fail(MEL_ERR_INVALID_ARG, "unknown tap kind %d", kind);
     if (e != hipSuccess) return fail(MEL_ERR_LAUNCH, "tap copy: %s", hipGetErrorString(e));
@@ -852,6 +976,18 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
     hipLaunchKernelGGL(select_action_kernel, dim3((bs + 255) / 256), dim3(256), 0, s, logits, mask, (long)bs, na, eps,
                        rand_u, rand_q, static_cast<const float*>(scratch), act);
     return check_launch("select_action");
+}
+
+mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row, int64_t rows_cap,
+                                  const int32_t* rows_dev, int32_t na, float eps, uint32_t seed, uint32_t step,
+                                  int32_t* act, void* stream) {
+    if (!logits || !act || rows_cap <= 0 || na < 1) return fail(MEL_ERR_INVALID_ARG, "bad select_action_rows arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    clear_stale_error();
+    StageScope t(MEL_STAGE_SELECT, s);
+    hipLaunchKernelGGL(select_rows_kernel, dim3((rows_cap + 255) / 256), dim3(256), 0, s, logits, logit_row, (long)rows_cap,
+                       rows_dev, na, eps, seed, step, act);
+    return check_launch("select_action_rows");
 }
 
 }  // extern "C"

@@ -163,6 +163,10 @@ class HipGraphVectorEnv:
         nbytes = self.env_num * per_env * torch.empty((), dtype=dtype).element_size()
         return self.state[off: off + nbytes].view(dtype).view(self.env_num, per_env)
 
+    def obs_matrix(self) -> torch.Tensor:
+        """[B, 8N] fp32 view of GraphEnv.obs_matrix of every env (device; what the round-batched forward reads)."""
+        return self._field(self.env.obs_matrix, 8 * self.n, torch.float32)
+
     def positions(self):
         return self._field(self.env.pos, 2 * self.n, torch.float64).view(self.env_num, self.n, 2)
 
@@ -259,6 +263,16 @@ class HipGraphVectorEnv:
                                           self.env_num, 0, C.byref(out.struct) if out is not None else None,
                                           self._stream()), "mel_env_reset")
         self._graph_loaded[:] = True
+
+    def round_device(self, pool: DevicePool, actions: torch.Tensor | None, row_offsets: torch.Tensor | None,
+                     live: torch.Tensor, episode_table: torch.Tensor | None, first: bool = False):
+        """One whole env round for every env (mel_env_round).  ``live`` int64 [B] is read (the active sets the
+        actions were computed for) and overwritten with the next round's active sets."""
+        _lib.check(self.lib.mel_env_round(
+            C.byref(self.env), C.byref(pool.struct), actions.data_ptr() if actions is not None else None,
+            row_offsets.data_ptr() if row_offsets is not None else None, live.data_ptr(),
+            episode_table.data_ptr() if episode_table is not None else None,
+            episode_table.shape[1] if episode_table is not None else 0, int(first), self._stream()), "mel_env_round")
 
     def step_device(self, pool: DevicePool, actions: torch.Tensor, out: ObsBuffers | None,
                     episode_table: torch.Tensor | None = None):

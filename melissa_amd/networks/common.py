@@ -175,18 +175,48 @@ class HipForwardMixin:
         _lib.check(st, type(self).__name__ + ".forward")
         return out
 
-    def hip_tap(self, kind: int, bs: int) -> torch.Tensor:
-        """Parity tap after hip_forward: 0 = adjacency masks [bs, N] int64 bit patterns, 1 = head input."""
+    def hip_tap(self, kind: int, bs: int, rows_cap: int = 0) -> torch.Tensor:
+        """Parity tap after a HIP forward: 0 = adjacency masks [bs, N] int64 bit patterns, 1 = head input
+        [rows, latent], 2 = int32 [3] rows processed (sum|U1|, sum|U2|, agent rows).  ``rows_cap`` = 0 after
+        ``hip_forward``, else the cap given to ``hip_forward_agents``."""
         lib = _lib.load()
         w = self._weights()
-        ws = self._ws
+        ws = self._ws_agents if rows_cap else self._ws
         if kind == 0:
             out = torch.empty(bs, self.agents_num, dtype=torch.int64, device=ws.device)
+        elif kind == 1:
+            out = torch.empty(rows_cap or bs, w.q_head.layer[0].in_dim, dtype=torch.float32, device=ws.device)
         else:
-            out = torch.empty(bs, w.q_head.layer[0].in_dim, dtype=torch.float32, device=ws.device)
-        _lib.check(lib.mel_forward_tap(C.byref(w), kind, bs, self.agents_num, ws.data_ptr(), out.data_ptr(),
+            out = torch.zeros(3, dtype=torch.int32, device=ws.device)
+        _lib.check(lib.mel_forward_tap(C.byref(w), kind, bs, self.agents_num, rows_cap, ws.data_ptr(), out.data_ptr(),
                                        _lib.current_stream_ptr(ws.device)), "mel_forward_tap")
         return out
+
+    def hip_forward_agents(self, obs_matrix: torch.Tensor, agent_mask: torch.Tensor, rows_cap: int,
+                           out: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None):
+        """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
+        [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
+        patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
+        if self._MODEL != _lib.MODEL_LDGN:
+            raise RuntimeError("hip_forward_agents is the L-DGN entry point")
+        lib = _lib.load()
+        assert obs_matrix.is_cuda and obs_matrix.dtype == torch.float32 and obs_matrix.stride(-1) == 1
+        bs = obs_matrix.shape[0]
+        w = self._weights()
+        need = int(lib.mel_workspace_bytes_agents(C.byref(w), bs, self.agents_num, rows_cap))
+        ws = getattr(self, "_ws_agents", None)
+        if ws is None or ws.numel() < need or ws.device != obs_matrix.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=obs_matrix.device)
+            self._ws_agents = ws
+        if out is None:
+            out = torch.empty(rows_cap, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
+        if row_offsets is None:
+            row_offsets = torch.empty(bs + 1, dtype=torch.int32, device=obs_matrix.device)
+        st = lib.mel_ldgn_forward_agents(C.byref(w), obs_matrix.data_ptr(), bs, self.agents_num, obs_matrix.stride(0),
+                                         agent_mask.data_ptr(), rows_cap, out.data_ptr(), row_offsets.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+        _lib.check(st, "mel_ldgn_forward_agents")
+        return out, row_offsets
 
     def _prepare_obs(self, obs):
         if isinstance(obs, np.ndarray):                       # l_dgn.py:103-104

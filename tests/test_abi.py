@@ -18,7 +18,7 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
     header = open(os.path.join(ROOT, "include", "melissa_hip.h")).read()
-    declared = set(re.findall(r"^(?:mel_status|size_t|const char\*|void\*|void|int32_t)\s+(mel_[a-z_]+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:mel_status|size_t|const char\*|void\*|void|int32_t)\s+(mel_[a-z_0-9]+)\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name

@@ -1,0 +1,145 @@
+"""GPU parity of the round-batched path: mel_ldgn_forward_agents rows equal the per-row forward / the
+oracle, and mel_env_round leaves every env in exactly the state the oracle reaches by replaying the same
+actions one AEC step at a time."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
+
+
+def make_ldgn(n, seed=9):
+    from melissa_amd.networks import LDGNNetwork
+    from oracle import net_oracle as no
+    sd = no.init_weights("l_dgn", seed=seed, random_conv_bias=True)
+    net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    return net, sd
+
+
+def random_obs_matrix(rng, bs, n):
+    m = np.zeros((bs, n, 8), dtype=np.float32)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2] = rng.randint(0, 9, size=(bs, n))
+    m[:, :, 3] = rng.randint(0, 4, size=(bs, n))
+    m[:, :, 4:7] = rng.randint(0, 2, size=(bs, n, 3))
+    m[:, :, 7] = (rng.uniform(size=(bs, n)) > 0.1)
+    return m
+
+
+@pytest.mark.parametrize("n,bs", [(20, 64), (50, 40), (64, 9), (5, 7)])
+def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs):
+    from oracle import net_oracle as no
+    rng = np.random.RandomState(n * 100 + bs)
+    mat = random_obs_matrix(rng, bs, n)
+    masks = np.zeros(bs, dtype=np.uint64)
+    rows = []
+    for b in range(bs):
+        k = rng.randint(0, min(n, 12) + 1)                     # 0..12 agents, some envs with none
+        for a in sorted(rng.choice(n, size=k, replace=False)):
+            masks[b] |= np.uint64(1) << np.uint64(a)
+            rows.append((b, int(a)))
+    net, sd = make_ldgn(n)
+    cap = bs * n
+    obs_matrix = torch.from_numpy(mat.reshape(bs, n * 8)).cuda()
+    with torch.no_grad():
+        logits, offsets = net.hip_forward_agents(obs_matrix, torch.from_numpy(masks.view(np.int64)).cuda(), cap)
+    offsets = offsets.cpu().numpy()
+    assert offsets[-1] == len(rows)
+    assert list(offsets[:-1]) == list(np.concatenate([[0], np.cumsum([bin(int(m)).count("1") for m in masks])])[:-1])
+    # the same (env, agent) rows as explicit observation rows with the index column
+    obs_rows = np.concatenate([mat.reshape(bs, -1)[[b for b, _ in rows]],
+                               np.array([[a] for _, a in rows], dtype=np.float32)], axis=1)
+    with torch.no_grad():
+        per_row = net.hip_forward(torch.from_numpy(obs_rows).cuda()).cpu().numpy()
+        want = no.ldgn_forward(sd, obs_rows, n).numpy()
+    got = logits[:len(rows)].cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    np.testing.assert_allclose(got, per_row, atol=2e-5, rtol=0)
+    totals = net.hip_tap(2, bs, cap).cpu().numpy()
+    assert totals[2] == len(rows) and totals[0] <= totals[1] <= bs * n
+
+
+def oracle_round(pz, act_of_agent):
+    """Replay one env round on the oracle exactly like mel_env_round: dead steps, then each active agent."""
+    n = pz.env.n
+    for _ in range(3 * n + 4):
+        env = pz.env
+        sel = env.agent_selection
+        dead = (env.terminated >> sel) & 1
+        obs, rew, term, trunc, info = pz.step(0 if dead else int(act_of_agent[sel]))
+        if term:
+            pz.done_count += 1
+            if info.get("explicit_reset") or pz.done_count == n:
+                pz.reset()
+                pz.done_count = 0
+                return
+        if info.get("environment_step"):
+            return
+    raise AssertionError("round did not terminate")
+
+
+@pytest.mark.parametrize("n,dynamic", [(20, True), (12, False)])
+def test_round_loop_matches_oracle(n, dynamic):
+    from melissa_amd import _lib as L
+    from melissa_amd.collect import RoundLoop, sample_episode_table
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.policy import DQNPolicy
+    from oracle import env_oracle as eo
+    from oracle import net_oracle as no
+    B, seed, K = 6, 77, 40
+    graphs = synthetic_graph_pool(n, 3, first_seed=50)
+    venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=dynamic, device="cuda", max_moves=48,
+                             construct_like_reference=False)
+    net, sd = make_ldgn(n)
+    # episodes: the oracle env consumes two samplings while it is constructed, so the device starts at #1
+    packed, table = sample_episode_table(venv, 14, seed)
+    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed,
+                     episodes=({k: v for k, v in packed.items()}, np.ascontiguousarray(table[:, 1:])))
+    refs = []
+    for b in range(B):
+        env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in graphs],
+                                dynamic_graph=dynamic,
+                                np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))))
+        pz = eo.OraclePettingZooEnv.__new__(eo.OraclePettingZooEnv)
+        pz.env, pz.n, pz.rewards, pz.done_count = env, n, [0] * n, 0
+        env.last()                                    # the observe after reset (clears is_new_round like the device)
+        refs.append(pz)
+    sets = lambda: venv.node_sets().cpu().numpy().view(np.uint64)
+    checked_rows = 0
+    for it in range(K):
+        live = loop.live.cpu().numpy().view(np.uint64).copy()
+        for b, pz in enumerate(refs):
+            assert int(live[b]) == pz.env.sel_active, (it, b)
+        mat = venv.obs_matrix().cpu().numpy().copy()
+        loop.step()
+        torch.cuda.synchronize()
+        offsets = loop.offsets.cpu().numpy()
+        act = loop.act.cpu().numpy()
+        logits = loop.logits.cpu().numpy()
+        rows = [(b, a) for b in range(B) for a in range(n) if (int(live[b]) >> a) & 1]
+        assert offsets[-1] == len(rows)
+        if rows:
+            obs_rows = np.concatenate([mat[[b for b, _ in rows]], np.array([[a] for _, a in rows], np.float32)], axis=1)
+            want = no.ldgn_forward(sd, obs_rows, n).numpy()
+            np.testing.assert_allclose(logits[:len(rows)], want, atol=TOL, rtol=0)
+            checked_rows += len(rows)
+        for b, pz in enumerate(refs):
+            np.testing.assert_array_equal(mat[b].reshape(n, 8), pz.env.obs_matrix)
+            acts = {a: act[offsets[b] + k] for k, a in enumerate(a for a in range(n) if (int(live[b]) >> a) & 1)}
+            oracle_round(pz, acts)
+        s = sets()
+        sc = venv.scalars().cpu().numpy()
+        pos = venv.positions().cpu().numpy()
+        one_hop = venv.one_hop().cpu().numpy().view(np.uint64)
+        for b, pz in enumerate(refs):
+            e = pz.env
+            assert int(s[b, L.SET_HAS_MESSAGE]) == e.has_message and int(s[b, L.SET_AGENTS]) == e.agents
+            assert int(s[b, L.SET_TERMINATED]) == e.terminated and int(s[b, L.SET_ALIVE]) == e.alive
+            assert int(sc[b, L.S_SELECTION]) == e.agent_selection and int(sc[b, L.S_NUM_MOVES]) == e.num_moves
+            np.testing.assert_array_equal(pos[b], e.pos)
+            assert [int(x) for x in one_hop[b]] == e.adj
+    c = loop.counters()
+    assert c["errors"] == 0 and c["episodes"] >= 3 and checked_rows > 100
