@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py - agent-decisions/s of the Melissa hot path on MI355X.
 
-One "step" = one collector iteration over one GPU's shard of envs (multi_agent_collector.py:150-308):
-L-DGN forward over B observation rows -> mask/argmax -> env.step (+ last(), + on-device episode reset).
+One "step" = one pass of the hot path over one GPU's shard of envs.  Default (--mode round): one whole env
+ROUND per env - ONE L-DGN forward over every (env, active agent) row of the round (the round's agents share
+obs_matrix, graph.py:186-188, so encoder / conv1 work is shared) -> argmax / eps-greedy -> ONE env launch
+that replays the round's AEC steps and the world step (+ on-device episode reset).  --mode aec: the
+reference collector's granularity (multi_agent_collector.py:150-308), one agent decision per env per step.
+Per-env trajectories and logits are identical in both modes.
 Workload = BASELINE.json's metric config: L-DGN, 50-node graphs, 1024 vectorised envs per GPU
 (weak scaling: each rank owns its own 1024 envs, no data-path collective), fp32, dynamic graph (the
 reference CLI default, common.py:51), synthetic connected RGGs + seeded random-init weights.
@@ -37,9 +41,9 @@ def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
 
 
-def build_workload(device, rank, envs, n_nodes, model_name, seed=9):
+def build_workload(device, rank, envs, n_nodes, model_name, mode, seed=9):
     import torch
-    from melissa_amd.collect import DecisionLoop
+    from melissa_amd.collect import DecisionLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
     from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
     from melissa_amd.policy import DQNPolicy
@@ -54,21 +58,23 @@ def build_workload(device, rank, envs, n_nodes, model_name, seed=9):
     venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device,
                              max_moves=48, seed=1000 + rank * envs, construct_like_reference=False)
     policy = DQNPolicy(net)
-    loop = DecisionLoop(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001)   # test eps
+    cls = RoundLoop if mode == "round" else DecisionLoop
+    loop = cls(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001)   # test eps (l_dgn.py:107)
     return net, venv, loop
 
 
-def stage_flops(totals, bs):
-    """ALGORITHMIC FLOPs (2*MAC) per launch of each GEMM stage, from the receptive-field row counts the
-    launch actually processed (pruned work is priced at the pruned count)."""
-    s1, s2 = totals[0], totals[1]
+def stage_flops(totals):
+    """ALGORITHMIC FLOPs (2*MAC) per launch of each GEMM stage, from the row counts the launch actually
+    processed: U1 = conv1 targets, U2 = conv1 sources, R = agent rows (pruned / shared work
+    is priced at the pruned / shared count)."""
+    u1, u2, r = totals[0], totals[1], totals[2]
     return {
-        "encoder": s2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
-        "conv1_lin": 2.0 * s2 * HC * HIDDEN,
-        "conv1_lin_r": 2.0 * s1 * HC * HIDDEN,
-        "conv2_lin": 2.0 * s1 * HC * HC,
-        "conv2_lin_r": 2.0 * bs * HC * HC,
-        "head_hidden": 2.0 * bs * ((HIDDEN + 2 * HC) * 256 + 2 * 128 * 128),
+        "encoder": u2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
+        "conv1_lin": 2.0 * u2 * HC * HIDDEN,
+        "conv1_lin_r": 2.0 * u1 * HC * HIDDEN,
+        "conv2_lin": 2.0 * u1 * HC * HC,
+        "conv2_lin_r": 2.0 * r * HC * HC,
+        "head_hidden": 2.0 * r * ((HIDDEN + 2 * HC) * 256 + 2 * 128 * 128),
     }
 
 
@@ -120,6 +126,7 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn"])
+    ap.add_argument("--mode", default="round", choices=["round", "aec"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -131,7 +138,10 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model)
+    if args.model == "hl_dgn":
+        args.mode = "aec"
+    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode)
+    rows_cap = loop.rows_cap if args.mode == "round" else 0
     lib = _lib.load()
 
     loop.run(args.warmup)
@@ -156,11 +166,12 @@ def main():
     if not args.no_profile and rank == 0:
         prof = lib.mel_prof_create(args.steps * 16)
         totals = torch.zeros(args.steps, 3, dtype=torch.int32, device=device)
+        ws = net._ws_agents if args.mode == "round" else net._ws
         lib.mel_prof_attach(prof)
         for k in range(args.steps):
             loop.step()
             if args.model == "l_dgn":
-                _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, 0, net._ws.data_ptr(),
+                _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, rows_cap, ws.data_ptr(),
                                                totals[k].data_ptr(), _lib.current_stream_ptr(device)))
         lib.mel_prof_attach(None)
         torch.cuda.synchronize()
@@ -169,19 +180,21 @@ def main():
         lib.mel_prof_read(prof, ms, cnt)
         lib.mel_prof_destroy(prof)
         stages = {name: (ms[i] / cnt[i] * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}   # us
-        mean_tot = totals.double().mean(dim=0).cpu().numpy() if args.model == "l_dgn" else (0.0, float(args.envs * args.nodes))
+        mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model == "l_dgn"
+                    else (0.0, float(args.envs * args.nodes), float(args.envs)))
         if args.model == "hl_dgn":
             fl = {"encoder": args.envs * args.nodes * 34048.0, "conv1_lin": 2.0 * args.envs * args.nodes * 2 * HC * HIDDEN,
                   "head_hidden": 2.0 * args.envs * (HC * 256 + 2 * 128 * 128)}
         else:
-            fl = stage_flops(mean_tot, args.envs)
+            fl = stage_flops(mean_tot)
         dom = max(fl, key=lambda k: stages.get(k, 0.0))
         achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": f"gemm_f32_kernel ({dom})", "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": None, "avg_launch_us": round(stages[dom], 2),
                     "algorithmic_flops_per_launch": fl[dom],
-                    "rows_per_launch": {"sum_S1": float(mean_tot[0]), "sum_S2": float(mean_tot[1])}}
+                    "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]),
+                                        "agent_rows": float(mean_tot[2])}}
 
     parallel.barrier()
     if rank != 0:
@@ -194,10 +207,13 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs "
-                               f"per GPU, fp32, dynamic graph, eps=0.001",
+                               f"per GPU, fp32, dynamic graph, eps=0.001, "
+                               + ("round-batched loop (one env round per step)" if args.mode == "round"
+                                  else "AEC-order loop (one agent decision per env per step)"),
+                   "loop": args.mode,
                    "envs_per_gpu": args.envs, "n_nodes": args.nodes, "global_envs": args.envs * world,
                    "parallelism": f"env-shard x{world} (no data-path collective)",
-                   "rows_per_step": args.envs * world, "live_decisions": decisions, "episodes_finished": episodes,
+                   "decisions_per_step": decisions / args.steps, "live_decisions": decisions, "episodes_finished": episodes,
                    "env_error_flags": errors},
         "roofline": roofline,
         "stage_us": {k: round(v, 2) for k, v in (stages or {}).items() if v > 0},

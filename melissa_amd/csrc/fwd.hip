@@ -21,14 +21,14 @@ Profiler* current_profiler() { return g_prof; }
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------------
-template <int TM, int TN>
+template <int WM, int WN, int TM, int TN>
 static void gemm_launch_t(const GemmArgs& g, int mode, hipStream_t s) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;      // 2 x 2 wavefronts
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, TM, TN, GEMM_MODE_ENC>), dim3(grid), dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<2, 2, TM, TN, GEMM_MODE_PLAIN>), dim3(grid), dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
 }
 
 mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint, int force_tile) {
@@ -36,18 +36,25 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
         return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
-    if (force_tile == 1 || (force_tile == 2 && g.N % 128 == 0)) {
-        if (force_tile == 1) gemm_launch_t<1, 1>(g, mode, stream);
-        else gemm_launch_t<2, 2>(g, mode, stream);
+    if (force_tile == 1 || (force_tile >= 2 && g.N % 128 == 0)) {
+        switch (force_tile) {
+            case 1: gemm_launch_t<2, 2, 1, 1>(g, mode, stream); break;     //  64 x  64, 4 waves
+            case 2: gemm_launch_t<2, 2, 2, 2>(g, mode, stream); break;     // 128 x 128, 4 waves
+            case 3: gemm_launch_t<2, 4, 2, 1>(g, mode, stream); break;     // 128 x 128, 8 waves (64x32 each)
+            case 4: gemm_launch_t<4, 2, 1, 2>(g, mode, stream); break;     // 128 x 128, 8 waves (32x64 each)
+            case 5: gemm_launch_t<2, 2, 2, 1>(g, mode, stream); break;     // 128 x  64, 4 waves
+            case 6: gemm_launch_t<2, 2, 1, 2>(g, mode, stream); break;     //  64 x 128, 4 waves
+            default: return fail(MEL_ERR_INVALID_ARG, "unknown tile %d", force_tile);
+        }
         return check_launch(what);
     }
     // 128x128 tiles once they give every CU about two workgroups, else 64x64 tiles (4x the workgroups,
     // a quarter of the per-wave MFMA chain).
     const long big = ((m_hint + 127) / 128) * (g.N / 128);
     if (g.N % 128 == 0 && big >= 448)
-        gemm_launch_t<2, 2>(g, mode, stream);
+        gemm_launch_t<2, 2, 2, 2>(g, mode, stream);
     else
-        gemm_launch_t<1, 1>(g, mode, stream);
+        gemm_launch_t<2, 2, 1, 1>(g, mode, stream);
     return check_launch(what);
 }
 

@@ -9,7 +9,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from melissa_amd import _lib  # noqa: E402
 
-SHAPES = [("conv2_lin", 6630, 512, 512), ("conv1_lin", 12962, 512, 128), ("conv1_lin_r", 6630, 512, 128),
+SHAPES = [("r_conv2_lin", 10653, 512, 512), ("r_conv1_lin", 16131, 512, 128), ("r_conv1_lin_r", 10653, 512, 128),
+          ("r_conv2_lin_r", 4820, 512, 512), ("r_head0", 4820, 256, 1152), ("r_head1", 4820, 128, 128),
+          ("conv2_lin", 6630, 512, 512), ("conv1_lin", 12962, 512, 128), ("conv1_lin_r", 6630, 512, 128),
           ("conv2_lin_r", 1024, 512, 512), ("head0", 1024, 256, 1152), ("head1", 1024, 128, 128),
           ("encoder", 12962, 128, 128), ("hl_conv1", 51200, 1024, 128), ("big", 65536, 512, 512)]
 
