@@ -81,6 +81,8 @@ struct PlanBuffers {
     int32_t* nid2;      // [sum|U2|] global node id (b*N + i) of packed row
     int32_t* arow1;     // [sum|U1|] row of the U2 list holding the same node
     float* dm1;         // [sum|U1|] decision-maker flag of the node (l_dgn.py:128)
+    int32_t* t_env;     // [sum|U1|] env of conv1 target row
+    int32_t* t_node;    // [sum|U1|] node id of conv1 target row
     int32_t* row_env;   // [R] env of agent row r
     int32_t* row_agent; // [R] agent (node id) of agent row r
     int32_t* arow_g;    // [R] row of the U1 list holding the agent
@@ -194,6 +196,8 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict
         const int r1 = o1 + rank_below(u1, lane);
         p.arow1[r1] = o2 + rank_below(u2, lane);
         p.dm1[r1] = dm;
+        p.t_env[r1] = b;
+        p.t_node[r1] = lane;
     }
     if ((live >> lane) & 1ull) {
         const int r = oL + rank_below(live, lane);
@@ -241,9 +245,10 @@ struct AttArgs {
     const float* obs;       // dm flag source
     int obs_stride, node_cols, aggregator;
     float* pooled;          // [bs, heads*C]
-    // ATT_SINGLE: one target per agent row
-    const int32_t* row_env;
-    const int32_t* row_agent;
+    // ATT_ROWS / ATT_SINGLE: one wavefront per target row
+    const int32_t* row_env;     // [rows] env of the row
+    const int32_t* row_agent;   // [rows] target node of the row
+    const int32_t* rows_dev;    // device-side row count
     int rows_cap, cat_off;
 };
 
@@ -280,7 +285,22 @@ __device__ __forceinline__ void store_vec(float* p, const Vec<VPL>& r) {
     }
 }
 
-// attention output of one target for this lane's VPL channels: relu(out + bias)
+// sum over the lanes of one head (lanes_per_head adjacent lanes).  The common case (16 lanes: C = 128,
+// 8 channels per lane) is four DPP moves inside a 16-lane row; anything else falls back to shuffles.
+__device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
+    if (lanes_per_head == 16) {
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, true));  // row_mirror
+        return s;
+    }
+    for (int o = lanes_per_head >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+
+// attention output of one target for this lane's VPL channels: relu(out + bias).  The source rows are
+// streamed once (online softmax); the next row's load is issued before the current row is consumed.
 template <int VPL>
 __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float* xr_row, uint64_t sources,
                                                   uint64_t smask, int soff, const Vec<VPL>& att,
@@ -290,11 +310,18 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
     Vec<VPL> acc;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    while (sources) {
-        const int j = lowest_bit(sources);
-        sources &= sources - 1;
-        const float* xl_row = a.xl + (size_t)(soff + rank_below(smask, j)) * a.ld_l + lane * VPL;
-        const Vec<VPL> xl = load_vec<VPL>(xl_row);
+    const float* base = a.xl + lane * VPL;
+    int j = lowest_bit(sources);                 // never empty: the self-loop is always a source
+    sources &= sources - 1;
+    Vec<VPL> nxt = load_vec<VPL>(base + (size_t)(soff + rank_below(smask, j)) * a.ld_l);
+    for (;;) {
+        const Vec<VPL> xl = nxt;
+        const bool more = sources != 0;
+        if (more) {
+            j = lowest_bit(sources);
+            sources &= sources - 1;
+            nxt = load_vec<VPL>(base + (size_t)(soff + rank_below(smask, j)) * a.ld_l);
+        }
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
@@ -302,13 +329,14 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
             z = z > 0.f ? z : 0.2f * z;          // leaky_relu(negative_slope=0.2)
             s = fmaf(att.v[i], z, s);
         }
-        for (int o = a.lanes_per_head >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        s = head_sum(s, a.lanes_per_head);
         const float mn = fmaxf(m, s);
         const float sc = expf(m - mn), pe = expf(s - mn);
         l = l * sc + pe;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) acc.v[i] = acc.v[i] * sc + pe * xl.v[i];
         m = mn;
+        if (!more) break;
     }
     const float inv = 1.f / (l + 1e-16f);
     Vec<VPL> out;
@@ -317,93 +345,100 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
     return out;
 }
 
+// ATT_ROWS / ATT_SINGLE: ONE WAVEFRONT PER TARGET ROW over the whole batch (envs differ a lot in how many
+// targets they have - a workgroup per env leaves the launch waiting for the few crowded envs).
+//   ATT_ROWS   conv1 of L-DGN: row r of the U1 list -> h1[r]; the agents' x_1 / x_2 go to the head input
+//   ATT_SINGLE conv2 of L-DGN: one target per agent row (only the controlling agent's row can reach its
+//              logits, l_dgn.py:135), sources = its closed neighbourhood inside U1 -> x_3
 template <int VPL, int MODE>
-__global__ __launch_bounds__(256) void gat_attend_kernel(AttArgs a) {
+__global__ __launch_bounds__(256) void gat_attend_rows_kernel(AttArgs a) {
+    const int lane = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.rows_cap || r >= *a.rows_dev) return;
+    const Vec<VPL> att = load_vec<VPL>(a.att + lane * VPL);
+    const Vec<VPL> bias = load_vec<VPL>(a.bias + lane * VPL);
+    const int b = a.row_env[r], t = a.row_agent[r];
+    const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
+    const uint64_t smask = a.smask[b];
+    const int soff = a.soff[b];
+    const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)r * a.ld_r, sources, smask, soff, att, bias, lane);
+    if constexpr (MODE == ATT_SINGLE) {
+        store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
+    } else {
+        store_vec<VPL>(a.out + (size_t)r * a.ldo + lane * VPL, o);
+        const uint64_t live = a.live[b];
+        if ((live >> t) & 1ull) {
+            float* cat = a.xcat + (size_t)(a.loff[b] + rank_below(live, t)) * a.ld_cat;
+            // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
+            store_vec<VPL>(cat + a.hidden + lane * VPL, o);
+            // x_1: its encoder row (l_dgn.py:122)
+            const float* h0 = a.h0 + (size_t)(soff + rank_below(smask, t)) * a.hidden;
+            for (int c = lane; c < a.hidden; c += 64) cat[c] = h0[c];
+        }
+    }
+}
+
+// ATT_POOL (HL-DGN): one workgroup per env (every env has exactly N targets, so this is balanced):
+// conv1 attention for all nodes, decision-maker mask, max / mean / add pool over the graph.
+template <int VPL>
+__global__ __launch_bounds__(256) void gat_attend_pool_kernel(AttArgs a) {
+    constexpr int HC = 64 * VPL;
+    __shared__ float part[4][HC];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
     const Vec<VPL> att = load_vec<VPL>(a.att + lane * VPL);
     const Vec<VPL> bias = load_vec<VPL>(a.bias + lane * VPL);
     const uint64_t full = (a.n == 64) ? ~0ull : ((1ull << a.n) - 1ull);
-
-    if constexpr (MODE == ATT_SINGLE) {
-        // conv2 of L-DGN: only the controlling agent's row can reach its logits (l_dgn.py:135)
-        const int r = blockIdx.x * 4 + wave;
-        if (r >= a.rows_cap || r >= a.loff[a.bs]) return;
-        const int b = a.row_env[r], g = a.row_agent[r];
-        const uint64_t sources = a.adj[(size_t)b * a.n + g] | (1ull << g);
-        const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)r * a.ld_r, sources, a.smask[b], a.soff[b],
-                                              att, bias, lane);
-        store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
-        return;
-    } else {
-        const int b = blockIdx.x;
-        const uint64_t tmask = a.tmask ? a.tmask[b] : full;
-        const uint64_t smask = a.smask ? a.smask[b] : full;
-        const int toff = a.toff ? a.toff[b] : b * a.n;
-        const int soff = a.soff ? a.soff[b] : b * a.n;
-        uint64_t live = 0;
-        int loff = 0;
-        if constexpr (MODE == ATT_ROWS) live = a.live[b], loff = a.loff[b];
-        Vec<VPL> pool;
+    Vec<VPL> pool;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
-        uint64_t rest = tmask;
-        for (int k = 0; rest; ++k) {
-            const int t = lowest_bit(rest);
-            rest &= rest - 1;
-            if ((k & 3) != wave) continue;
-            const int trow = toff + rank_below(tmask, t);
-            const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
-            const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)trow * a.ld_r, sources, smask, soff, att,
-                                                  bias, lane);
-            if constexpr (MODE == ATT_ROWS) {
-                store_vec<VPL>(a.out + (size_t)trow * a.ldo + lane * VPL, o);
-                if ((live >> t) & 1ull) {
-                    float* cat = a.xcat + (size_t)(loff + rank_below(live, t)) * a.ld_cat;
-                    // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
-                    store_vec<VPL>(cat + a.hidden + lane * VPL, o);
-                    // x_1: its encoder row (l_dgn.py:122)
-                    const float* h0 = a.h0 + (size_t)(soff + rank_below(smask, t)) * a.hidden;
-                    for (int c = lane; c < a.hidden; c += 64) cat[c] = h0[c];
-                }
-            } else {
-                // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
-                const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
+    for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
+    for (int t = wave; t < a.n; t += 4) {
+        const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
+        const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)(b * a.n + t) * a.ld_r, sources, full, b * a.n, att,
+                                              bias, lane);
+        // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
+        const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) {
-                    const float v = o.v[i] * dm;
-                    pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? fmaxf(pool.v[i], v) : pool.v[i] + v;
-                }
-            }
+        for (int i = 0; i < VPL; ++i) {
+            const float v = o.v[i] * dm;
+            pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? fmaxf(pool.v[i], v) : pool.v[i] + v;
         }
-        if constexpr (MODE == ATT_POOL) {
-            __shared__ float part[4][64 * VPL];
+    }
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) part[wave][lane * VPL + i] = pool.v[i];
-            __syncthreads();
-            for (int c = threadIdx.x; c < 64 * VPL; c += 256) {
-                float v;
-                if (a.aggregator == MEL_AGG_MAX) {
-                    v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
-                } else {
-                    v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
-                    if (a.aggregator == MEL_AGG_MEAN) v /= (float)a.n;
-                }
-                a.pooled[(size_t)b * (64 * VPL) + c] = v;
-            }
+    for (int i = 0; i < VPL; ++i) part[wave][lane * VPL + i] = pool.v[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < HC; c += 256) {
+        float v;
+        if (a.aggregator == MEL_AGG_MAX) {
+            v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
+        } else {
+            v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+            if (a.aggregator == MEL_AGG_MEAN) v /= (float)a.n;
         }
+        a.pooled[(size_t)b * HC + c] = v;
     }
 }
 
 template <int MODE>
 static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const char* what) {
-    const int grid = (MODE == ATT_SINGLE) ? (a.rows_cap + 3) / 4 : a.bs;
-    switch (hc / 64) {
-        case 2: hipLaunchKernelGGL((gat_attend_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((gat_attend_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((gat_attend_kernel<8, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((gat_attend_kernel<16, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-        default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
+    if constexpr (MODE == ATT_POOL) {
+        switch (hc / 64) {
+            case 2: hipLaunchKernelGGL((gat_attend_pool_kernel<2>), dim3(a.bs), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((gat_attend_pool_kernel<4>), dim3(a.bs), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((gat_attend_pool_kernel<8>), dim3(a.bs), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((gat_attend_pool_kernel<16>), dim3(a.bs), dim3(256), 0, s, a); break;
+            default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
+        }
+    } else {
+        const int grid = (a.rows_cap + 3) / 4;
+        switch (hc / 64) {
+            case 2: hipLaunchKernelGGL((gat_attend_rows_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((gat_attend_rows_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((gat_attend_rows_kernel<8, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((gat_attend_rows_kernel<16, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+            default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
+        }
     }
     return check_launch(what);
 }
@@ -591,6 +626,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         L.plan.nid2 = c.take<int32_t>(d.u2_cap);
         L.plan.arow1 = c.take<int32_t>(d.u1_cap);
         L.plan.dm1 = c.take<float>(d.u1_cap);
+        L.plan.t_env = c.take<int32_t>(d.u1_cap);
+        L.plan.t_node = c.take<int32_t>(d.u1_cap);
         L.plan.row_env = c.take<int32_t>(R);
         L.plan.row_agent = c.take<int32_t>(R);
         L.plan.arow_g = c.take<int32_t>(R);
@@ -631,6 +668,8 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
     const int hidden = w->encoder.layer[1].out_dim;
     if (w->encoder.layer[0].in_dim != w->in_dim || w->encoder.layer[1].in_dim != w->encoder.layer[0].out_dim)
         return fail(MEL_ERR_INVALID_ARG, "encoder layer shapes inconsistent");
+    if (w->encoder.layer[0].out_dim > 256)
+        return fail(MEL_ERR_UNSUPPORTED, "encoder hidden width %d > 256", w->encoder.layer[0].out_dim);
     if (w->encoder.layer[0].out_dim % 32 || hidden % 64)
         return fail(MEL_ERR_UNSUPPORTED, "encoder widths must be multiples of 64 (got %d, %d)", w->encoder.layer[0].out_dim, hidden);
     const int hc = w->conv1.heads * w->conv1.channels;
@@ -765,8 +804,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
         AttArgs a{};
         a.xl = L.xl1, a.ld_l = hc, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
-        a.adj = L.plan.adj, a.live = L.plan.live, a.tmask = L.plan.u1, a.smask = L.plan.u2;
-        a.toff = L.plan.off1, a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
+        a.adj = L.plan.adj, a.live = L.plan.live, a.smask = L.plan.u2;
+        a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
+        a.row_env = L.plan.t_env, a.row_agent = L.plan.t_node, a.rows_dev = n1, a.rows_cap = U1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
@@ -790,9 +830,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv2 attention, one target per agent row -> x_3
         AttArgs a{};
         a.xl = L.xl2, a.ld_l = hc, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
-        a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1, a.loff = L.plan.offL;
+        a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
-        a.row_env = L.plan.row_env, a.row_agent = L.plan.row_agent, a.rows_cap = R;
+        a.row_env = L.plan.row_env, a.row_agent = L.plan.row_agent, a.rows_dev = nL, a.rows_cap = R;
         a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
         StageScope t(MEL_STAGE_CONV2_ATT, s);
         if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;

@@ -67,27 +67,27 @@ enum { GEMM_MODE_PLAIN = 0, GEMM_MODE_ENC = 1 };
 
 // Per-thread staging coordinates of one 16-byte chunk (constant across K steps).
 struct AChunk {
-    const float* src;    // PLAIN: &A[arow(row)][chunk*4]  (null when the row is beyond M)
+    const float* src;    // PLAIN: &A[arow(row)][chunk*4]
     float x[8];          // ENC:   node features
-    bool ok;
 };
+// Rows beyond M are clamped to row M-1 instead of being predicated: a predicated load turns into a branch
+// plus a merge, and the merge makes the compiler wait for the load right where it was issued (no prefetch
+// overlap).  The clamped rows only feed accumulator rows that the epilogue never stores.
 
+// enc: layer-0 weights of the encoder staged in LDS as [K][9] = {w[k][0..7], b[k]} (ENC mode only)
 template <int MODE>
-__device__ __forceinline__ f32x4 fetch_a(const GemmArgs& g, const AChunk& c, int k0, int kc) {
+__device__ __forceinline__ f32x4 fetch_a(const GemmArgs& g, const AChunk& c, int k0, int kc, const float* enc) {
     if constexpr (MODE == GEMM_MODE_PLAIN) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        return c.ok ? *reinterpret_cast<const f32x4*>(c.src + k0) : zero;
+        return *reinterpret_cast<const f32x4*>(c.src + k0);
     } else {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int k = k0 + kc + e;
-            float s = g.enc_b[k];
-            const float* wrow = g.enc_w + (size_t)k * g.in_dim;
+            const float* wrow = enc + (k0 + kc + e) * 9;
+            float s = wrow[8];
 #pragma unroll
-            for (int f = 0; f < 8; ++f)
-                if (f < g.in_dim) s = fmaf(wrow[f], c.x[f], s);
-            v[e] = c.ok ? fmaxf(s, 0.f) : 0.f;
+            for (int f = 0; f < 8; ++f) s = fmaf(wrow[f], c.x[f], s);       // w is zero-padded beyond in_dim
+            v[e] = fmaxf(s, 0.f);
         }
         const f32x4 out = {v[0], v[1], v[2], v[3]};
         return out;
@@ -100,7 +100,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;   // float4 chunks per thread per K step
     constexpr int W_CHUNKS = BN * (GEMM_BK / 4) / T;
     constexpr int BUF = (BM + BN) * GEMM_LDS_STRIDE;   // floats per LDS stage
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    constexpr int ENC_MAX_K = 256;                     // encoder hidden width the ENC producer supports
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + (MODE == GEMM_MODE_ENC ? ENC_MAX_K * 9 : 0)];
+    float* enc = lds + 2 * BUF;
 
     // Tile order.  The row count may be ragged and device-side: only the first `active` workgroup ids
     // have work (the dispatcher deals consecutive ids round-robin over the 8 XCDs, so they are spread
@@ -119,6 +121,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
     const int n0 = (wg % nbn) * BN;
 
     const int tid = threadIdx.x;
+    if constexpr (MODE == GEMM_MODE_ENC) {
+        for (int i = tid; i < g.K * 9; i += T) {
+            const int k = i / 9, f = i - k * 9;
+            enc[i] = f == 8 ? g.enc_b[k] : (f < g.in_dim ? g.enc_w[(size_t)k * g.in_dim + f] : 0.f);
+        }
+        __syncthreads();
+    }
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -129,23 +138,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
     AChunk ac[A_CHUNKS];
 #pragma unroll
     for (int i = 0; i < A_CHUNKS; ++i) {
-        const int row = m0 + crow + i * (T / 8);
-        ac[i].ok = row < M;
+        const int row = min(m0 + crow + i * (T / 8), M - 1);
         ac[i].src = nullptr;
 #pragma unroll
         for (int f = 0; f < 8; ++f) ac[i].x[f] = 0.f;
-        if (ac[i].ok) {
-            if constexpr (MODE == GEMM_MODE_PLAIN) {
-                const int ar = g.arow ? g.arow[row] : row;
-                ac[i].src = g.A + (size_t)ar * g.lda + kc;
-            } else {
-                const int id = g.nid ? g.nid[row] : row;
-                const int b = id / g.n_nodes, node = id - b * g.n_nodes;
-                const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
+        if constexpr (MODE == GEMM_MODE_PLAIN) {
+            const int ar = g.arow ? g.arow[row] : row;
+            ac[i].src = g.A + (size_t)ar * g.lda + kc;
+        } else {
+            const int id = g.nid ? g.nid[row] : row;
+            const int b = id / g.n_nodes, node = id - b * g.n_nodes;
+            const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
 #pragma unroll
-                for (int f = 0; f < 8; ++f)
-                    if (f < g.in_dim) ac[i].x[f] = x[f];
-            }
+            for (int f = 0; f < 8; ++f)
+                if (f < g.in_dim) ac[i].x[f] = x[f];
         }
     }
     const float* w_src[W_CHUNKS];
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
 
     f32x4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(g, ac[i], 0, kc);
+    for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(g, ac[i], 0, kc, enc);
 #pragma unroll
     for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i]);
 #pragma unroll
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
         if (more) {                       // next K step: global loads stay in flight under the MFMAs
             const int k0 = (kt + 1) * GEMM_BK;
 #pragma unroll
-            for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(g, ac[i], k0, kc);
+            for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(g, ac[i], k0, kc, enc);
 #pragma unroll
             for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i] + k0);
         }
