@@ -70,10 +70,8 @@ def stage_flops(totals):
     u1, u2, r = totals[0], totals[1], totals[2]
     return {
         "encoder": u2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
-        "conv1_lin": 2.0 * u2 * HC * HIDDEN,
-        "conv1_lin_r": 2.0 * u1 * HC * HIDDEN,
-        "conv2_lin": 2.0 * u1 * HC * HC,
-        "conv2_lin_r": 2.0 * r * HC * HC,
+        "conv1_lin": 2.0 * (u2 + u1) * HC * HIDDEN,        # lin_l on U2 rows + lin_r on U1 rows, one grouped launch
+        "conv2_lin": 2.0 * (u1 + r) * HC * HC,             # lin_l on U1 rows + lin_r on the agent rows
         "head_hidden": 2.0 * r * ((HIDDEN + 2 * HC) * 256 + 2 * 128 * 128),
     }
 

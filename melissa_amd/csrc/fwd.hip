@@ -22,39 +22,72 @@ Profiler* current_profiler() { return g_prof; }
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN>
-static void gemm_launch_t(const GemmArgs& g, int mode, hipStream_t s) {
+static void gemm_launch_t(const GemmArgs* gs, int count, int mode, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
+    GemmBatch batch{};
+    batch.count = count;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        batch.start[i] = total;
+        const int tiles = ((gs[i].M + BM - 1) / BM) * (gs[i].N / BN);
+        total += (tiles + 7) & ~7;               // keep every problem's ids aligned to the 8 XCDs
+    }
+    batch.start[count] = total;
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(grid), dim3(64 * WM * WN), 0, s, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
+}
+
+static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
+    if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
+        return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
+    return MEL_OK;
 }
 
 mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint, int force_tile) {
     if (g.M <= 0) return MEL_OK;
-    if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
-        return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
+    if (mel_status st = check_gemm_shape(g, what)) return st;
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
     if (force_tile == 1 || (force_tile >= 2 && g.N % 128 == 0)) {
         switch (force_tile) {
-            case 1: gemm_launch_t<2, 2, 1, 1>(g, mode, stream); break;     //  64 x  64, 4 waves
-            case 2: gemm_launch_t<2, 2, 2, 2>(g, mode, stream); break;     // 128 x 128, 4 waves
-            case 3: gemm_launch_t<2, 4, 2, 1>(g, mode, stream); break;     // 128 x 128, 8 waves (64x32 each)
-            case 4: gemm_launch_t<4, 2, 1, 2>(g, mode, stream); break;     // 128 x 128, 8 waves (32x64 each)
-            case 5: gemm_launch_t<2, 2, 2, 1>(g, mode, stream); break;     // 128 x  64, 4 waves
-            case 6: gemm_launch_t<2, 2, 1, 2>(g, mode, stream); break;     //  64 x 128, 4 waves
+            case 1: gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream); break;     //  64 x  64, 4 waves
+            case 2: gemm_launch_t<2, 2, 2, 2>(&g, 1, mode, stream); break;     // 128 x 128, 4 waves
+            case 3: gemm_launch_t<2, 4, 2, 1>(&g, 1, mode, stream); break;     // 128 x 128, 8 waves (64x32 each)
+            case 4: gemm_launch_t<4, 2, 1, 2>(&g, 1, mode, stream); break;     // 128 x 128, 8 waves (32x64 each)
+            case 5: gemm_launch_t<2, 2, 2, 1>(&g, 1, mode, stream); break;     // 128 x  64, 4 waves
+            case 6: gemm_launch_t<2, 2, 1, 2>(&g, 1, mode, stream); break;     //  64 x 128, 4 waves
             default: return fail(MEL_ERR_INVALID_ARG, "unknown tile %d", force_tile);
         }
         return check_launch(what);
     }
-    // 128x128 tiles once they give every CU about two workgroups, else 64x64 tiles (4x the workgroups,
-    // a quarter of the per-wave MFMA chain).
+    // Measured (tools/gemm_bench.py): the 64x64 tile (4x the workgroups, a quarter of the per-wave MFMA
+    // chain, 4 workgroups per CU) wins or ties everywhere except long-K problems with thousands of tiles.
     const long big = ((m_hint + 127) / 128) * (g.N / 128);
-    if (g.N % 128 == 0 && big >= 448)
-        gemm_launch_t<2, 2, 2, 2>(g, mode, stream);
+    if (g.N % 128 == 0 && big >= 1536 && g.K >= 512)
+        gemm_launch_t<2, 2, 2, 2>(&g, 1, mode, stream);
     else
-        gemm_launch_t<2, 2, 1, 1>(g, mode, stream);
+        gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream);
+    return check_launch(what);
+}
+
+mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, hipStream_t stream, const char* what) {
+    if (count < 1 || count > GEMM_MAX_GROUP) return fail(MEL_ERR_INVALID_ARG, "%s: group of %d", what, count);
+    long big = 0;
+    bool n128 = true, long_k = true;
+    for (int i = 0; i < count; ++i) {
+        if (gs[i].M <= 0) return fail(MEL_ERR_INVALID_ARG, "%s: empty problem in group", what);
+        if (mel_status st = check_gemm_shape(gs[i], what)) return st;
+        const long h = (hints && hints[i] >= 0 && hints[i] <= gs[i].M) ? hints[i] : gs[i].M;
+        big += ((h + 127) / 128) * (gs[i].N / 128);
+        n128 = n128 && gs[i].N % 128 == 0;
+        long_k = long_k && gs[i].K >= 512;
+    }
+    if (n128 && long_k && big >= 1536)
+        gemm_launch_t<2, 2, 2, 2>(gs, count, GEMM_MODE_PLAIN, stream);
+    else
+        gemm_launch_t<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
     return check_launch(what);
 }
 
@@ -724,14 +757,13 @@ static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t ro
             g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
             if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint)) return st;
         } else {
-            GemmArgs g;
-            g.A = in_q, g.lda = ld_q, g.W = q.weight, g.bias = q.bias;
-            g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = q.out_dim, g.K = q.in_dim, g.relu = 1;
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "Q hidden", rows_hint)) return st;
-            GemmArgs h;
-            h.A = in_v, h.lda = ld_v, h.W = v.weight, h.bias = v.bias;
-            h.Y = out + q.out_dim, h.ldy = ldo, h.M = (int)rows, h.M_dev = rows_dev, h.N = v.out_dim, h.K = v.in_dim, h.relu = 1;
-            if (mel_status st = launch_gemm(h, GEMM_MODE_PLAIN, s, "V hidden", rows_hint)) return st;
+            GemmArgs g[2];
+            g[0].A = in_q, g[0].lda = ld_q, g[0].W = q.weight, g[0].bias = q.bias;
+            g[0].Y = out, g[0].ldy = ldo, g[0].M = (int)rows, g[0].M_dev = rows_dev, g[0].N = q.out_dim, g[0].K = q.in_dim, g[0].relu = 1;
+            g[1].A = in_v, g[1].lda = ld_v, g[1].W = v.weight, g[1].bias = v.bias;
+            g[1].Y = out + q.out_dim, g[1].ldy = ldo, g[1].M = (int)rows, g[1].M_dev = rows_dev, g[1].N = v.out_dim, g[1].K = v.in_dim, g[1].relu = 1;
+            const long hints[2] = {rows_hint, rows_hint};
+            if (mel_status st = launch_gemm_group(g, hints, w->dueling ? 2 : 1, s, "Q + V hidden")) return st;
         }
         in_q = out, in_v = out + q.out_dim, ld_q = ld_v = ldo;
     }
@@ -760,13 +792,13 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const int32_t* nL = L.plan.offL + bs;
     const int32_t* n1 = L.plan.off1 + bs;
     const int32_t* n2 = L.plan.off2 + bs;
-    // expected sizes of the ragged row lists, for tile selection only (mean degree of the r = 0.2 disc
-    // graph is about 0.126 N; the closed two-hop ball covers about a quarter of the unit square; a round has
-    // about N/6 active agents whose neighbourhoods overlap)
+    // expected sizes of the ragged row lists, for tile selection only.  Measured means on r = 0.2 disc graphs
+    // (N = 50): one agent per row: |U1| ~ 0.13 N, |U2| ~ 0.25 N; a whole round (about 0.1 N active agents
+    // with overlapping neighbourhoods): |U1| ~ 0.21 N, |U2| ~ 0.32 N.
     const bool single = agent_mask == nullptr;
-    const long hintL = single ? bs : bs * (long)(n < 6 ? n : n / 6);
-    const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : bs * (long)(n < 4 ? n : (2 * n) / 3);
-    const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : bs * (long)n;
+    const long hintL = single ? bs : bs * (long)(n < 10 ? 1 : n / 10);
+    const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : bs * (long)(n < 5 ? n : 1 + n / 5);
+    const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : bs * (long)(n < 3 ? n : 1 + n / 3);
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -787,19 +819,16 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         StageScope t(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", hint2)) return st;
     }
-    {   // conv1.lin_l on the U2 rows, conv1.lin_r on the U1 rows
-        GemmArgs g;
-        g.A = L.h0, g.lda = hidden, g.W = w->conv1.lin_l.weight, g.bias = w->conv1.lin_l.bias;
-        g.Y = L.xl1, g.ldy = hc, g.M = U2, g.M_dev = n2, g.N = hc, g.K = hidden;
-        {
-            StageScope t(MEL_STAGE_CONV1_LIN, s);
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l", hint2)) return st;
-        }
-        GemmArgs r;
-        r.A = L.h0, r.lda = hidden, r.arow = L.plan.arow1, r.W = w->conv1.lin_r.weight, r.bias = w->conv1.lin_r.bias;
-        r.Y = L.xr1, r.ldy = hc, r.M = U1, r.M_dev = n1, r.N = hc, r.K = hidden;
-        StageScope t(MEL_STAGE_CONV1_LIN_R, s);
-        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv1.lin_r", hint1)) return st;
+    {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
+        GemmArgs g[2];
+        g[0].A = L.h0, g[0].lda = hidden, g[0].W = w->conv1.lin_l.weight, g[0].bias = w->conv1.lin_l.bias;
+        g[0].Y = L.xl1, g[0].ldy = hc, g[0].M = U2, g[0].M_dev = n2, g[0].N = hc, g[0].K = hidden;
+        g[1].A = L.h0, g[1].lda = hidden, g[1].arow = L.plan.arow1;
+        g[1].W = w->conv1.lin_r.weight, g[1].bias = w->conv1.lin_r.bias;
+        g[1].Y = L.xr1, g[1].ldy = hc, g[1].M = U1, g[1].M_dev = n1, g[1].N = hc, g[1].K = hidden;
+        const long hints[2] = {hint2, hint1};
+        StageScope t(MEL_STAGE_CONV1_LIN, s);
+        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r")) return st;
     }
     {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
         AttArgs a{};
@@ -812,20 +841,18 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
     }
-    {   // conv2 projections; the decision-maker mask (l_dgn.py:128) rides along as a row scale
-        GemmArgs g;
-        g.A = L.h1, g.lda = hc, g.rscale = L.plan.dm1, g.W = w->conv2.lin_l.weight, g.bias = w->conv2.lin_l.bias;
-        g.Y = L.xl2, g.ldy = hc, g.M = U1, g.M_dev = n1, g.N = hc, g.K = hc;
-        {
-            StageScope t(MEL_STAGE_CONV2_LIN, s);
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv2.lin_l", hint1)) return st;
-        }
-        GemmArgs r;
-        r.A = L.h1, r.lda = hc, r.arow = L.plan.arow_g, r.rscale = L.plan.dm_g;
-        r.W = w->conv2.lin_r.weight, r.bias = w->conv2.lin_r.bias;
-        r.Y = L.xr2, r.ldy = hc, r.M = R, r.M_dev = nL, r.N = hc, r.K = hc;
-        StageScope t(MEL_STAGE_CONV2_LIN_R, s);
-        if (mel_status st = launch_gemm(r, GEMM_MODE_PLAIN, s, "conv2.lin_r", hintL)) return st;
+    {   // conv2.lin_l on the U1 rows + conv2.lin_r on the agent rows, one grouped launch; the decision-maker
+        // mask (l_dgn.py:128) rides along as a row scale
+        GemmArgs g[2];
+        g[0].A = L.h1, g[0].lda = hc, g[0].rscale = L.plan.dm1;
+        g[0].W = w->conv2.lin_l.weight, g[0].bias = w->conv2.lin_l.bias;
+        g[0].Y = L.xl2, g[0].ldy = hc, g[0].M = U1, g[0].M_dev = n1, g[0].N = hc, g[0].K = hc;
+        g[1].A = L.h1, g[1].lda = hc, g[1].arow = L.plan.arow_g, g[1].rscale = L.plan.dm_g;
+        g[1].W = w->conv2.lin_r.weight, g[1].bias = w->conv2.lin_r.bias;
+        g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;
+        const long hints[2] = {hint1, hintL};
+        StageScope t(MEL_STAGE_CONV2_LIN, s);
+        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv2.lin_l + lin_r")) return st;
     }
     {   // conv2 attention, one target per agent row -> x_3
         AttArgs a{};

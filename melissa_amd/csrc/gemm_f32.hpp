@@ -60,6 +60,15 @@ struct GemmArgs {
     int relu = 0;
 };
 
+// Up to four independent problems in one launch (e.g. conv.lin_l + conv.lin_r, or the Q and V hidden layers):
+// small problems ride in the shadow of the big one instead of paying their own latency-bound launch.
+constexpr int GEMM_MAX_GROUP = 4;
+struct GemmBatch {
+    GemmArgs p[GEMM_MAX_GROUP];
+    int start[GEMM_MAX_GROUP + 1];   // first workgroup id of each problem (multiples of 8), total at [count]
+    int count;
+};
+
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDS_STRIDE = GEMM_BK + 4;   // floats; 144-byte rows
 
@@ -95,7 +104,12 @@ __device__ __forceinline__ f32x4 fetch_a(const GemmArgs& g, const AChunk& c, int
 }
 
 template <int WM, int WN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32_kernel(GemmBatch batch) {
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+        if (k < batch.count && (int)blockIdx.x >= batch.start[k]) pi = k;
+    const GemmArgs& g = batch.p[pi];
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN;
     constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;   // float4 chunks per thread per K step
     constexpr int W_CHUNKS = BN * (GEMM_BK / 4) / T;
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
     const int nbn = g.N / BN;
     const int M = g.M_dev ? min(*g.M_dev, g.M) : g.M;
     const int active = ((M + BM - 1) / BM) * nbn;
-    int wg = blockIdx.x;
+    int wg = blockIdx.x - batch.start[pi];
     if (wg >= active) return;
     {
         const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
@@ -256,5 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_kernel(GemmArgs g) {
 // count the caller expects (ragged lists are sized on the device; the grid still covers g.M rows).
 mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1,
                        int force_tile = 0);
+// Several PLAIN problems in one launch; hints[i] = expected rows of problem i (-1 = g.M).
+mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, hipStream_t stream, const char* what);
 
 }  // namespace mel
