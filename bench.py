@@ -41,7 +41,7 @@ def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
 
 
-def build_workload(device, rank, envs, n_nodes, model_name, mode, seed=9):
+def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, seed=9):
     import torch
     from melissa_amd.collect import DecisionLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
@@ -58,8 +58,11 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, seed=9):
     venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device,
                              max_moves=48, seed=1000 + rank * envs, construct_like_reference=False)
     policy = DQNPolicy(net)
-    cls = RoundLoop if mode == "round" else DecisionLoop
-    loop = cls(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001)   # test eps (l_dgn.py:107)
+    if mode == "round":
+        loop = RoundLoop(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001,   # test eps (l_dgn.py:107)
+                         use_graph=use_graph)
+    else:
+        loop = DecisionLoop(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001)
     return net, venv, loop
 
 
@@ -125,6 +128,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn"])
     ap.add_argument("--mode", default="round", choices=["round", "aec"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -138,7 +142,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if args.model == "hl_dgn":
         args.mode = "aec"
-    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode)
+    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph)
     rows_cap = loop.rows_cap if args.mode == "round" else 0
     lib = _lib.load()
 
@@ -166,6 +170,8 @@ def main():
         totals = torch.zeros(args.steps, 3, dtype=torch.int32, device=device)
         ws = net._ws_agents if args.mode == "round" else net._ws
         lib.mel_prof_attach(prof)
+        if args.mode == "round":
+            loop.use_graph = False                 # the stage timers bracket eager launches
         for k in range(args.steps):
             loop.step()
             if args.model == "l_dgn":
@@ -208,7 +214,7 @@ def main():
                                f"per GPU, fp32, dynamic graph, eps=0.001, "
                                + ("round-batched loop (one env round per step)" if args.mode == "round"
                                   else "AEC-order loop (one agent decision per env per step)"),
-                   "loop": args.mode,
+                   "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),
                    "envs_per_gpu": args.envs, "n_nodes": args.nodes, "global_envs": args.envs * world,
                    "parallelism": f"env-shard x{world} (no data-path collective)",
                    "decisions_per_step": decisions / args.steps, "live_decisions": decisions, "episodes_finished": episodes,

@@ -146,11 +146,12 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
 
 /* Row-wise argmax + eps-greedy for the round-batched loop: the row count lives on the device
  * (rows_dev, may be NULL = rows_cap) and the exploration stream is a counter-based hash of
- * (seed, step, row) instead of host numpy draws.  logit_row (optional, device int32 [rows_cap]) maps an
+ * (seed, step + *step_dev, row) instead of host numpy draws (step_dev: optional device counter, e.g. the
+ * one mel_env_round advances, so the stream moves on when the launches are replayed from a HIP graph).  logit_row (optional, device int32 [rows_cap]) maps an
  * action row to its logits row (HL-DGN: all agents of an env share the env's logits). */
 mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row, int64_t rows_cap,
                                   const int32_t* rows_dev, int32_t n_actions, float eps, uint32_t seed,
-                                  uint32_t step, int32_t* act, void* stream);
+                                  uint32_t step, const uint32_t* step_dev, int32_t* act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Environment half.  State of B independent envs lives in caller-owned device memory laid out as
@@ -272,10 +273,11 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
  *   actions     device int32 [rows], one per (env, active agent), ordered by env then agent id
  *   row_offsets device int32 [B+1], first action row of each env (from mel_ldgn_forward_agents)
  *   live        device uint64 [B]; in: the active sets the actions belong to, out: the next round's
- *   first != 0  only publishes the current active sets (call once after mel_env_reset). */
+ *   first != 0  only publishes the current active sets (call once after mel_env_reset).
+ *   round_counter (optional, device uint32): incremented once per call. */
 mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
                          const int32_t* row_offsets, uint64_t* live, const int32_t* episode_table,
-                         int32_t table_stride, int32_t first, void* stream);
+                         int32_t table_stride, int32_t first, uint32_t* round_counter, void* stream);
 
 /* last() only (mutates is_new_round exactly like GraphEnv.observe, graph.py:205-211). */
 mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n,

@@ -118,7 +118,7 @@ def load(build_if_missing: bool = True):
     lib.mel_ldgn_forward_agents.restype = i32
     lib.mel_ldgn_forward_agents.argtypes = [W, vp, i64, i32, i32, vp, i64, vp, vp, vp, sz, vp]
     lib.mel_select_action_rows.restype = i32
-    lib.mel_select_action_rows.argtypes = [vp, vp, i64, vp, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
+    lib.mel_select_action_rows.argtypes = [vp, vp, i64, vp, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.mel_select_action.restype = i32
     lib.mel_select_action.argtypes = [vp, vp, i64, i32, C.c_float, vp, vp, vp, vp, vp]
     lib.mel_env_state_bytes.restype = sz
@@ -130,7 +130,7 @@ def load(build_if_missing: bool = True):
     lib.mel_env_step.restype = i32
     lib.mel_env_step.argtypes = [E, P, vp, vp, i64, O, vp, i32, vp]
     lib.mel_env_round.restype = i32
-    lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp]
+    lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp, vp]
     lib.mel_env_observe.restype = i32
     lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
     lib.mel_prof_create.restype = vp

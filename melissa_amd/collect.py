@@ -93,8 +93,9 @@ class RoundLoop:
     """
 
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
-                 eps: float = 0.0, episodes=None, rows_cap: int | None = None):
+                 eps: float = 0.0, episodes=None, rows_cap: int | None = None, use_graph: bool = False):
         self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
+        self.use_graph, self.graph = use_graph, None
         dev = venv.device
         packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
         self.pool = venv.load_pool(packed)
@@ -106,21 +107,37 @@ class RoundLoop:
         self.logits = torch.zeros(self.rows_cap, self.n_actions, dtype=torch.float32, device=dev)
         self.act = torch.zeros(self.rows_cap, dtype=torch.int32, device=dev)
         self.iterations = 0
+        self.rounds = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side round counter (RNG step)
+        self._obs_matrix = venv.obs_matrix()
         venv.reset_device(self.pool, self.table[:, 0].contiguous(), None)
         venv.round_device(self.pool, None, None, self.live, None, first=True)
 
-    def step(self):
+    def _launch(self):
+        """The fixed launch sequence of one round (no host reads, no allocation: capturable)."""
         lib = _lib.load()
         net = self.policy.model
         dev = self.venv.device
-        net.hip_forward_agents(self.venv.obs_matrix(), self.live, self.rows_cap, out=self.logits,
-                               row_offsets=self.offsets)
+        net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets)
         rows_dev = self.offsets.data_ptr() + 4 * self.venv.env_num
         _lib.check(lib.mel_select_action_rows(self.logits.data_ptr(), None, self.rows_cap, rows_dev, self.n_actions,
-                                              float(self.eps), self.seed & 0xFFFFFFFF, self.iterations & 0xFFFFFFFF,
+                                              float(self.eps), self.seed & 0xFFFFFFFF, 0, self.rounds.data_ptr(),
                                               self.act.data_ptr(), _lib.current_stream_ptr(dev)),
                    "mel_select_action_rows")
-        self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table)
+        self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds)
+
+    def step(self):
+        if self.use_graph:
+            if self.graph is None:
+                self._launch()                        # warm-up outside capture (workspace allocation, lazy init)
+                self.iterations += 1
+                torch.cuda.synchronize(self.venv.device)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):    # launches land on the capture stream (torch's current one)
+                    self._launch()
+                return                                # capture does not execute: the next call replays
+            self.graph.replay()
+        else:
+            self._launch()
         self.iterations += 1
 
     def run(self, iterations: int):

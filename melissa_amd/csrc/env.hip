@@ -401,6 +401,7 @@ struct RoundArgs {
     const int32_t* episode_table;
     int table_stride;
     int first;                     // 1: only publish the active set (no step) - used right after a reset
+    uint32_t* round_counter;       // optional: rounds played (device), drives the device-side RNG step
 };
 
 __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     if (b >= a.env.n_envs) return;
     const int lane = lane_id();
     const int n = a.env.n_nodes;
+    if (a.round_counter && b == 0 && lane == 0 && !a.first) atomicAdd(a.round_counter, 1u);
     Env s;
     env_load(a.env, b, lane, s);
     const mel_env_obs none{};
@@ -602,7 +604,7 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
 
 mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
                          const int32_t* row_offsets, uint64_t* live, const int32_t* episode_table,
-                         int32_t table_stride, int32_t first, void* stream) {
+                         int32_t table_stride, int32_t first, uint32_t* round_counter, void* stream) {
     if (mel_status st = check_env(env, env->n_envs)) return st;
     if (mel_status st = check_pool(env, pool)) return st;
     if (!live) return fail(MEL_ERR_INVALID_ARG, "live mask buffer is null");
@@ -611,7 +613,7 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     clear_stale_error();
     RoundArgs a{};
     a.env = *env, a.pool = *pool, a.actions = actions, a.row_offsets = row_offsets, a.live = live;
-    a.episode_table = episode_table, a.table_stride = table_stride, a.first = first;
+    a.episode_table = episode_table, a.table_stride = table_stride, a.first = first, a.round_counter = round_counter;
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_round");

@@ -40,6 +40,26 @@ static void gemm_launch_t(const GemmArgs* gs, int count, int mode, hipStream_t s
         hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
 }
 
+template <int WM, int WN, int TM, int TN>
+static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int LDS_STAGE = (BM + BN) * GEMM_LDS_STRIDE * 4 * 2;
+    constexpr int PER_CU = (160 * 1024) / LDS_STAGE > 4 ? 4 : (160 * 1024) / LDS_STAGE;    // workgroups an LDS-limited CU holds
+    GemmBatch batch{};
+    batch.count = count;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        tiles += ((long)((gs[i].M + BM - 1) / BM) * (gs[i].N / BN) + 7) & ~7L;
+    }
+    long grid = 256L * PER_CU;                    // 256 CUs; a multiple of 8 (XCD affinity of tile ids)
+    if (grid > tiles) grid = tiles;
+    if (mode == GEMM_MODE_ENC)
+        hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+    else
+        hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+}
+
 static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
     if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
         return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
@@ -58,6 +78,8 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
             case 4: gemm_launch_t<4, 2, 1, 2>(&g, 1, mode, stream); break;     // 128 x 128, 8 waves (32x64 each)
             case 5: gemm_launch_t<2, 2, 2, 1>(&g, 1, mode, stream); break;     // 128 x  64, 4 waves
             case 6: gemm_launch_t<2, 2, 1, 2>(&g, 1, mode, stream); break;     //  64 x 128, 4 waves
+            case 11: gemm_launch_persistent<2, 2, 1, 1>(&g, 1, mode, stream); break;   // persistent  64 x  64
+            case 12: gemm_launch_persistent<2, 2, 2, 2>(&g, 1, mode, stream); break;   // persistent 128 x 128
             default: return fail(MEL_ERR_INVALID_ARG, "unknown tile %d", force_tile);
         }
         return check_launch(what);
@@ -579,9 +601,12 @@ __device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0
 __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ logits,
                                                           const int32_t* __restrict__ logit_row, long rows_cap,
                                                           const int32_t* __restrict__ rows_dev, int na, float eps,
-                                                          uint32_t seed, uint32_t step, int32_t* __restrict__ act) {
+                                                          uint32_t seed, uint32_t step,
+                                                          const uint32_t* __restrict__ step_dev,
+                                                          int32_t* __restrict__ act) {
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows_cap || (rows_dev && r >= *rows_dev)) return;
+    if (step_dev) step += *step_dev;            // device-side counter: advances under hipGraph replay
     const float* q = logits + (size_t)(logit_row ? logit_row[r] : r) * na;
     int best = 0;
     float bv = -INFINITY;
@@ -1054,13 +1079,13 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
 
 mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row, int64_t rows_cap,
                                   const int32_t* rows_dev, int32_t na, float eps, uint32_t seed, uint32_t step,
-                                  int32_t* act, void* stream) {
+                                  const uint32_t* step_dev, int32_t* act, void* stream) {
     if (!logits || !act || rows_cap <= 0 || na < 1) return fail(MEL_ERR_INVALID_ARG, "bad select_action_rows arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     clear_stale_error();
     StageScope t(MEL_STAGE_SELECT, s);
     hipLaunchKernelGGL(select_rows_kernel, dim3((rows_cap + 255) / 256), dim3(256), 0, s, logits, logit_row, (long)rows_cap,
-                       rows_dev, na, eps, seed, step, act);
+                       rows_dev, na, eps, seed, step, step_dev, act);
     return check_launch("select_action_rows");
 }
 

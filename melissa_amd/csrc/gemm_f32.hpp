@@ -266,6 +266,230 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent variant: a fixed grid of workgroups walks the tile list of all problems of the launch.
+// What it buys at the sizes of this path (a few hundred to a few thousand tiles, K as short as 128):
+//   * the first K step of the NEXT tile (pointer set-up incl. the row-gather indices, then the global
+//     loads) is issued under the MFMAs of the current tile's last K steps, and its LDS stage is filled
+//     before the current tile's epilogue - so no tile after the first pays the cold prologue;
+//   * the epilogue's stores drain while the next tile is already computing;
+//   * no per-tile workgroup launch / exit.
+// Tile ids are padded per problem to multiples of 8 so that id % 8 (= XCD under round-robin dispatch, the
+// grid is a multiple of 8) keeps meaning "same XCD" for the A-panel-sharing remap.
+// ------------------------------------------------------------------------------------------------
+template <int A_CHUNKS, int W_CHUNKS>
+struct TileCtx {
+    AChunk ac[A_CHUNKS];
+    const float* w_src[W_CHUNKS];
+    int m0, n0, M, pi, KT;
+};
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(GemmBatch batch) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN;
+    constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;
+    constexpr int W_CHUNKS = BN * (GEMM_BK / 4) / T;
+    constexpr int BUF = (BM + BN) * GEMM_LDS_STRIDE;
+    constexpr int ENC_MAX_K = 256;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF + (MODE == GEMM_MODE_ENC ? ENC_MAX_K * 9 : 0)];
+    float* enc = lds + 2 * BUF;
+
+    // tile bookkeeping (wave-uniform): active tiles and padded prefix per problem
+    int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
+        act[i] = 0, rows[i] = 0;
+        if (i < batch.count) {
+            const GemmArgs& q = batch.p[i];
+            rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
+            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN);
+        }
+        pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
+    }
+    const int total = pre[GEMM_MAX_GROUP];
+    const int stride = gridDim.x;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int crow = tid >> 3;
+    const int kc = (tid & 7) * 4;
+
+    // first valid tile at or after t (skips the per-problem padding)
+    auto next_valid = [&](int t) {
+        for (; t < total; t += stride) {
+            int pi = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (t >= pre[k]) pi = k;
+            if (t - pre[pi] < act[pi]) return t;
+        }
+        return total;
+    };
+    auto setup = [&](TileCtx<A_CHUNKS, W_CHUNKS>& c, int t) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (t >= pre[k]) pi = k;
+        const GemmArgs& g = batch.p[pi];
+        const int nbn = g.N / BN;
+        int wg = t - pre[pi];
+        {
+            const int active = act[pi];
+            const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
+            wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+        }
+        c.pi = pi, c.M = rows[pi], c.KT = g.K / GEMM_BK;
+        c.m0 = (wg / nbn) * BM, c.n0 = (wg % nbn) * BN;
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int row = min(c.m0 + crow + i * (T / 8), c.M - 1);
+            c.ac[i].src = nullptr;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) c.ac[i].x[f] = 0.f;
+            if constexpr (MODE == GEMM_MODE_PLAIN) {
+                const int ar = g.arow ? g.arow[row] : row;
+                c.ac[i].src = g.A + (size_t)ar * g.lda + kc;
+            } else {
+                const int id = g.nid ? g.nid[row] : row;
+                const int b = id / g.n_nodes, node = id - b * g.n_nodes;
+                const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
+#pragma unroll
+                for (int f = 0; f < 8; ++f)
+                    if (f < g.in_dim) c.ac[i].x[f] = x[f];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) {
+            const int n = c.n0 + crow + i * (T / 8);
+            const float* base = (g.W_hi && n >= g.split_n) ? g.W_hi + (size_t)(n - g.split_n) * g.K
+                                                            : g.W + (size_t)n * g.K;
+            c.w_src[i] = base + kc;
+        }
+    };
+
+    int t = next_valid(blockIdx.x);
+    if (t >= total) return;
+    if constexpr (MODE == GEMM_MODE_ENC) {
+        const GemmArgs& g = batch.p[0];
+        for (int i = tid; i < g.K * 9; i += T) {
+            const int k = i / 9, f = i - k * 9;
+            enc[i] = f == 8 ? g.enc_b[k] : (f < g.in_dim ? g.enc_w[(size_t)k * g.in_dim + f] : 0.f);
+        }
+        __syncthreads();
+    }
+
+    const int st_off = crow * GEMM_LDS_STRIDE + kc;
+    const int a_off = (wm * 32 * TM + r) * GEMM_LDS_STRIDE + 4 * h;
+    const int w_off = BM * GEMM_LDS_STRIDE + (wn * 32 * TN + r) * GEMM_LDS_STRIDE + 4 * h;
+
+    TileCtx<A_CHUNKS, W_CHUNKS> cur, nxt;
+    setup(cur, t);
+    nxt = cur;
+    f32x4 a_reg[A_CHUNKS], w_reg[W_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(batch.p[0], cur.ac[i], 0, kc, enc);
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(cur.w_src[i]);
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i)
+        *reinterpret_cast<f32x4*>(lds + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < W_CHUNKS; ++i)
+        *reinterpret_cast<f32x4*>(lds + BM * GEMM_LDS_STRIDE + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = w_reg[i];
+    __syncthreads();
+    int stage = 0;
+
+    for (;;) {
+        const int tn = next_valid(t + stride);
+        const bool has_next = tn < total;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int KT = cur.KT;
+        for (int kt = 0; kt < KT; ++kt) {
+            const float* cst = lds + stage * BUF;
+            float* nst = lds + (stage ^ 1) * BUF;
+            const bool last = kt + 1 == KT;
+            // one K step ahead of its first load, resolve the next tile's pointers (row-gather indices)
+            if (has_next && (kt + 2 == KT || (KT == 1 && last))) setup(nxt, tn);
+            const bool fill = !last || has_next;
+            if (!last) {
+                const int k0 = (kt + 1) * GEMM_BK;
+#pragma unroll
+                for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(batch.p[0], cur.ac[i], k0, kc, enc);
+#pragma unroll
+                for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(cur.w_src[i] + k0);
+            } else if (has_next) {
+#pragma unroll
+                for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = fetch_a<MODE>(batch.p[0], nxt.ac[i], 0, kc, enc);
+#pragma unroll
+                for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(nxt.w_src[i]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int u = 0; u < TM; ++u)
+                    a[u] = *reinterpret_cast<const f32x4*>(cst + a_off + u * 32 * GEMM_LDS_STRIDE + q * 8);
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+                    b[u] = *reinterpret_cast<const f32x4*>(cst + w_off + u * 32 * GEMM_LDS_STRIDE + q * 8);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            }
+            if (fill) {
+#pragma unroll
+                for (int i = 0; i < A_CHUNKS; ++i)
+                    *reinterpret_cast<f32x4*>(nst + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = a_reg[i];
+#pragma unroll
+                for (int i = 0; i < W_CHUNKS; ++i)
+                    *reinterpret_cast<f32x4*>(nst + BM * GEMM_LDS_STRIDE + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = w_reg[i];
+            }
+            __syncthreads();
+            stage ^= 1;
+        }
+        {   // epilogue of the finished tile (the next tile's first K step already sits in LDS)
+            const GemmArgs& g = batch.p[cur.pi];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = cur.n0 + wn * 32 * TN + j * 32 + r;
+                const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n]
+                                                                 : (g.bias ? g.bias[n] : 0.f);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = cur.m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (m < cur.M) {
+                            float v = acc[i][j][e];
+                            if (g.rscale) v *= g.rscale[m];
+                            v += bias;
+                            if (g.relu) v = fmaxf(v, 0.f);
+                            g.Y[(size_t)m * g.ldy + n] = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        t = tn;
+    }
+}
+
 // Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.  `m_hint` is the row
 // count the caller expects (ragged lists are sized on the device; the grid still covers g.M rows).
 mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1,

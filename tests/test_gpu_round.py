@@ -143,3 +143,27 @@ def test_round_loop_matches_oracle(n, dynamic):
             assert [int(x) for x in one_hop[b]] == e.adj
     c = loop.counters()
     assert c["errors"] == 0 and c["episodes"] >= 3 and checked_rows > 100
+
+
+def test_graph_replay_matches_eager_launches():
+    """The round step captured once into a HIP graph and replayed must walk exactly the same trajectory as
+    the eager launch sequence (incl. the eps-greedy stream, which is keyed on a device-side round counter)."""
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.policy import DQNPolicy
+    n, B = 20, 64
+    graphs = synthetic_graph_pool(n, 4, first_seed=5)
+    net, _ = make_ldgn(n)
+    finals = []
+    for use_graph in (False, True):
+        venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
+                                 construct_like_reference=False)
+        loop = RoundLoop(venv, DQNPolicy(net), episodes_per_env=10, seed=3, eps=0.05, use_graph=use_graph)
+        loop.run(60)
+        torch.cuda.synchronize()
+        finals.append((venv.scalars().cpu().numpy().copy(), venv.node_sets().cpu().numpy().copy(),
+                       venv.positions().cpu().numpy().copy(), loop.counters()))
+    np.testing.assert_array_equal(finals[0][0], finals[1][0])
+    np.testing.assert_array_equal(finals[0][1], finals[1][1])
+    np.testing.assert_array_equal(finals[0][2], finals[1][2])
+    assert finals[0][3] == finals[1][3] and finals[0][3]["errors"] == 0 and finals[0][3]["episodes"] > 20
