@@ -109,12 +109,22 @@ mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, 
  * is evaluated.  logits: device fp32 [rows_cap, n_actions], rows ordered by env then agent id; only the
  * first sum(popcount(agent_mask)) rows are written (rows_cap >= that sum, <= bs*n_nodes).
  * row_offsets (optional, device int32 [bs+1]): first logits row of each env, total at [bs].
+ * select (optional): also write each row's action (see mel_select).
  * Each row equals mel_ldgn_forward on (obs_matrix, agent) within fp32 rounding. */
+/* Optional fused action selection for mel_ldgn_forward_agents: argmax of each logits row (+ eps-greedy with
+ * the same counter-based stream as mel_select_action_rows) written by the kernel that produces the logits. */
+typedef struct mel_select {
+    int32_t*        act;       /* device int32 [rows_cap]                                          */
+    float           eps;
+    uint32_t        seed;
+    const uint32_t* step_dev;  /* optional device counter added to the stream position             */
+} mel_select;
+
 size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap);
 mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
                                    int32_t obs_stride, const uint64_t* agent_mask, int64_t rows_cap,
-                                   float* logits, int32_t* row_offsets, void* workspace, size_t ws_bytes,
-                                   void* stream);
+                                   float* logits, int32_t* row_offsets, const mel_select* select,
+                                   void* workspace, size_t ws_bytes, void* stream);
 
 mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs,
                              int32_t n_nodes, int32_t obs_width, float* logits, void* workspace,

@@ -48,6 +48,10 @@ class MelWeights(C.Structure):
                 ("v_head", MelMlp)]
 
 
+class MelSelect(C.Structure):
+    _fields_ = [("act", C.c_void_p), ("eps", C.c_float), ("seed", C.c_uint32), ("step_dev", C.c_void_p)]
+
+
 class MelEnvBatch(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("n_nodes", C.c_int32), ("dynamic_graph", C.c_int32),
                 ("has_local_ratio", C.c_int32), ("local_ratio", C.c_double),
@@ -116,7 +120,7 @@ def load(build_if_missing: bool = True):
     lib.mel_workspace_bytes_agents.restype = sz
     lib.mel_workspace_bytes_agents.argtypes = [W, i64, i32, i64]
     lib.mel_ldgn_forward_agents.restype = i32
-    lib.mel_ldgn_forward_agents.argtypes = [W, vp, i64, i32, i32, vp, i64, vp, vp, vp, sz, vp]
+    lib.mel_ldgn_forward_agents.argtypes = [W, vp, i64, i32, i32, vp, i64, vp, vp, C.POINTER(MelSelect), vp, sz, vp]
     lib.mel_select_action_rows.restype = i32
     lib.mel_select_action_rows.argtypes = [vp, vp, i64, vp, i32, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.mel_select_action.restype = i32

@@ -108,6 +108,9 @@ class RoundLoop:
         self.act = torch.zeros(self.rows_cap, dtype=torch.int32, device=dev)
         self.iterations = 0
         self.rounds = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side round counter (RNG step)
+        self._select = _lib.MelSelect()
+        self._select.act, self._select.eps = self.act.data_ptr(), float(eps)
+        self._select.seed, self._select.step_dev = seed & 0xFFFFFFFF, self.rounds.data_ptr()
         self._obs_matrix = venv.obs_matrix()
         venv.reset_device(self.pool, self.table[:, 0].contiguous(), None)
         venv.round_device(self.pool, None, None, self.live, None, first=True)
@@ -117,12 +120,9 @@ class RoundLoop:
         lib = _lib.load()
         net = self.policy.model
         dev = self.venv.device
-        net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets)
-        rows_dev = self.offsets.data_ptr() + 4 * self.venv.env_num
-        _lib.check(lib.mel_select_action_rows(self.logits.data_ptr(), None, self.rows_cap, rows_dev, self.n_actions,
-                                              float(self.eps), self.seed & 0xFFFFFFFF, 0, self.rounds.data_ptr(),
-                                              self.act.data_ptr(), _lib.current_stream_ptr(dev)),
-                   "mel_select_action_rows")
+        # forward + fused argmax / eps-greedy (the dueling tail writes the action next to the logits)
+        net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets,
+                               select=self._select)
         self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds)
 
     def step(self):

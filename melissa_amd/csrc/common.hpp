@@ -88,6 +88,38 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// ---- cross-lane reads with a WAVE-UNIFORM source lane: v_readlane (VALU -> SGPR), no LDS round trip ----
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int lane_i32(int v, int src_uniform) {
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src_uniform));
+}
+__device__ __forceinline__ float lane_f32(float v, int src_uniform) {
+    return __builtin_bit_cast(float, lane_i32(__builtin_bit_cast(int, v), src_uniform));
+}
+__device__ __forceinline__ uint64_t lane_u64(uint64_t v, int src_uniform) {
+    const int src = __builtin_amdgcn_readfirstlane(src_uniform);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double lane_f64(double v, int src_uniform) {
+    return __longlong_as_double((long long)lane_u64((uint64_t)__double_as_longlong(v), src_uniform));
+}
+// sum of an int over the wave: DPP butterfly inside each 16-lane row, then four readlanes
+__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
 __device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

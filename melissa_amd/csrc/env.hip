@@ -21,16 +21,9 @@ constexpr int SKIP_NONE = -2;   // _skip_agent_selection is None
 constexpr int MAX_AGENT_STEPS = 4;          // graph.py:332, selector.py:44
 constexpr double R2_F64 = 0.04000000000000001;   // 0.2 ** 2 (nx.geometric_edges, core.py:311)
 
-__device__ __forceinline__ double shfl_f64(double v, int src) {
-    const unsigned long long u = __double_as_longlong(v);
-    uint32_t lo = __shfl((uint32_t)u, src, 64), hi = __shfl((uint32_t)(u >> 32), src, 64);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// every cross-lane read in this file has a wave-uniform source lane (loop counter / selected agent)
+__device__ __forceinline__ double shfl_f64(double v, int src) { return lane_f64(v, src); }
+__device__ __forceinline__ int wave_sum_i32(int v) { return wave_sum_i32_dpp(v); }
 __device__ __forceinline__ uint64_t bit(int i) { return 1ull << i; }
 
 // Wave-uniform working copy of one env's masks/scalars + this lane's per-node values.
@@ -50,17 +43,21 @@ struct Env {
 
 __device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane, Env& s) {
     const int n = e.n_nodes;
+    // wave-uniform state: forced into SGPRs so mask arithmetic and branches run on the scalar unit
     const uint64_t* ns = e.node_sets + (size_t)b * 8;
-    s.has_msg = ns[0], s.origin_set = ns[1], s.interested = ns[2], s.scripted = ns[3];
-    s.truncated = ns[4], s.alive = ns[5], s.terminated = ns[6], s.agents = ns[7];
+    s.has_msg = uniform_u64(ns[0]), s.origin_set = uniform_u64(ns[1]), s.interested = uniform_u64(ns[2]);
+    s.scripted = uniform_u64(ns[3]), s.truncated = uniform_u64(ns[4]), s.alive = uniform_u64(ns[5]);
+    s.terminated = uniform_u64(ns[6]), s.agents = uniform_u64(ns[7]);
     const uint64_t* ss = e.sel_sets + (size_t)b * 4;
-    s.sel_active = ss[0], s.sel_selected = ss[1], s.info_valid = ss[2], s.taken_action = ss[3];
+    s.sel_active = uniform_u64(ss[0]), s.sel_selected = uniform_u64(ss[1]);
+    s.info_valid = uniform_u64(ss[2]), s.taken_action = uniform_u64(ss[3]);
     const int32_t* sc = e.scalars + (size_t)b * MEL_ENV_SCALARS;
-    s.origin = sc[MEL_S_ORIGIN], s.sel = sc[MEL_S_SELECTION], s.skip = sc[MEL_S_SKIP];
-    s.num_moves = sc[MEL_S_NUM_MOVES], s.world_msgs = sc[MEL_S_WORLD_MSGS], s.new_round = sc[MEL_S_NEW_ROUND];
-    s.episode = sc[MEL_S_EPISODE], s.move_cursor = sc[MEL_S_MOVE_CURSOR], s.decisions = sc[MEL_S_DECISIONS];
-    s.done_count = sc[MEL_S_DONE_COUNT], s.episodes_done = sc[MEL_S_EPISODES_DONE], s.error = sc[MEL_S_ERROR];
-    s.ep_cursor = sc[MEL_S_EP_CURSOR];
+    s.origin = uniform_i32(sc[MEL_S_ORIGIN]), s.sel = uniform_i32(sc[MEL_S_SELECTION]), s.skip = uniform_i32(sc[MEL_S_SKIP]);
+    s.num_moves = uniform_i32(sc[MEL_S_NUM_MOVES]), s.world_msgs = uniform_i32(sc[MEL_S_WORLD_MSGS]);
+    s.new_round = uniform_i32(sc[MEL_S_NEW_ROUND]), s.episode = uniform_i32(sc[MEL_S_EPISODE]);
+    s.move_cursor = uniform_i32(sc[MEL_S_MOVE_CURSOR]), s.decisions = uniform_i32(sc[MEL_S_DECISIONS]);
+    s.done_count = uniform_i32(sc[MEL_S_DONE_COUNT]), s.episodes_done = uniform_i32(sc[MEL_S_EPISODES_DONE]);
+    s.error = uniform_i32(sc[MEL_S_ERROR]), s.ep_cursor = uniform_i32(sc[MEL_S_EP_CURSOR]);
     s.episode_rewards = e.episode_rewards[b];
     const size_t k = (size_t)b * n + lane;
     const bool on = lane < n;
@@ -103,7 +100,7 @@ __device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lan
 __device__ __forceinline__ uint64_t two_hop_of(uint64_t one_hop, int lane, int n) {
     uint64_t m = one_hop;
     for (int j = 0; j < n; ++j) {
-        const uint64_t t = readlane_u64(one_hop, j);
+        const uint64_t t = lane_u64(one_hop, j);
         if ((one_hop >> j) & 1ull) m |= t;
     }
     return m & ~bit(lane);
@@ -140,7 +137,7 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
                                            int lane) {
     const int n = e.n_nodes;
     // :246 the source always transmits on its first opportunity
-    const int origin_msgs = __shfl(s.msgs, s.origin, 64);
+    const int origin_msgs = lane_i32(s.msgs, s.origin);
     if (lane == s.origin && origin_msgs == 0) s.act = 1;
     // :249-254 relay in id order; has_message is re-read at each agent's turn
     uint64_t cand = __ballot(lane < n && s.act != NONE && s.act != 0);
@@ -148,7 +145,7 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
         const int i = lowest_bit(cand);
         cand &= cand - 1;
         if ((s.has_msg >> i) & 1ull) {                       // relay_message core.py:268-279
-            const uint64_t nb = readlane_u64(s.one_hop, i);
+            const uint64_t nb = lane_u64(s.one_hop, i);
             s.world_msgs += 1;
             if (lane == i) s.msgs += 1;
             s.taken_action |= bit(i);
@@ -314,8 +311,8 @@ __device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_epis
         s.one_hop = lane < n ? pool.one_hop[k] : 0ull;
     }
     s.two_hop = two_hop_of(s.one_hop, lane, n);                         // core.py:421
-    s.origin = pool.origin[episode];
-    s.interested = pool.interested[episode] & full;
+    s.origin = uniform_i32(pool.origin[episode]);
+    s.interested = uniform_u64(pool.interested[episode]) & full;
     s.scripted = 0;
     s.world_msgs = 0;
     s.has_msg = bit(s.origin);                                          // :432-434
@@ -372,7 +369,7 @@ __device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s
         o.stats[row * MEL_ENV_LOGGER_STATS + lane] =
             ok ? e.info_stats[((size_t)b * n + a) * MEL_ENV_LOGGER_STATS + lane] : 0.0;
     }
-    const uint64_t nb = readlane_u64(s.one_hop, valid ? a : 0);         // all lanes take part
+    const uint64_t nb = lane_u64(s.one_hop, valid ? a : 0);
     if (lane == 0) {
         if (o.agent_id) o.agent_id[row] = a;
         if (o.action_mask) o.action_mask[2 * row] = o.action_mask[2 * row + 1] = dead ? 0 : 1;   // :190-192
@@ -414,8 +411,10 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     env_load(a.env, b, lane, s);
     const mel_env_obs none{};
     if (!a.first) {
-        const uint64_t live_in = a.live[b];
-        const int base = a.row_offsets[b];
+        const uint64_t live_in = uniform_u64(a.live[b]);
+        const int base = uniform_i32(a.row_offsets[b]);
+        // every agent's action in one coalesced load (lane = agent), read back with v_readlane
+        const int my_action = ((live_in >> lane) & 1ull) ? a.actions[base + rank_below(live_in, lane)] : 0;
         for (int it = 0; it < 3 * n + 4; ++it) {
             const int sel = s.sel;
             if (sel < 0) {
@@ -428,14 +427,14 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
                     s.error |= 4;
                     break;
                 }
-                action = a.actions[base + rank_below(live_in, sel)];
+                action = lane_i32(my_action, sel);
             }
             env_step(a.env, a.pool, b, s, action, lane);
             const int r = env_observe(a.env, b, s, none, 0, lane);
             if (r & 1) s.done_count += 1;
             if ((r & 1) && ((r & 2) || s.done_count == n)) {                  // episode over
                 s.episodes_done += 1;
-                const int ep = a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)];
+                const int ep = uniform_i32(a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)]);
                 env_reset(a.env, a.pool, b, s, ep, 0, lane);
                 env_observe(a.env, b, s, none, 0, lane);
                 break;

@@ -151,7 +151,7 @@ __device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, i
     const float r2 = (float)(0.2 * 0.2);
     uint64_t m = 0;
     for (int j = 0; j < n; ++j) {
-        const float xj = __shfl(x, j, 64), yj = __shfl(y, j, 64);
+        const float xj = lane_f32(x, j), yj = lane_f32(y, j);     // j is the loop counter: v_readlane
         const float dx = x - xj, dy = y - yj;
         const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
         if (d2 < r2) m |= 1ull << j;
@@ -498,6 +498,18 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
     return check_launch(what);
 }
 
+// counter-based uniform stream for the on-device exploration noise
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {     // lowbias32 integer hash
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+
 // ------------------------------------------------------------------------------------------------
 // dueling tail: last Linear of Q and V + q - mean(q) + v  (l_dgn.py:142-147); one wave per row
 // ------------------------------------------------------------------------------------------------
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(256) void dueling_tail_kernel(const float* __restri
                                                            const float* __restrict__ hv, int ldv, int kv,
                                                            mel_linear q_last, mel_linear v_last, int bs,
                                                            const int32_t* __restrict__ rows_dev, int dueling,
-                                                           float* __restrict__ logits) {
+                                                           float* __restrict__ logits, mel_select sel) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs || (rows_dev && b >= *rows_dev)) return;
     const int lane = lane_id();
@@ -533,6 +545,25 @@ __global__ __launch_bounds__(256) void dueling_tail_kernel(const float* __restri
 #pragma unroll
     for (int a = 0; a < 8; ++a)
         if (a < na && lane == a) logits[(size_t)b * na + a] = q[a] - mean + v;
+    if (sel.act && lane == 0) {                 // fused DQN action selection
+        int best = 0;
+        float bv = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+            if (a < na && q[a] - mean + v > bv) bv = q[a] - mean + v, best = a;
+        if (sel.eps > 0.f) {
+            const uint32_t step = sel.step_dev ? *sel.step_dev : 0u;
+            const uint32_t base = mix32(sel.seed ^ mix32(step * 0x9e3779b9U + (uint32_t)b));
+            if (u01(base) < sel.eps) {
+                best = 0, bv = -1.f;
+                for (int a = 0; a < na; ++a) {
+                    const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
+                    if (u > bv) bv = u, best = a;
+                }
+            }
+        }
+        sel.act[b] = best;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -588,16 +619,6 @@ __global__ __launch_bounds__(256) void select_action_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // row-wise action selection with a counter-based RNG (round-batched loop: row count lives on the device)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {     // lowbias32 integer hash
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
-
 __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ logits,
                                                           const int32_t* __restrict__ logit_row, long rows_cap,
                                                           const int32_t* __restrict__ rows_dev, int na, float eps,
@@ -764,7 +785,7 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
 // dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail.
 // rows_dev (device row count) may be null.
 static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t rows, const int32_t* rows_dev,
-                            long rows_hint, float* logits, hipStream_t s) {
+                            long rows_hint, float* logits, hipStream_t s, const mel_select* select = nullptr) {
     const int nl = w->q_head.n_layers;
     const float* in_q = L.xcat;
     const float* in_v = L.xcat;
@@ -796,14 +817,14 @@ static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t ro
     const mel_linear& vl = w->v_head.layer[nl - 1];
     StageScope t(MEL_STAGE_HEAD_TAIL, s);
     hipLaunchKernelGGL(dueling_tail_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
-                       vl.in_dim, ql, vl, (int)rows, rows_dev, w->dueling, logits);
+                       vl.in_dim, ql, vl, (int)rows, rows_dev, w->dueling, logits, select ? *select : mel_select{});
     return check_launch("dueling tail");
 }
 
 // L-DGN for a set of controlling agents per env (agent_mask == null: the index column names one)
 static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, const Dims& d, int obs_stride,
                                     const uint64_t* agent_mask, float* logits, int32_t* row_offsets_out,
-                                    void* workspace, size_t ws_bytes, hipStream_t s) {
+                                    const mel_select* select, void* workspace, size_t ws_bytes, hipStream_t s) {
     if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
     const FwdLayout L = carve(w, d, workspace);
     if (ws_bytes < L.bytes) return fail(MEL_ERR_WORKSPACE, "workspace %zu < %zu bytes", ws_bytes, L.bytes);
@@ -889,7 +910,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         StageScope t(MEL_STAGE_CONV2_ATT, s);
         if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
     }
-    return run_heads(w, L, R, nL, hintL, logits, s);
+    return run_heads(w, L, R, nL, hintL, logits, s, select);
 }
 
 }  // namespace mel
@@ -914,18 +935,20 @@ size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_no
 mel_status mel_ldgn_forward(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_width,
                             float* logits, void* workspace, size_t ws_bytes, void* stream) {
     if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_width, true)) return st;
-    return ldgn_forward_impl(w, obs, make_dims(bs, n, bs, true), obs_width, nullptr, logits, nullptr, workspace,
-                             ws_bytes, static_cast<hipStream_t>(stream));
+    return ldgn_forward_impl(w, obs, make_dims(bs, n, bs, true), obs_width, nullptr, logits, nullptr, nullptr,
+                             workspace, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_stride,
                                    const uint64_t* agent_mask, int64_t rows_cap, float* logits,
-                                   int32_t* row_offsets, void* workspace, size_t ws_bytes, void* stream) {
+                                   int32_t* row_offsets, const mel_select* select, void* workspace,
+                                   size_t ws_bytes, void* stream) {
     if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_stride, false)) return st;
     if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "agent_mask is null");
     if (rows_cap < 1 || rows_cap > bs * (int64_t)n) return fail(MEL_ERR_INVALID_ARG, "rows_cap=%ld outside [1, bs*n]", (long)rows_cap);
+    if (select && !select->act) return fail(MEL_ERR_INVALID_ARG, "select->act is null");
     return ldgn_forward_impl(w, obs, make_dims(bs, n, rows_cap, false), obs_stride, agent_mask, logits, row_offsets,
-                             workspace, ws_bytes, static_cast<hipStream_t>(stream));
+                             select, workspace, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,

@@ -193,7 +193,8 @@ class HipForwardMixin:
         return out
 
     def hip_forward_agents(self, obs_matrix: torch.Tensor, agent_mask: torch.Tensor, rows_cap: int,
-                           out: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None):
+                           out: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None,
+                           select: "_lib.MelSelect | None" = None):
         """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
         [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
         patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
@@ -214,6 +215,7 @@ class HipForwardMixin:
             row_offsets = torch.empty(bs + 1, dtype=torch.int32, device=obs_matrix.device)
         st = lib.mel_ldgn_forward_agents(C.byref(w), obs_matrix.data_ptr(), bs, self.agents_num, obs_matrix.stride(0),
                                          agent_mask.data_ptr(), rows_cap, out.data_ptr(), row_offsets.data_ptr(),
+                                         C.byref(select) if select is not None else None,
                                          ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
         _lib.check(st, "mel_ldgn_forward_agents")
         return out, row_offsets
