@@ -192,10 +192,21 @@ def main():
         else:
             fl = stage_flops(mean_tot)
         dom = max(fl, key=lambda k: stages.get(k, 0.0))
+        # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+        # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied there); only valid for the
+        # workload those passes were taken on.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        if (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
+                and os.path.exists(pmc_path)):
+            pmc = json.load(open(pmc_path))["per_launch"]
+            key = {"conv1_lin": "conv1 (lin_l+lin_r)", "conv2_lin": "conv2 (lin_l+lin_r)", "head_hidden": None}.get(dom)
+            if key in pmc:
+                traffic = pmc[key]["hbm_bytes_corrected"]
         achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": f"gemm_f32_kernel ({dom})", "achieved": round(achieved, 3),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": None, "avg_launch_us": round(stages[dom], 2),
+                    "traffic": traffic, "avg_launch_us": round(stages[dom], 2),
                     "algorithmic_flops_per_launch": fl[dom],
                     "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]),
                                         "agent_rows": float(mean_tot[2])}}
