@@ -41,9 +41,9 @@ def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
 
 
-def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, seed=9):
+def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9):
     import torch
-    from melissa_amd.collect import DecisionLoop, RoundLoop
+    from melissa_amd.collect import DecisionLoop, MultiStreamRoundLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
     from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
     from melissa_amd.policy import DQNPolicy
@@ -55,14 +55,21 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, see
                            device=device, backend="hip")
     net.eval()
     graphs = synthetic_graph_pool(n_nodes, 64, first_seed=0)
-    venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device,
-                             max_moves=48, seed=1000 + rank * envs, construct_like_reference=False)
+    make_venv = lambda count, seed: HipGraphVectorEnv(count, n_nodes, graph_pool=graphs, dynamic_graph=True,
+                                                      device=device, max_moves=48, seed=seed,
+                                                      construct_like_reference=False)
     policy = DQNPolicy(net)
-    if mode == "round":
-        loop = RoundLoop(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001,   # test eps (l_dgn.py:107)
-                         use_graph=use_graph)
+    base = 1000 + rank * envs
+    if mode == "round" and streams > 1:
+        loop = MultiStreamRoundLoop(make_venv, policy, envs, streams=streams, episodes_per_env=12, seed=base,
+                                    eps=0.001, use_graph=use_graph)                       # test eps (l_dgn.py:107)
+        venv = loop.loops[0].venv
+    elif mode == "round":
+        venv = make_venv(envs, base)
+        loop = RoundLoop(venv, policy, episodes_per_env=12, seed=base, eps=0.001, use_graph=use_graph)
     else:
-        loop = DecisionLoop(venv, policy, episodes_per_env=12, seed=1000 + rank * envs, eps=0.001)
+        venv = make_venv(envs, base)
+        loop = DecisionLoop(venv, policy, episodes_per_env=12, seed=base, eps=0.001)
     return net, venv, loop
 
 
@@ -129,21 +136,28 @@ def main():
     ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn"])
     ap.add_argument("--mode", default="round", choices=["round", "aec"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="round mode: sub-batches of the GPU's envs on separate HIP streams (measured: no gain "
+                         "in one process, 16.3 vs 16.2 M/s at 2 streams, worse at 3-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
 
     import torch
     from melissa_amd import _lib, parallel
-    rank, local_rank, world = parallel.init_distributed()
+    rank, local_rank, world = parallel.init_distributed("gloo" if args.rehearse_on_one_gpu else None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if args.model == "hl_dgn":
         args.mode = "aec"
-    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph)
-    rows_cap = loop.rows_cap if args.mode == "round" else 0
+    net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph,
+                                     args.streams)
     lib = _lib.load()
 
     loop.run(args.warmup)
@@ -166,14 +180,24 @@ def main():
     # ---- per-stage HIP-event timing of the same step (separate, untimed pass) ----------------------
     roofline, stages = None, None
     if not args.no_profile and rank == 0:
+        # stage timers bracket eager launches of ONE launch chain over all of the GPU's envs (same kernels,
+        # same row counts per launch as a single-stream step; the timed pass above may overlap sub-batches)
+        if args.mode == "round" and args.streams > 1:
+            torch.cuda.synchronize()
+            _n, _v, ploop = build_workload(device, rank, args.envs, args.nodes, args.model, "round", False, 1)
+            ploop.run(args.warmup)
+        else:
+            ploop = loop
+            if args.mode == "round":
+                ploop.use_graph = False
+        rows_cap = ploop.rows_cap if args.mode == "round" else 0
+        torch.cuda.synchronize()
         prof = lib.mel_prof_create(args.steps * 16)
         totals = torch.zeros(args.steps, 3, dtype=torch.int32, device=device)
-        ws = net._ws_agents if args.mode == "round" else net._ws
+        ws = ploop.workspace if args.mode == "round" else net._ws
         lib.mel_prof_attach(prof)
-        if args.mode == "round":
-            loop.use_graph = False                 # the stage timers bracket eager launches
         for k in range(args.steps):
-            loop.step()
+            ploop.step()
             if args.model == "l_dgn":
                 _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, rows_cap, ws.data_ptr(),
                                                totals[k].data_ptr(), _lib.current_stream_ptr(device)))
@@ -226,6 +250,7 @@ def main():
                                + ("round-batched loop (one env round per step)" if args.mode == "round"
                                   else "AEC-order loop (one agent decision per env per step)"),
                    "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),
+                   "streams": args.streams if args.mode == "round" else 1,
                    "envs_per_gpu": args.envs, "n_nodes": args.nodes, "global_envs": args.envs * world,
                    "parallelism": f"env-shard x{world} (no data-path collective)",
                    "decisions_per_step": decisions / args.steps, "live_decisions": decisions, "episodes_finished": episodes,

@@ -5,6 +5,7 @@ without a GPU.  The .so is git-ignored but travels to the GPU box with the gpuru
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -24,12 +25,25 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    h = hashlib.sha256()
+    for rel in SOURCES + HEADERS:
+        path = os.path.join(CSRC, rel)
+        if os.path.exists(path):
+            h.update(rel.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """Content based (a snapshot copy scrambles mtimes): stale iff the sources' hash differs from the one
+    recorded next to the library when it was built."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return open(HASH_PATH).read().strip() != source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -39,13 +53,20 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     # -ffp-contract=off: the env's float64 arithmetic and the fp32 radius rule must round exactly like
     # the reference's Python/NumPy expressions (no fused multiply-add unless written as fmaf).
+    tmp = f"{LIB_PATH}.tmp.{os.getpid()}"          # atomic publish: concurrent ranks never see a partial file
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", *srcs, "-o", LIB_PATH]
+           "-ffp-contract=off", *srcs, "-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+    os.replace(tmp, LIB_PATH)
+    with open(HASH_PATH + f".tmp.{os.getpid()}", "w") as f:
+        f.write(source_hash())
+    os.replace(HASH_PATH + f".tmp.{os.getpid()}", HASH_PATH)
     return LIB_PATH
 
 

@@ -93,9 +93,11 @@ class RoundLoop:
     """
 
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
-                 eps: float = 0.0, episodes=None, rows_cap: int | None = None, use_graph: bool = False):
+                 eps: float = 0.0, episodes=None, rows_cap: int | None = None, use_graph: bool = False,
+                 stream: "torch.cuda.Stream | None" = None):
         self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
         self.use_graph, self.graph = use_graph, None
+        self.stream = stream                       # None: torch's current stream
         dev = venv.device
         packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
         self.pool = venv.load_pool(packed)
@@ -112,8 +114,12 @@ class RoundLoop:
         self._select.act, self._select.eps = self.act.data_ptr(), float(eps)
         self._select.seed, self._select.step_dev = seed & 0xFFFFFFFF, self.rounds.data_ptr()
         self._obs_matrix = venv.obs_matrix()
+        # own forward scratch: several loops may share one network on different streams
+        self.workspace = torch.empty(policy.model.agents_workspace_bytes(venv.env_num, self.rows_cap),
+                                     dtype=torch.uint8, device=dev)
         venv.reset_device(self.pool, self.table[:, 0].contiguous(), None)
         venv.round_device(self.pool, None, None, self.live, None, first=True)
+        torch.cuda.synchronize(dev)
 
     def _launch(self):
         """The fixed launch sequence of one round (no host reads, no allocation: capturable)."""
@@ -122,13 +128,20 @@ class RoundLoop:
         dev = self.venv.device
         # forward + fused argmax / eps-greedy (the dueling tail writes the action next to the logits)
         net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets,
-                               select=self._select)
+                               select=self._select, workspace=self.workspace)
         self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds)
 
     def step(self):
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._step()
+        else:
+            self._step()
+
+    def _step(self):
         if self.use_graph:
             if self.graph is None:
-                self._launch()                        # warm-up outside capture (workspace allocation, lazy init)
+                self._launch()                        # warm-up outside capture (lazy init)
                 self.iterations += 1
                 torch.cuda.synchronize(self.venv.device)
                 self.graph = torch.cuda.CUDAGraph()
@@ -148,3 +161,50 @@ class RoundLoop:
         sc = self.venv.scalars().cpu().numpy()
         return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
                     errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)
+
+
+class MultiStreamRoundLoop:
+    """The GPU's envs split into independent sub-batches, each a :class:`RoundLoop` on its own HIP stream.
+    One serial launch chain leaves the chip under-filled (latency-bound plan / env / attention launches, GEMM
+    tails); sub-batches on separate streams fill those gaps with each other's work.  Envs are independent, so
+    this changes nothing about any env's trajectory."""
+
+    def __init__(self, make_venv, policy, n_envs: int, streams: int = 2, episodes_per_env: int = 8, seed: int = 0,
+                 eps: float = 0.0, use_graph: bool = True):
+        per = (n_envs + streams - 1) // streams
+        self.loops = []
+        for k in range(streams):
+            lo, hi = k * per, min((k + 1) * per, n_envs)
+            if hi <= lo:
+                break
+            venv = make_venv(hi - lo, seed + lo)
+            self.loops.append(RoundLoop(venv, policy, episodes_per_env=episodes_per_env, seed=seed + lo, eps=eps,
+                                        use_graph=use_graph, stream=torch.cuda.Stream(device=venv.device)))
+        self.iterations = 0
+
+    @property
+    def use_graph(self):
+        return self.loops[0].use_graph
+
+    @use_graph.setter
+    def use_graph(self, v):
+        for l in self.loops:
+            l.use_graph = v
+
+    def step(self):
+        for l in self.loops:
+            l.step()
+        self.iterations += 1
+
+    def run(self, iterations: int):
+        for _ in range(iterations):
+            self.step()
+
+    def counters(self) -> dict:
+        out = dict(decisions=0, episodes=0, errors=0, iterations=self.iterations)
+        for l in self.loops:
+            c = l.counters()
+            out["decisions"] += c["decisions"]
+            out["episodes"] += c["episodes"]
+            out["errors"] |= c["errors"]
+        return out

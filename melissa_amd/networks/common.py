@@ -192,9 +192,12 @@ class HipForwardMixin:
                                        _lib.current_stream_ptr(ws.device)), "mel_forward_tap")
         return out
 
+    def agents_workspace_bytes(self, bs: int, rows_cap: int) -> int:
+        return int(_lib.load().mel_workspace_bytes_agents(C.byref(self._weights()), bs, self.agents_num, rows_cap))
+
     def hip_forward_agents(self, obs_matrix: torch.Tensor, agent_mask: torch.Tensor, rows_cap: int,
                            out: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None,
-                           select: "_lib.MelSelect | None" = None):
+                           select: "_lib.MelSelect | None" = None, workspace: torch.Tensor | None = None):
         """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
         [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
         patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
@@ -205,10 +208,15 @@ class HipForwardMixin:
         bs = obs_matrix.shape[0]
         w = self._weights()
         need = int(lib.mel_workspace_bytes_agents(C.byref(w), bs, self.agents_num, rows_cap))
-        ws = getattr(self, "_ws_agents", None)
-        if ws is None or ws.numel() < need or ws.device != obs_matrix.device:
-            ws = torch.empty(need, dtype=torch.uint8, device=obs_matrix.device)
-            self._ws_agents = ws
+        if workspace is not None:                  # caller-owned scratch (one per concurrent stream)
+            ws = workspace
+            if ws.numel() < need:
+                raise RuntimeError(f"workspace of {ws.numel()} bytes < {need} needed")
+        else:
+            ws = getattr(self, "_ws_agents", None)
+            if ws is None or ws.numel() < need or ws.device != obs_matrix.device:
+                ws = torch.empty(need, dtype=torch.uint8, device=obs_matrix.device)
+                self._ws_agents = ws
         if out is None:
             out = torch.empty(rows_cap, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
         if row_offsets is None:

@@ -85,10 +85,15 @@ def broadcast_parameters(model: torch.nn.Module, src: int = 0):
         off += n
 
 
+def _scalar_device(device):
+    """gloo reduces host tensors, nccl (RCCL) device tensors."""
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
+
+
 def all_reduce_max(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -96,7 +101,7 @@ def all_reduce_max(value: float, device) -> float:
 def all_reduce_sum(value: float, device) -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
