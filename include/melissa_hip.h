@@ -12,6 +12,7 @@
  * Reference interfaces replaced (paths relative to the reference repo):
  *   mel_ldgn_forward   -> LDGNNetwork.forward        graph_env/env/utils/networks/l_dgn.py:92-151
  *   mel_hldgn_forward  -> HLDGNNetwork.forward       graph_env/env/utils/networks/hl_dgn.py:82-119
+ *   mel_dgnr_forward   -> DGNRNetwork.forward        graph_env/env/utils/networks/dgn_r.py:82-129
  *                         (both include build_pyg_batch_time, networks/common.py:6-64, and the
  *                          [3P] radius_graph / GATv2Conv / global_*_pool / tianshou MLP they call)
  *   mel_select_action  -> [3P] tianshou DQNPolicy.forward mask + argmax and exploration_noise,
@@ -46,6 +47,10 @@ typedef int32_t mel_status;
 
 #define MEL_MODEL_LDGN         0
 #define MEL_MODEL_HLDGN        1
+#define MEL_MODEL_DGNR         2   /* dgn_r.py: the L-DGN skeleton with TransformerConv layers       */
+
+#define MEL_CONV_GATV2         0
+#define MEL_CONV_TRANSFORMER   1
 
 #define MEL_AGG_MAX            0   /* hl_dgn.py:56-60 */
 #define MEL_AGG_MEAN           1
@@ -59,8 +64,12 @@ typedef struct mel_linear {
     int32_t out_dim;
 } mel_linear;
 
-/* [3P] PyG GATv2Conv parameters: lin_l / lin_r [heads*C, in], att [1, heads, C],
- * bias [heads*C]; negative_slope 0.2, self-loops added, softmax eps 1e-16. */
+/* One attention conv layer.
+ * kind MEL_CONV_GATV2 - [3P] PyG GATv2Conv: lin_l (sources) / lin_r (targets)
+ *   [heads*C, in], att [1, heads, C], bias [heads*C]; negative_slope 0.2, self-loops added, eps 1e-16.
+ * kind MEL_CONV_TRANSFORMER - [3P] PyG TransformerConv(root_weight=False) (A.2): lin_l = lin_key and
+ *   lin_v = lin_value (sources), lin_r = lin_query (targets); score q.k/sqrt(C), NO self-loops, no output
+ *   bias (att, bias NULL); lin_skip is a parameter of the module but never used. */
 typedef struct mel_gatv2 {
     mel_linear lin_l;
     mel_linear lin_r;
@@ -68,6 +77,9 @@ typedef struct mel_gatv2 {
     const float* bias;
     int32_t heads;
     int32_t channels;      /* C, per head */
+    mel_linear lin_v;
+    int32_t kind;
+    int32_t reserved;
 } mel_gatv2;
 
 /* [3P] tianshou MLP: Linear, ReLU, ..., Linear (no activation after the last layer). */
@@ -122,6 +134,16 @@ typedef struct mel_select {
 
 size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap);
 mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
+                                   int32_t obs_stride, const uint64_t* agent_mask, int64_t rows_cap,
+                                   float* logits, int32_t* row_offsets, const mel_select* select,
+                                   void* workspace, size_t ws_bytes, void* stream);
+
+/* DGNRNetwork.forward (graph_env/env/utils/networks/dgn_r.py:82-129): same contracts as the two L-DGN
+ * entry points above, for weights with model == MEL_MODEL_DGNR (TransformerConv layers). */
+mel_status mel_dgnr_forward(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
+                            int32_t obs_width, float* logits, void* workspace, size_t ws_bytes,
+                            void* stream);
+mel_status mel_dgnr_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
                                    int32_t obs_stride, const uint64_t* agent_mask, int64_t rows_cap,
                                    float* logits, int32_t* row_offsets, const mel_select* select,
                                    void* workspace, size_t ws_bytes, void* stream);

@@ -8,7 +8,8 @@ import os
 from . import build as _build
 
 MAX_HEAD_LAYERS = 6
-MODEL_LDGN, MODEL_HLDGN = 0, 1
+MODEL_LDGN, MODEL_HLDGN, MODEL_DGNR = 0, 1, 2
+CONV_GATV2, CONV_TRANSFORMER = 0, 1
 AGG = {"max": 0, "mean": 1, "add": 2}
 OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = 0, -1, -2, -3, -4, -5
 ENV_SCALARS, ENV_LOGGER_STATS = 16, 10
@@ -19,7 +20,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+EXPORTS = ("mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
@@ -35,7 +36,8 @@ class MelLinear(C.Structure):
 
 class MelGatv2(C.Structure):
     _fields_ = [("lin_l", MelLinear), ("lin_r", MelLinear), ("att", C.c_void_p), ("bias", C.c_void_p),
-                ("heads", C.c_int32), ("channels", C.c_int32)]
+                ("heads", C.c_int32), ("channels", C.c_int32), ("lin_v", MelLinear), ("kind", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class MelMlp(C.Structure):
@@ -111,6 +113,10 @@ def load(build_if_missing: bool = True):
     lib.mel_workspace_bytes.argtypes = [W, i64, i32]
     lib.mel_ldgn_forward.restype = i32
     lib.mel_ldgn_forward.argtypes = [W, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_dgnr_forward.restype = i32
+    lib.mel_dgnr_forward.argtypes = [W, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_dgnr_forward_agents.restype = i32
+    lib.mel_dgnr_forward_agents.argtypes = [W, vp, i64, i32, i32, vp, i64, vp, vp, C.POINTER(MelSelect), vp, sz, vp]
     lib.mel_hldgn_forward.restype = i32
     lib.mel_hldgn_forward.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
     lib.mel_gemm_f32.restype = i32

@@ -290,6 +290,8 @@ struct AttArgs {
     const int32_t* soff;    // [bs] first source row, or null = b*N
     const int32_t* loff;    // [bs+1] first agent row of the env (ATT_ROWS) / row count at [bs] (ATT_SINGLE)
     int bs, n, lanes_per_head;
+    int kind;               // MEL_CONV_*
+    float score_scale;      // TransformerConv: 1 / sqrt(C)
     // ATT_ROWS
     float* out;             // [rows, ldo] relu(out + bias)
     int ldo;
@@ -356,42 +358,60 @@ __device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
 
 // attention output of one target for this lane's VPL channels: relu(out + bias).  The source rows are
 // streamed once (online softmax); the next row's load is issued before the current row is consumed.
-template <int VPL>
+// KIND = MEL_CONV_GATV2:       e = att . leaky_relu(x_r[i] + x_l[j]),          out = sum alpha x_l[j]
+// KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
+template <int VPL, int KIND>
 __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float* xr_row, uint64_t sources,
                                                   uint64_t smask, int soff, const Vec<VPL>& att,
                                                   const Vec<VPL>& bias, int lane) {
+    constexpr int HC = 64 * VPL;
     const Vec<VPL> xr = load_vec<VPL>(xr_row + lane * VPL);
     float m = -INFINITY, l = 0.f;
     Vec<VPL> acc;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    const float* base = a.xl + lane * VPL;
-    int j = lowest_bit(sources);                 // never empty: the self-loop is always a source
-    sources &= sources - 1;
-    Vec<VPL> nxt = load_vec<VPL>(base + (size_t)(soff + rank_below(smask, j)) * a.ld_l);
-    for (;;) {
-        const Vec<VPL> xl = nxt;
-        const bool more = sources != 0;
-        if (more) {
-            j = lowest_bit(sources);
-            sources &= sources - 1;
-            nxt = load_vec<VPL>(base + (size_t)(soff + rank_below(smask, j)) * a.ld_l);
-        }
-        float s = 0.f;
+    if (sources) {                               // TransformerConv adds no self-loop: a target may be isolated
+        const float* base = a.xl + lane * VPL;
+        int j = lowest_bit(sources);
+        sources &= sources - 1;
+        const float* row = base + (size_t)(soff + rank_below(smask, j)) * a.ld_l;
+        Vec<VPL> nxt = load_vec<VPL>(row), nxt_v;
+        if constexpr (KIND == MEL_CONV_TRANSFORMER) nxt_v = load_vec<VPL>(row + HC);
+        for (;;) {
+            const Vec<VPL> xl = nxt;
+            Vec<VPL> xv;
+            if constexpr (KIND == MEL_CONV_TRANSFORMER) xv = nxt_v;
+            const bool more = sources != 0;
+            if (more) {
+                j = lowest_bit(sources);
+                sources &= sources - 1;
+                row = base + (size_t)(soff + rank_below(smask, j)) * a.ld_l;
+                nxt = load_vec<VPL>(row);
+                if constexpr (KIND == MEL_CONV_TRANSFORMER) nxt_v = load_vec<VPL>(row + HC);
+            }
+            float s = 0.f;
+            if constexpr (KIND == MEL_CONV_GATV2) {
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            float z = xr.v[i] + xl.v[i];
-            z = z > 0.f ? z : 0.2f * z;          // leaky_relu(negative_slope=0.2)
-            s = fmaf(att.v[i], z, s);
-        }
-        s = head_sum(s, a.lanes_per_head);
-        const float mn = fmaxf(m, s);
-        const float sc = expf(m - mn), pe = expf(s - mn);
-        l = l * sc + pe;
+                for (int i = 0; i < VPL; ++i) {
+                    float z = xr.v[i] + xl.v[i];
+                    z = z > 0.f ? z : 0.2f * z;          // leaky_relu(negative_slope=0.2)
+                    s = fmaf(att.v[i], z, s);
+                }
+                s = head_sum(s, a.lanes_per_head);
+            } else {
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) acc.v[i] = acc.v[i] * sc + pe * xl.v[i];
-        m = mn;
-        if (!more) break;
+                for (int i = 0; i < VPL; ++i) s = fmaf(xr.v[i], xl.v[i], s);
+                s = head_sum(s, a.lanes_per_head) * a.score_scale;
+            }
+            const float mn = fmaxf(m, s);
+            const float sc = expf(m - mn), pe = expf(s - mn);
+            l = l * sc + pe;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                acc.v[i] = acc.v[i] * sc + pe * (KIND == MEL_CONV_TRANSFORMER ? xv.v[i] : xl.v[i]);
+            m = mn;
+            if (!more) break;
+        }
     }
     const float inv = 1.f / (l + 1e-16f);
     Vec<VPL> out;
@@ -400,23 +420,33 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
     return out;
 }
 
+template <int VPL>
+__device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
+    Vec<VPL> r;
+    if (p) return load_vec<VPL>(p + lane * VPL);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) r.v[i] = 0.f;
+    return r;
+}
+
 // ATT_ROWS / ATT_SINGLE: ONE WAVEFRONT PER TARGET ROW over the whole batch (envs differ a lot in how many
 // targets they have - a workgroup per env leaves the launch waiting for the few crowded envs).
 //   ATT_ROWS   conv1 of L-DGN: row r of the U1 list -> h1[r]; the agents' x_1 / x_2 go to the head input
 //   ATT_SINGLE conv2 of L-DGN: one target per agent row (only the controlling agent's row can reach its
 //              logits, l_dgn.py:135), sources = its closed neighbourhood inside U1 -> x_3
-template <int VPL, int MODE>
+template <int VPL, int MODE, int KIND>
 __global__ __launch_bounds__(256) void gat_attend_rows_kernel(AttArgs a) {
     const int lane = lane_id();
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.rows_cap || r >= *a.rows_dev) return;
-    const Vec<VPL> att = load_vec<VPL>(a.att + lane * VPL);
-    const Vec<VPL> bias = load_vec<VPL>(a.bias + lane * VPL);
+    const Vec<VPL> att = load_vec_or_zero<VPL>(a.att, lane);
+    const Vec<VPL> bias = load_vec_or_zero<VPL>(a.bias, lane);
     const int b = a.row_env[r], t = a.row_agent[r];
-    const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
+    uint64_t sources = a.adj[(size_t)b * a.n + t];
+    if (KIND == MEL_CONV_GATV2) sources |= 1ull << t;              // GATv2Conv adds self-loops
     const uint64_t smask = a.smask[b];
     const int soff = a.soff[b];
-    const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)r * a.ld_r, sources, smask, soff, att, bias, lane);
+    const Vec<VPL> o = attend_target<VPL, KIND>(a, a.xr + (size_t)r * a.ld_r, sources, smask, soff, att, bias, lane);
     if constexpr (MODE == ATT_SINGLE) {
         store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
     } else {
@@ -450,8 +480,8 @@ __global__ __launch_bounds__(256) void gat_attend_pool_kernel(AttArgs a) {
     for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
     for (int t = wave; t < a.n; t += 4) {
         const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
-        const Vec<VPL> o = attend_target<VPL>(a, a.xr + (size_t)(b * a.n + t) * a.ld_r, sources, full, b * a.n, att,
-                                              bias, lane);
+        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2>(a, a.xr + (size_t)(b * a.n + t) * a.ld_r, sources, full,
+                                                              b * a.n, att, bias, lane);
         // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
         const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
@@ -487,13 +517,19 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         }
     } else {
         const int grid = (a.rows_cap + 3) / 4;
+#define MEL_ATT_LAUNCH(V)                                                                                      \
+    if (a.kind == MEL_CONV_TRANSFORMER)                                                                        \
+        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); \
+    else                                                                                                       \
+        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);
         switch (hc / 64) {
-            case 2: hipLaunchKernelGGL((gat_attend_rows_kernel<2, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((gat_attend_rows_kernel<4, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-            case 8: hipLaunchKernelGGL((gat_attend_rows_kernel<8, MODE>), dim3(grid), dim3(256), 0, s, a); break;
-            case 16: hipLaunchKernelGGL((gat_attend_rows_kernel<16, MODE>), dim3(grid), dim3(256), 0, s, a); break;
+            case 2: MEL_ATT_LAUNCH(2) break;
+            case 4: MEL_ATT_LAUNCH(4) break;
+            case 8: MEL_ATT_LAUNCH(8) break;
+            case 16: MEL_ATT_LAUNCH(16) break;
             default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
         }
+#undef MEL_ATT_LAUNCH
     }
     return check_launch(what);
 }
@@ -695,7 +731,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.plan.adj = c.take<uint64_t>(M);
     L.plan.live = c.take<uint64_t>(d.bs);
     const int latent = w->q_head.layer[0].in_dim;
-    if (w->model == MEL_MODEL_LDGN) {
+    if (w->model != MEL_MODEL_HLDGN) {
         L.plan.u1 = c.take<uint64_t>(d.bs);
         L.plan.u2 = c.take<uint64_t>(d.bs);
         L.plan.cnt = c.take<int32_t>(3 * d.bs);
@@ -712,10 +748,11 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         L.plan.arow_g = c.take<int32_t>(R);
         L.plan.dm_g = c.take<float>(R);
         L.h0 = c.take<float>((size_t)d.u2_cap * hidden);
-        L.xl1 = c.take<float>((size_t)d.u2_cap * hc);
+        const int srcw = (w->conv1.kind == MEL_CONV_TRANSFORMER) ? 2 * hc : hc;     // key | value side by side
+        L.xl1 = c.take<float>((size_t)d.u2_cap * srcw);
         L.xr1 = c.take<float>((size_t)d.u1_cap * hc);
         L.h1 = c.take<float>((size_t)d.u1_cap * hc);
-        L.xl2 = c.take<float>((size_t)d.u1_cap * hc);
+        L.xl2 = c.take<float>((size_t)d.u1_cap * srcw);
         L.xr2 = c.take<float>(R * hc);
     } else {
         L.h0 = c.take<float>(M * hidden);
@@ -759,12 +796,20 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
         return fail(MEL_ERR_UNSUPPORTED, "channels per head (%d) must be a power-of-two multiple of %d", w->conv1.channels, hc / 64);
     if (w->conv1.lin_l.in_dim != hidden || w->conv1.lin_l.out_dim != hc || w->conv1.lin_r.out_dim != hc)
         return fail(MEL_ERR_INVALID_ARG, "conv1 projection shapes inconsistent");
+    const int want_kind = (model == MEL_MODEL_DGNR) ? MEL_CONV_TRANSFORMER : MEL_CONV_GATV2;
+    if (w->conv1.kind != want_kind) return fail(MEL_ERR_INVALID_ARG, "conv1 kind %d does not fit model %d", w->conv1.kind, model);
+    if (want_kind == MEL_CONV_GATV2 && (!w->conv1.att || !w->conv1.bias)) return fail(MEL_ERR_INVALID_ARG, "conv1 att/bias null");
+    if (want_kind == MEL_CONV_TRANSFORMER && (w->conv1.lin_v.in_dim != hidden || w->conv1.lin_v.out_dim != hc))
+        return fail(MEL_ERR_INVALID_ARG, "conv1 value projection shape inconsistent");
     int latent = hc;
-    if (model == MEL_MODEL_LDGN) {
-        if (w->conv2.heads != w->conv1.heads || w->conv2.channels != w->conv1.channels ||
+    if (model != MEL_MODEL_HLDGN) {
+        if (w->conv2.heads != w->conv1.heads || w->conv2.channels != w->conv1.channels || w->conv2.kind != want_kind ||
             w->conv2.lin_l.in_dim != hc || w->conv2.lin_l.out_dim != hc || w->conv2.lin_r.out_dim != hc)
             return fail(MEL_ERR_INVALID_ARG, "conv2 projection shapes inconsistent");
-        latent = hidden + 2 * hc;                    // l_dgn.py:44
+        if (want_kind == MEL_CONV_GATV2 && (!w->conv2.att || !w->conv2.bias)) return fail(MEL_ERR_INVALID_ARG, "conv2 att/bias null");
+        if (want_kind == MEL_CONV_TRANSFORMER && (w->conv2.lin_v.in_dim != hc || w->conv2.lin_v.out_dim != hc))
+            return fail(MEL_ERR_INVALID_ARG, "conv2 value projection shape inconsistent");
+        latent = hidden + 2 * hc;                    // l_dgn.py:44, dgn_r.py:63
     }
     const mel_mlp* heads[2] = {&w->q_head, &w->v_head};
     for (int k = 0; k < (w->dueling ? 2 : 1); ++k) {
@@ -834,6 +879,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const int node_cols = w->in_dim + 3;
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int latent = hidden + 2 * hc;
+    const bool tconv = w->conv1.kind == MEL_CONV_TRANSFORMER;
+    const int srcw = tconv ? 2 * hc : hc;          // source-side projection width (key | value)
     const int R = (int)d.rows_cap, U1 = (int)d.u1_cap, U2 = (int)d.u2_cap;
     const int32_t* nL = L.plan.offL + bs;
     const int32_t* n1 = L.plan.off1 + bs;
@@ -868,7 +915,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
         GemmArgs g[2];
         g[0].A = L.h0, g[0].lda = hidden, g[0].W = w->conv1.lin_l.weight, g[0].bias = w->conv1.lin_l.bias;
-        g[0].Y = L.xl1, g[0].ldy = hc, g[0].M = U2, g[0].M_dev = n2, g[0].N = hc, g[0].K = hidden;
+        g[0].Y = L.xl1, g[0].ldy = srcw, g[0].M = U2, g[0].M_dev = n2, g[0].N = srcw, g[0].K = hidden;
+        if (tconv)       // key | value of the sources in one problem (weights split along n)
+            g[0].W_hi = w->conv1.lin_v.weight, g[0].bias_hi = w->conv1.lin_v.bias, g[0].split_n = hc;
         g[1].A = L.h0, g[1].lda = hidden, g[1].arow = L.plan.arow1;
         g[1].W = w->conv1.lin_r.weight, g[1].bias = w->conv1.lin_r.bias;
         g[1].Y = L.xr1, g[1].ldy = hc, g[1].M = U1, g[1].M_dev = n1, g[1].N = hc, g[1].K = hidden;
@@ -878,7 +927,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     }
     {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
         AttArgs a{};
-        a.xl = L.xl1, a.ld_l = hc, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
+        a.xl = L.xl1, a.ld_l = srcw, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
+        a.kind = w->conv1.kind, a.score_scale = 1.0f / sqrtf((float)w->conv1.channels);
         a.adj = L.plan.adj, a.live = L.plan.live, a.smask = L.plan.u2;
         a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
         a.row_env = L.plan.t_env, a.row_agent = L.plan.t_node, a.rows_dev = n1, a.rows_cap = U1;
@@ -892,7 +942,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         GemmArgs g[2];
         g[0].A = L.h1, g[0].lda = hc, g[0].rscale = L.plan.dm1;
         g[0].W = w->conv2.lin_l.weight, g[0].bias = w->conv2.lin_l.bias;
-        g[0].Y = L.xl2, g[0].ldy = hc, g[0].M = U1, g[0].M_dev = n1, g[0].N = hc, g[0].K = hc;
+        g[0].Y = L.xl2, g[0].ldy = srcw, g[0].M = U1, g[0].M_dev = n1, g[0].N = srcw, g[0].K = hc;
+        if (tconv) g[0].W_hi = w->conv2.lin_v.weight, g[0].bias_hi = w->conv2.lin_v.bias, g[0].split_n = hc;
         g[1].A = L.h1, g[1].lda = hc, g[1].arow = L.plan.arow_g, g[1].rscale = L.plan.dm_g;
         g[1].W = w->conv2.lin_r.weight, g[1].bias = w->conv2.lin_r.bias;
         g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;
@@ -902,7 +953,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     }
     {   // conv2 attention, one target per agent row -> x_3
         AttArgs a{};
-        a.xl = L.xl2, a.ld_l = hc, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
+        a.xl = L.xl2, a.ld_l = srcw, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
+        a.kind = w->conv2.kind, a.score_scale = 1.0f / sqrtf((float)w->conv2.channels);
         a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
         a.row_env = L.plan.row_env, a.row_agent = L.plan.row_agent, a.rows_dev = nL, a.rows_cap = R;
@@ -944,6 +996,25 @@ mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64
                                    int32_t* row_offsets, const mel_select* select, void* workspace,
                                    size_t ws_bytes, void* stream) {
     if (mel_status st = validate(w, MEL_MODEL_LDGN, bs, n, obs_stride, false)) return st;
+    if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "agent_mask is null");
+    if (rows_cap < 1 || rows_cap > bs * (int64_t)n) return fail(MEL_ERR_INVALID_ARG, "rows_cap=%ld outside [1, bs*n]", (long)rows_cap);
+    if (select && !select->act) return fail(MEL_ERR_INVALID_ARG, "select->act is null");
+    return ldgn_forward_impl(w, obs, make_dims(bs, n, rows_cap, false), obs_stride, agent_mask, logits, row_offsets,
+                             select, workspace, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+mel_status mel_dgnr_forward(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_width,
+                            float* logits, void* workspace, size_t ws_bytes, void* stream) {
+    if (mel_status st = validate(w, MEL_MODEL_DGNR, bs, n, obs_width, true)) return st;
+    return ldgn_forward_impl(w, obs, make_dims(bs, n, bs, true), obs_width, nullptr, logits, nullptr, nullptr,
+                             workspace, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+mel_status mel_dgnr_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n, int32_t obs_stride,
+                                   const uint64_t* agent_mask, int64_t rows_cap, float* logits,
+                                   int32_t* row_offsets, const mel_select* select, void* workspace,
+                                   size_t ws_bytes, void* stream) {
+    if (mel_status st = validate(w, MEL_MODEL_DGNR, bs, n, obs_stride, false)) return st;
     if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "agent_mask is null");
     if (rows_cap < 1 || rows_cap > bs * (int64_t)n) return fail(MEL_ERR_INVALID_ARG, "rows_cap=%ld outside [1, bs*n]", (long)rows_cap);
     if (select && !select->act) return fail(MEL_ERR_INVALID_ARG, "select->act is null");
@@ -993,7 +1064,7 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
     {
         AttArgs a{};
         a.xl = L.xl1, a.ld_l = 2 * hc, a.xr = L.xl1 + hc, a.ld_r = 2 * hc;
-        a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj;
+        a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj, a.kind = MEL_CONV_GATV2;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.obs = obs, a.obs_stride = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
         a.pooled = L.xcat;
@@ -1025,7 +1096,7 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
         e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
     else if (kind == 1)
         e = hipMemcpyAsync(out, L.xcat, (size_t)d.rows_cap * w->q_head.layer[0].in_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
-    else if (kind == 2 && w->model == MEL_MODEL_LDGN) {
+    else if (kind == 2 && w->model != MEL_MODEL_HLDGN) {
         int32_t* o = static_cast<int32_t*>(out);
         e = hipMemcpyAsync(o, L.plan.off1 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(o + 1, L.plan.off2 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);

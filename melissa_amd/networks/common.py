@@ -71,6 +71,24 @@ class GATv2Conv(nn.Module):
         nn.init.zeros_(self.bias)
 
 
+class TransformerConv(nn.Module):
+    """Parameter container with PyG 2.2 ``TransformerConv(in, C, heads, root_weight=False)`` names and shapes
+    (SURVEY.md A.2): ``lin_key`` / ``lin_query`` / ``lin_value`` Linear(in, H*C) with bias, plus ``lin_skip``,
+    which PyG creates but never uses when ``root_weight=False`` (kept so state_dicts load)."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, root_weight: bool = False):
+        super().__init__()
+        assert not root_weight, "the reference builds TransformerConv with root_weight=False (dgn_r.py:47-58)"
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.lin_key = nn.Linear(in_channels, heads * out_channels)
+        self.lin_query = nn.Linear(in_channels, heads * out_channels)
+        self.lin_value = nn.Linear(in_channels, heads * out_channels)
+        self.lin_skip = nn.Linear(in_channels, heads * out_channels)
+        for lin in (self.lin_key, self.lin_query, self.lin_value, self.lin_skip):
+            a = math.sqrt(6.0 / (lin.in_features + lin.out_features))
+            nn.init.uniform_(lin.weight, -a, a)
+
+
 def check_obs(obs: torch.Tensor, input_dim: int, agents_num: int):
     """The two shape errors of build_pyg_batch_time (networks/common.py:20-29)."""
     if obs.ndim != 2:
@@ -98,11 +116,19 @@ def _mlp(struct: _lib.MelMlp, linears):
         _lin(struct.layer[k], lin)
 
 
-def _gat(struct: _lib.MelGatv2, conv: GATv2Conv):
+def _gat(struct: _lib.MelGatv2, conv):
+    struct.heads, struct.channels = conv.heads, conv.out_channels
+    if isinstance(conv, TransformerConv):
+        struct.kind = _lib.CONV_TRANSFORMER
+        _lin(struct.lin_l, conv.lin_key)          # sources
+        _lin(struct.lin_v, conv.lin_value)        # sources
+        _lin(struct.lin_r, conv.lin_query)        # targets
+        struct.att, struct.bias = None, None
+        return
+    struct.kind = _lib.CONV_GATV2
     _lin(struct.lin_l, conv.lin_l)
     _lin(struct.lin_r, conv.lin_r)
     struct.att, struct.bias = conv.att.data_ptr(), conv.bias.data_ptr()
-    struct.heads, struct.channels = conv.heads, conv.out_channels
 
 
 class HipForwardMixin:
@@ -125,7 +151,7 @@ class HipForwardMixin:
         w.model, w.in_dim, w.n_actions = self._MODEL, self.input_dim, self.output_dim
         _mlp(w.encoder, self.encoder.linears())
         _gat(w.conv1, self.conv1)
-        if self._MODEL == _lib.MODEL_LDGN:
+        if self._MODEL != _lib.MODEL_HLDGN:
             _gat(w.conv2, self.conv2)
         if self.use_dueling:
             w.dueling = 1
@@ -165,9 +191,10 @@ class HipForwardMixin:
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs.device)
         stream = _lib.current_stream_ptr(obs.device)
-        if self._MODEL == _lib.MODEL_LDGN:
-            st = lib.mel_ldgn_forward(C.byref(w), obs.data_ptr(), bs, self.agents_num, obs.shape[1],
-                                      out.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        if self._MODEL in (_lib.MODEL_LDGN, _lib.MODEL_DGNR):
+            fn = lib.mel_ldgn_forward if self._MODEL == _lib.MODEL_LDGN else lib.mel_dgnr_forward
+            st = fn(C.byref(w), obs.data_ptr(), bs, self.agents_num, obs.shape[1], out.data_ptr(), ws.data_ptr(),
+                    ws.numel(), stream)
         else:
             st = lib.mel_hldgn_forward(C.byref(w), _lib.AGG[self.aggregator_name], obs.data_ptr(), bs,
                                        self.agents_num, obs.shape[1], out.data_ptr(), ws.data_ptr(),
@@ -201,8 +228,8 @@ class HipForwardMixin:
         """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
         [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
         patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
-        if self._MODEL != _lib.MODEL_LDGN:
-            raise RuntimeError("hip_forward_agents is the L-DGN entry point")
+        if self._MODEL == _lib.MODEL_HLDGN:
+            raise RuntimeError("hip_forward_agents is the L-DGN / DGN-R entry point")
         lib = _lib.load()
         assert obs_matrix.is_cuda and obs_matrix.dtype == torch.float32 and obs_matrix.stride(-1) == 1
         bs = obs_matrix.shape[0]
@@ -221,10 +248,10 @@ class HipForwardMixin:
             out = torch.empty(rows_cap, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
         if row_offsets is None:
             row_offsets = torch.empty(bs + 1, dtype=torch.int32, device=obs_matrix.device)
-        st = lib.mel_ldgn_forward_agents(C.byref(w), obs_matrix.data_ptr(), bs, self.agents_num, obs_matrix.stride(0),
-                                         agent_mask.data_ptr(), rows_cap, out.data_ptr(), row_offsets.data_ptr(),
-                                         C.byref(select) if select is not None else None,
-                                         ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+        fn = lib.mel_ldgn_forward_agents if self._MODEL == _lib.MODEL_LDGN else lib.mel_dgnr_forward_agents
+        st = fn(C.byref(w), obs_matrix.data_ptr(), bs, self.agents_num, obs_matrix.stride(0), agent_mask.data_ptr(),
+                rows_cap, out.data_ptr(), row_offsets.data_ptr(), C.byref(select) if select is not None else None,
+                ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
         _lib.check(st, "mel_ldgn_forward_agents")
         return out, row_offsets
 
@@ -269,6 +296,21 @@ def gatv2_dense(conv: GATv2Conv, x: torch.Tensor, adj: torch.Tensor) -> torch.Te
     alpha = p / (p.sum(dim=2, keepdim=True) + 1e-16)
     out = torch.einsum("bijh,bjhc->bihc", alpha, x_l)
     return out.reshape(bs * n, h * c) + conv.bias
+
+
+def transformer_dense(conv: TransformerConv, x: torch.Tensor, adj: torch.Tensor) -> torch.Tensor:
+    bs, n, _ = adj.shape
+    h, c = conv.heads, conv.out_channels
+    q = conv.lin_query(x).view(bs, n, h, c)
+    k = conv.lin_key(x).view(bs, n, h, c)
+    v = conv.lin_value(x).view(bs, n, h, c)
+    e = torch.einsum("bihc,bjhc->bijh", q, k) / math.sqrt(c)
+    e = e.masked_fill(~adj[..., None], -float("inf"))
+    e_max = e.max(dim=2, keepdim=True).values
+    e_max = torch.where(torch.isfinite(e_max), e_max, torch.zeros((), device=e.device))
+    p = torch.where(adj[..., None], torch.exp(e - e_max), torch.zeros((), device=e.device))
+    alpha = p / (p.sum(dim=2, keepdim=True) + 1e-16)
+    return torch.einsum("bijh,bjhc->bihc", alpha, v).reshape(bs * n, h * c)
 
 
 def unpack(obs: torch.Tensor, input_dim: int, n: int):

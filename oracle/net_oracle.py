@@ -11,6 +11,7 @@ algorithms at the reference's call sites:
 * ``build_pyg_batch_time``   graph_env/env/utils/networks/common.py:6-64
 * ``LDGNNetwork.forward``    graph_env/env/utils/networks/l_dgn.py:92-151
 * ``HLDGNNetwork.forward``   graph_env/env/utils/networks/hl_dgn.py:82-119
+* ``DGNRNetwork.forward``    graph_env/env/utils/networks/dgn_r.py:82-129 ([3P] ``TransformerConv``, A.2)
 * [3P] ``radius_graph(pos, r=0.2, loop=False)``: fp32, dist^2 < r^2 strict, first 33 hits in index
   order per target then self dropped (torch_cluster CUDA kernel semantics for max_num_neighbors=32)
 * [3P] ``GATv2Conv`` (A.1), ``global_{max,mean,add}_pool`` (A.4), tianshou ``MLP`` (A.0),
@@ -76,12 +77,25 @@ def init_weights(model: str, input_dim=5, hidden=128, heads=4, n_actions=2, seed
         sd[f"{prefix}.att"] = _glorot(gen, 1, heads, hidden)
         sd[f"{prefix}.bias"] = _uniform(gen, 0.1, hc) if random_conv_bias else torch.zeros(hc)
 
+    def tconv(prefix, in_f):
+        # PyG 2.2 TransformerConv(in, C, heads, root_weight=False): lin_key / lin_query / lin_value and a
+        # lin_skip that exists as a parameter but is never used (dgn_r.py:47-58)
+        hc = heads * hidden
+        for lin in ("lin_key", "lin_query", "lin_value", "lin_skip"):
+            sd[f"{prefix}.{lin}.weight"] = _glorot(gen, hc, in_f)
+            sd[f"{prefix}.{lin}.bias"] = _uniform(gen, 1.0 / math.sqrt(in_f), hc)
+
     mlp("encoder", [input_dim, hidden, hidden])
-    conv("conv1", hidden)
-    if model == "l_dgn":
+    if model == "dgn_r":
+        tconv("conv1", hidden)
+        tconv("conv2", hidden * heads)
+        latent = hidden + 2 * hidden * heads                     # dgn_r.py:63
+    elif model == "l_dgn":
+        conv("conv1", hidden)
         conv("conv2", hidden * heads)
         latent = hidden + 2 * hidden * heads                     # l_dgn.py:44
     elif model == "hl_dgn":
+        conv("conv1", hidden)
         latent = hidden * heads                                  # hl_dgn.py:64
     else:
         raise ValueError(model)
@@ -190,6 +204,48 @@ def gatv2_dense(sd, prefix, x, adj, heads):
 _GAT = {"edges": gatv2_edges, "dense": gatv2_dense}
 
 
+def transformer_edges(sd, prefix, x, adj, heads):
+    """[3P] PyG TransformerConv(root_weight=False) (A.2): q = lin_query(x_i), k = lin_key(x_j),
+    v = lin_value(x_j); e = q.k / sqrt(C); softmax over incoming edges (eps 1e-16); NO self-loops (an
+    isolated target gets zeros); heads concatenated; no output bias, lin_skip unused."""
+    bs, n, _ = adj.shape
+    hc = sd[f"{prefix}.lin_key.weight"].shape[0]
+    c = hc // heads
+    q = F.linear(x, sd[f"{prefix}.lin_query.weight"], sd[f"{prefix}.lin_query.bias"]).view(-1, heads, c)
+    k = F.linear(x, sd[f"{prefix}.lin_key.weight"], sd[f"{prefix}.lin_key.bias"]).view(-1, heads, c)
+    v = F.linear(x, sd[f"{prefix}.lin_value.weight"], sd[f"{prefix}.lin_value.bias"]).view(-1, heads, c)
+    b_idx, i_idx, j_idx = torch.nonzero(adj, as_tuple=True)
+    src = b_idx * n + j_idx
+    dst = b_idx * n + i_idx
+    e = (q[dst] * k[src]).sum(dim=-1) / math.sqrt(c)
+    e_max = torch.full((bs * n, heads), -float("inf")).scatter_reduce(
+        0, dst[:, None].expand(-1, heads), e, reduce="amax", include_self=True)
+    p = (e - e_max[dst]).exp()
+    denom = torch.zeros(bs * n, heads).index_add_(0, dst, p) + 1e-16
+    alpha = p / denom[dst]
+    out = torch.zeros(bs * n, heads, c).index_add_(0, dst, v[src] * alpha[:, :, None])
+    return out.reshape(bs * n, hc)
+
+
+def transformer_dense(sd, prefix, x, adj, heads):
+    bs, n, _ = adj.shape
+    hc = sd[f"{prefix}.lin_key.weight"].shape[0]
+    c = hc // heads
+    q = (x @ sd[f"{prefix}.lin_query.weight"].t() + sd[f"{prefix}.lin_query.bias"]).view(bs, n, heads, c)
+    k = (x @ sd[f"{prefix}.lin_key.weight"].t() + sd[f"{prefix}.lin_key.bias"]).view(bs, n, heads, c)
+    v = (x @ sd[f"{prefix}.lin_value.weight"].t() + sd[f"{prefix}.lin_value.bias"]).view(bs, n, heads, c)
+    e = torch.einsum("bihc,bjhc->bijh", q, k) / math.sqrt(c)
+    e = e.masked_fill(~adj[..., None], -float("inf"))
+    e_max = e.max(dim=2, keepdim=True).values
+    e_max = torch.where(torch.isfinite(e_max), e_max, torch.zeros(()))     # isolated targets
+    p = torch.where(adj[..., None], torch.exp(e - e_max), torch.zeros(()))
+    alpha = p / (p.sum(dim=2, keepdim=True) + 1e-16)
+    return torch.einsum("bijh,bjhc->bihc", alpha, v).reshape(bs * n, hc)
+
+
+_TCONV = {"edges": transformer_edges, "dense": transformer_dense}
+
+
 def _dueling(sd, x):
     q = _mlp(sd, "Q", x, _n_layers(sd, "Q"))
     v = _mlp(sd, "V", x, _n_layers(sd, "V"))
@@ -219,6 +275,27 @@ def ldgn_forward(sd, obs, agents_num, heads=4, formulation="edges", return_inter
     out = _dueling(sd, x_cat)
     if return_intermediates:
         return out, dict(adj=adj, x_1=x_1, x_2=x_2, x_3=x_3, h1=h1)
+    return out
+
+
+def dgnr_forward(sd, obs, agents_num, heads=4, formulation="edges", return_intermediates=False):
+    """dgn_r.py:82-129: same skeleton as L-DGN with TransformerConv layers."""
+    obs = torch.as_tensor(np.asarray(obs) if not torch.is_tensor(obs) else obs)
+    pos, feats, dm, g = unpack_obs(obs, agents_num, sd["encoder.model.0.weight"].shape[1])
+    bs, n = pos.shape[:2]
+    adj = radius_adjacency(pos)
+    conv = _TCONV[formulation]
+    x = F.relu(_mlp(sd, "encoder", feats.reshape(bs * n, -1), 2))         # :97-98
+    gi = torch.arange(bs) * n + g
+    x_1 = x[gi]
+    x = F.relu(conv(sd, "conv1", x, adj, heads))                         # :104-105
+    x_2 = x[gi]
+    x = x * dm.reshape(bs * n, 1)                                        # :109
+    x = F.relu(conv(sd, "conv2", x, adj, heads))                         # :112-113
+    x_3 = x[gi]
+    out = _dueling(sd, torch.cat([x_1, x_2, x_3], dim=1))
+    if return_intermediates:
+        return out, dict(adj=adj, x_1=x_1, x_2=x_2, x_3=x_3)
     return out
 
 

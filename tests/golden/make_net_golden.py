@@ -91,6 +91,11 @@ def make(name, n, rows, seed, weight_seed):
         for k in ("x_1", "x_2", "x_3"):
             out[f"ldgn_{k}"] = inter[k].numpy()
         out["adj"] = np.packbits(inter["adj"].numpy(), axis=-1, bitorder="little")
+        sd = no.init_weights("dgn_r", seed=weight_seed + 2)
+        logits, inter = no.dgnr_forward(sd, obs, n, return_intermediates=True)
+        out["dgnr_logits"] = logits.numpy()
+        for k in ("x_1", "x_2", "x_3"):
+            out[f"dgnr_{k}"] = inter[k].numpy()
         sd = no.init_weights("hl_dgn", seed=weight_seed + 1, random_conv_bias=True)
         for agg in ("max", "mean", "add"):
             logits, inter = no.hldgn_forward(sd, obs, n, aggregator=agg, return_intermediates=True)

@@ -15,10 +15,12 @@ DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
 
 
 def make_net(model, n, seed, agg="max", dueling=True):
-    from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
+    from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
     from oracle import net_oracle as no
     sd = no.init_weights(model, seed=seed, random_conv_bias=True)
-    if model == "l_dgn":
+    if model == "dgn_r":
+        net = DGNRNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    elif model == "l_dgn":
         net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
     else:
         net = HLDGNNetwork(5, 128, 2, 4, n, aggregator=agg, dueling_param=DUEL(), device="cuda", backend="hip")
@@ -45,6 +47,21 @@ def test_ldgn_matches_golden(path):
                                atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[11:-4] for p in GOLDENS])
+def test_dgnr_matches_golden(path):
+    """TransformerConv path (dgn_r.py): logits and the x_1|x_2|x_3 head input; the goldens include a clique
+    (neighbour cap) and a lattice with isolated nodes (no self-loops -> zero rows)."""
+    g = np.load(path)
+    n, obs = int(g["n"]), g["obs"]
+    net, _ = make_net("dgn_r", n, int(g["weight_seed"]) + 2)
+    with torch.no_grad():
+        logits, state = net(obs, state=None)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["dgnr_logits"], atol=TOL, rtol=0)
+    xcat = net.hip_tap(1, obs.shape[0]).cpu().numpy()
+    np.testing.assert_allclose(xcat, np.concatenate([g["dgnr_x_1"], g["dgnr_x_2"], g["dgnr_x_3"]], axis=1),
+                               atol=TOL, rtol=0)
+
+
 @pytest.mark.parametrize("agg", ["max", "mean", "add"])
 @pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[11:-4] for p in GOLDENS])
 def test_hldgn_matches_golden(path, agg):
@@ -59,7 +76,7 @@ def test_hldgn_matches_golden(path, agg):
     np.testing.assert_allclose(pooled, g[f"hldgn_{agg}_pooled"], atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn"])
+@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])
 @pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (1, 5), (7, 1)])
 def test_matches_oracle_on_random_batches(model, n, bs):
     """Fresh seeded inputs at sizes the oracle finishes in seconds (incl. ragged / tiny / max-N cases)."""
@@ -77,7 +94,8 @@ def test_matches_oracle_on_random_batches(model, n, bs):
     with torch.no_grad():
         got = net(obs)[0].cpu().numpy()
         torch.set_num_threads(8)
-        want = (no.ldgn_forward(sd, obs, n) if model == "l_dgn" else no.hldgn_forward(sd, obs, n)).numpy()
+        fwd = {"l_dgn": no.ldgn_forward, "hl_dgn": no.hldgn_forward, "dgn_r": no.dgnr_forward}[model]
+        want = fwd(sd, obs, n).numpy()
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
 
 

@@ -10,11 +10,12 @@ TOL = 1e-4
 DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
 
 
-def make_ldgn(n, seed=9):
-    from melissa_amd.networks import LDGNNetwork
+def make_ldgn(n, seed=9, model="l_dgn"):
+    from melissa_amd.networks import DGNRNetwork, LDGNNetwork
     from oracle import net_oracle as no
-    sd = no.init_weights("l_dgn", seed=seed, random_conv_bias=True)
-    net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    sd = no.init_weights(model, seed=seed, random_conv_bias=True)
+    cls = LDGNNetwork if model == "l_dgn" else DGNRNetwork
+    net = cls(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
     net.load_state_dict(sd)
     return net, sd
 
@@ -29,8 +30,9 @@ def random_obs_matrix(rng, bs, n):
     return m
 
 
+@pytest.mark.parametrize("model", ["l_dgn", "dgn_r"])
 @pytest.mark.parametrize("n,bs", [(20, 64), (50, 40), (64, 9), (5, 7)])
-def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs):
+def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs, model):
     from oracle import net_oracle as no
     rng = np.random.RandomState(n * 100 + bs)
     mat = random_obs_matrix(rng, bs, n)
@@ -41,7 +43,7 @@ def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs):
         for a in sorted(rng.choice(n, size=k, replace=False)):
             masks[b] |= np.uint64(1) << np.uint64(a)
             rows.append((b, int(a)))
-    net, sd = make_ldgn(n)
+    net, sd = make_ldgn(n, model=model)
     cap = bs * n
     obs_matrix = torch.from_numpy(mat.reshape(bs, n * 8)).cuda()
     with torch.no_grad():
@@ -54,7 +56,7 @@ def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs):
                                np.array([[a] for _, a in rows], dtype=np.float32)], axis=1)
     with torch.no_grad():
         per_row = net.hip_forward(torch.from_numpy(obs_rows).cuda()).cpu().numpy()
-        want = no.ldgn_forward(sd, obs_rows, n).numpy()
+        want = (no.ldgn_forward if model == "l_dgn" else no.dgnr_forward)(sd, obs_rows, n).numpy()
     got = logits[:len(rows)].cpu().numpy()
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
     np.testing.assert_allclose(got, per_row, atol=2e-5, rtol=0)

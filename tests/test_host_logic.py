@@ -6,7 +6,7 @@ import torch
 
 from melissa_amd.env.episodes import (EpisodeSampler, Graph, movement_offsets, pack_episodes,
                                       synthetic_graph_pool)
-from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
+from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
 from melissa_amd.policy import DQNPolicy, MultiAgentSharedPolicy
 from oracle import env_oracle as eo
 from oracle import net_oracle as no
@@ -63,6 +63,13 @@ def test_network_dropin_surface():
     assert sum(p.numel() for p in hl.parameters()) == 315139
     with pytest.raises(KeyError):
         HLDGNNetwork(5, 128, 2, 4, 20, aggregator="median", dueling_param=DUEL())
+    dr = DGNRNetwork(5, 128, 2, 4, 20, dueling_param=DUEL(), backend="torch")
+    assert set(dr.state_dict()) == set(no.init_weights("dgn_r")) and sum(p.numel() for p in dr.parameters()) == 1660675
+    g = np.load("tests/golden/net_golden_n20.npz")
+    dr.load_state_dict(no.init_weights("dgn_r", seed=int(g["weight_seed"]) + 2))
+    with torch.enable_grad():
+        out, _ = dr(g["obs"])
+    np.testing.assert_allclose(out.detach().numpy(), g["dgnr_logits"], atol=1e-5, rtol=0)
     single = LDGNNetwork(5, 128, 2, 4, 20, dueling_param=None, backend="torch")
     assert "out_linear.weight" in single.state_dict() and single.out_linear.in_features == 1152
     with pytest.raises(ValueError, match="Expected obs to be 2D"):

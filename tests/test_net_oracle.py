@@ -29,6 +29,11 @@ def test_formulations_agree_and_match_golden(path):
             np.testing.assert_allclose(idn[k].numpy(), g[f"ldgn_{k}"], atol=2e-5, rtol=0)
         adj_bits = np.unpackbits(g["adj"], axis=-1, bitorder="little")[..., :n].astype(bool)
         assert np.array_equal(adj_bits, ie["adj"].numpy())
+        sd = no.init_weights("dgn_r", seed=ws + 2)
+        e = no.dgnr_forward(sd, obs, n, formulation="edges")
+        d = no.dgnr_forward(sd, obs, n, formulation="dense")
+        np.testing.assert_allclose(e.numpy(), d.numpy(), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(e.numpy(), g["dgnr_logits"], atol=1e-6, rtol=0)
         sd = no.init_weights("hl_dgn", seed=ws + 1, random_conv_bias=True)
         for agg in ("max", "mean", "add"):
             e = no.hldgn_forward(sd, obs, n, aggregator=agg, formulation="edges")
@@ -64,6 +69,9 @@ def test_state_dict_names_and_counts():
     sd = no.init_weights("l_dgn")
     assert sum(v.numel() for v in sd.values()) == 1005315
     assert sd["conv2.lin_l.weight"].shape == (512, 512) and sd["conv1.att"].shape == (1, 4, 128)
+    sd = no.init_weights("dgn_r")
+    assert sum(v.numel() for v in sd.values()) == 1660675          # incl. the unused lin_skip
+    assert sd["conv2.lin_key.weight"].shape == (512, 512) and "conv1.att" not in sd
     sd = no.init_weights("hl_dgn")
     assert sum(v.numel() for v in sd.values()) == 315139
     assert "conv2.att" not in sd and sd["Q.model.0.weight"].shape == (128, 512)
