@@ -297,6 +297,26 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
                         const int32_t* env_ids, int64_t n, const mel_env_obs* out,
                         const int32_t* episode_table, int32_t table_stride, void* stream);
 
+/* Device-resident replay of the round-batched loop (the counterpart of the per-(env, agent) sub-buffers the
+ * reference collector routes transitions into, multi_agent_collector.py:229-271).  A round of env b is ONE
+ * record: the obs_matrix its agents decided on, who acted, their actions, the rewards GraphEnv.rewards holds
+ * after the round's world step (graph.py:373-389), who was terminated by it (graph.py:330-334) and the
+ * obs_matrix every one of them observes next - i.e. the transition (obs, act, rew, done, obs_next) of each
+ * acting agent i is (obs|i, act[i], rew[i], done bit i, obs_next|i).  Records of an env are consecutive ring
+ * slots, so n-step returns follow an agent by walking slots while it keeps acting. */
+typedef struct mel_round_replay {
+    int32_t   capacity;        /* K ring slots per env                                            */
+    int32_t   reserved;
+    float*    obs;             /* [B, K, 8N]                                                      */
+    float*    obs_next;        /* [B, K, 8N]                                                      */
+    uint64_t* acted;           /* [B, K]                                                          */
+    uint64_t* done;            /* [B, K]                                                          */
+    int8_t*   act;             /* [B, K, N]                                                       */
+    float*    rew;             /* [B, K, N]                                                       */
+    int32_t*  episode;         /* [B, K] episode ordinal of the env when the round was played     */
+    int32_t*  cursor;          /* [B]    rounds recorded so far (slot = cursor % K)               */
+} mel_round_replay;
+
 /* One whole env ROUND per launch for every env of the batch (round-batched loop): replays, in the
  * reference's AEC order, the dead-agent steps and one GraphEnv.step per active agent with that agent's
  * action until the world step fires or the episode ends (then the env is reset to
@@ -306,10 +326,12 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
  *   row_offsets device int32 [B+1], first action row of each env (from mel_ldgn_forward_agents)
  *   live        device uint64 [B]; in: the active sets the actions belong to, out: the next round's
  *   first != 0  only publishes the current active sets (call once after mel_env_reset).
- *   round_counter (optional, device uint32): incremented once per call. */
+ *   round_counter (optional, device uint32): incremented once per call.
+ *   replay (optional): every env that had acting agents appends one record (see mel_round_replay). */
 mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
                          const int32_t* row_offsets, uint64_t* live, const int32_t* episode_table,
-                         int32_t table_stride, int32_t first, uint32_t* round_counter, void* stream);
+                         int32_t table_stride, int32_t first, uint32_t* round_counter,
+                         const mel_round_replay* replay, void* stream);
 
 /* last() only (mutates is_new_round exactly like GraphEnv.observe, graph.py:205-211). */
 mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n,

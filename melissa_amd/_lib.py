@@ -54,6 +54,12 @@ class MelSelect(C.Structure):
     _fields_ = [("act", C.c_void_p), ("eps", C.c_float), ("seed", C.c_uint32), ("step_dev", C.c_void_p)]
 
 
+class MelRoundReplay(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("reserved", C.c_int32), ("obs", C.c_void_p), ("obs_next", C.c_void_p),
+                ("acted", C.c_void_p), ("done", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p),
+                ("episode", C.c_void_p), ("cursor", C.c_void_p)]
+
+
 class MelEnvBatch(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("n_nodes", C.c_int32), ("dynamic_graph", C.c_int32),
                 ("has_local_ratio", C.c_int32), ("local_ratio", C.c_double),
@@ -140,7 +146,7 @@ def load(build_if_missing: bool = True):
     lib.mel_env_step.restype = i32
     lib.mel_env_step.argtypes = [E, P, vp, vp, i64, O, vp, i32, vp]
     lib.mel_env_round.restype = i32
-    lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MelRoundReplay), vp]
     lib.mel_env_observe.restype = i32
     lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
     lib.mel_prof_create.restype = vp

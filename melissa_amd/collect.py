@@ -94,10 +94,11 @@ class RoundLoop:
 
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
                  eps: float = 0.0, episodes=None, rows_cap: int | None = None, use_graph: bool = False,
-                 stream: "torch.cuda.Stream | None" = None):
+                 stream: "torch.cuda.Stream | None" = None, replay=None):
         self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
         self.use_graph, self.graph = use_graph, None
         self.stream = stream                       # None: torch's current stream
+        self.replay = replay                       # optional melissa_amd.replay.RoundReplay
         dev = venv.device
         packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
         self.pool = venv.load_pool(packed)
@@ -129,7 +130,8 @@ class RoundLoop:
         # forward + fused argmax / eps-greedy (the dueling tail writes the action next to the logits)
         net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets,
                                select=self._select, workspace=self.workspace)
-        self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds)
+        self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds,
+                               replay=self.replay)
 
     def step(self):
         if self.stream is not None:

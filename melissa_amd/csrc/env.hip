@@ -173,8 +173,9 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
     s.cover = __popcll(s.two_hop & (s.has_msg | s.origin_set));
 }
 
-// graph.py:254-271
-__device__ __forceinline__ void write_obs_matrix(const mel_env_batch& e, int b, const Env& s, int lane) {
+// graph.py:254-271 (copy: optional second destination, the replay's obs_next slot)
+__device__ __forceinline__ void write_obs_matrix(const mel_env_batch& e, int b, const Env& s, int lane,
+                                                 float* copy = nullptr) {
     if (lane >= e.n_nodes) return;
     float4* row = reinterpret_cast<float4*>(e.obs_matrix + ((size_t)b * e.n_nodes + lane) * 8);
     const float act = (s.act != NONE) ? (float)s.act : 0.f;
@@ -183,6 +184,11 @@ __device__ __forceinline__ void write_obs_matrix(const mel_env_batch& e, int b, 
     const float dm = ((s.scripted >> lane) & 1ull) ? 0.f : 1.f;
     row[0] = make_float4((float)s.px, (float)s.py, (float)__popcll(s.one_hop), (float)s.msgs);
     row[1] = make_float4(act, interested, has, dm);
+    if (copy) {
+        float4* c = reinterpret_cast<float4*>(copy + (size_t)lane * 8);
+        c[0] = row[0];
+        c[1] = row[1];
+    }
 }
 
 // graph.py:402-463, float64, same operation order
@@ -229,13 +235,15 @@ __device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, 
 }
 
 // GraphEnv.step graph.py:303-359 (+ the sticky reward copy of [3P] PettingZooEnv.step)
-__device__ __forceinline__ void env_step(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
-                                         int action, int lane) {
+// returns true when this step completed the round and ran the world step
+__device__ __forceinline__ bool env_step(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
+                                         int action, int lane, float* obs_next_copy = nullptr) {
     const int n = e.n_nodes;
     const int a = s.sel;
+    bool world = false;
     if (a < 0) {                      // reference would raise KeyError; flag it and stay put
         s.error |= 2;
-        return;
+        return false;
     }
     if ((s.terminated >> a) & 1ull) {                                   // :304-310 dead step
         s.sel_active &= ~bit(a);
@@ -259,10 +267,11 @@ __device__ __forceinline__ void env_step(const mel_env_batch& e, const mel_episo
         }
         s.sel = selector_next(s, lane);                                 // :321
         if (s.sel == NONE) {                                            // :324 round complete
+            world = true;
             if ((s.alive >> lane) & 1ull) s.reward = 0.0;               // _clear_rewards
             s.act = s.cur_act;                                          // :362-365
             world_step(e, pool, s, lane);
-            write_obs_matrix(e, b, s, lane);                            // :370-371
+            write_obs_matrix(e, b, s, lane, obs_next_copy);             // :370-371
             const double r0 = agent_reward(s);
             double r = r0;
             if (e.has_local_ratio) r = 0.0 * (1.0 - e.local_ratio) + r0 * e.local_ratio;   // :380-384
@@ -295,6 +304,7 @@ __device__ __forceinline__ void env_step(const mel_env_batch& e, const mel_episo
         }
     }
     if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;               // PettingZooEnv.step (A.6)
+    return world;
 }
 
 // GraphEnv.reset + World.reset, graph.py:222-248 / core.py:343-437, from a pre-sampled pool episode
@@ -399,6 +409,7 @@ struct RoundArgs {
     int table_stride;
     int first;                     // 1: only publish the active set (no step) - used right after a reset
     uint32_t* round_counter;       // optional: rounds played (device), drives the device-side RNG step
+    mel_round_replay replay;       // optional (capacity 0 = off)
 };
 
 __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
@@ -415,6 +426,23 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
         const int base = uniform_i32(a.row_offsets[b]);
         // every agent's action in one coalesced load (lane = agent), read back with v_readlane
         const int my_action = ((live_in >> lane) & 1ull) ? a.actions[base + rank_below(live_in, lane)] : 0;
+        // replay record of this round (only envs with acting agents): pre-state now, outcome after the world step
+        float* rec_next = nullptr;
+        size_t rec = 0;
+        if (a.replay.capacity > 0 && live_in) {
+            const int cur = uniform_i32(a.replay.cursor[b]);
+            rec = (size_t)b * a.replay.capacity + (cur % a.replay.capacity);
+            const float* src = a.env.obs_matrix + (size_t)b * n * 8;
+            float* dst = a.replay.obs + rec * n * 8;
+            for (int c = lane; c < n * 8; c += 64) dst[c] = src[c];
+            if (lane < n) a.replay.act[rec * n + lane] = (int8_t)my_action;
+            if (lane == 0) {
+                a.replay.acted[rec] = live_in;
+                a.replay.episode[rec] = s.ep_cursor;
+                a.replay.cursor[b] = cur + 1;
+            }
+            rec_next = a.replay.obs_next + rec * n * 8;
+        }
         for (int it = 0; it < 3 * n + 4; ++it) {
             const int sel = s.sel;
             if (sel < 0) {
@@ -429,8 +457,12 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
                 }
                 action = lane_i32(my_action, sel);
             }
-            env_step(a.env, a.pool, b, s, action, lane);
+            const bool world = env_step(a.env, a.pool, b, s, action, lane, rec_next);
             const int r = env_observe(a.env, b, s, none, 0, lane);
+            if (world && rec_next) {          // the world step just ran: rewards / terminations of this round
+                if (lane < n) a.replay.rew[rec * n + lane] = ((live_in >> lane) & 1ull) ? (float)s.reward : 0.f;
+                if (lane == 0) a.replay.done[rec] = s.terminated & live_in;
+            }
             if (r & 1) s.done_count += 1;
             if ((r & 1) && ((r & 2) || s.done_count == n)) {                  // episode over
                 s.episodes_done += 1;
@@ -603,7 +635,8 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
 
 mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const int32_t* actions,
                          const int32_t* row_offsets, uint64_t* live, const int32_t* episode_table,
-                         int32_t table_stride, int32_t first, uint32_t* round_counter, void* stream) {
+                         int32_t table_stride, int32_t first, uint32_t* round_counter,
+                         const mel_round_replay* replay, void* stream) {
     if (mel_status st = check_env(env, env->n_envs)) return st;
     if (mel_status st = check_pool(env, pool)) return st;
     if (!live) return fail(MEL_ERR_INVALID_ARG, "live mask buffer is null");
@@ -613,6 +646,12 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     RoundArgs a{};
     a.env = *env, a.pool = *pool, a.actions = actions, a.row_offsets = row_offsets, a.live = live;
     a.episode_table = episode_table, a.table_stride = table_stride, a.first = first, a.round_counter = round_counter;
+    if (replay) {
+        if (replay->capacity < 1 || !replay->obs || !replay->obs_next || !replay->acted || !replay->done ||
+            !replay->act || !replay->rew || !replay->episode || !replay->cursor)
+            return fail(MEL_ERR_INVALID_ARG, "incomplete replay block");
+        a.replay = *replay;
+    }
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_round");

@@ -266,7 +266,7 @@ class HipGraphVectorEnv:
 
     def round_device(self, pool: DevicePool, actions: torch.Tensor | None, row_offsets: torch.Tensor | None,
                      live: torch.Tensor, episode_table: torch.Tensor | None, first: bool = False,
-                     round_counter: torch.Tensor | None = None):
+                     round_counter: torch.Tensor | None = None, replay=None):
         """One whole env round for every env (mel_env_round).  ``live`` int64 [B] is read (the active sets the
         actions were computed for) and overwritten with the next round's active sets."""
         _lib.check(self.lib.mel_env_round(
@@ -274,7 +274,8 @@ class HipGraphVectorEnv:
             row_offsets.data_ptr() if row_offsets is not None else None, live.data_ptr(),
             episode_table.data_ptr() if episode_table is not None else None,
             episode_table.shape[1] if episode_table is not None else 0, int(first),
-            round_counter.data_ptr() if round_counter is not None else None, self._stream()), "mel_env_round")
+            round_counter.data_ptr() if round_counter is not None else None,
+            C.byref(replay.struct) if replay is not None else None, self._stream()), "mel_env_round")
 
     def step_device(self, pool: DevicePool, actions: torch.Tensor, out: ObsBuffers | None,
                     episode_table: torch.Tensor | None = None):

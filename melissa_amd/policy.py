@@ -117,13 +117,14 @@ class DQNPolicy(nn.Module):
         if self._target and self._iter % self._freq == 0:
             self.sync_weight()
         self.optim.zero_grad()
-        logits, _ = self.model(batch["obs"])
-        act = torch.as_tensor(batch["act"], device=logits.device, dtype=torch.long)
-        q = logits[torch.arange(len(act), device=logits.device), act]
-        returns = torch.as_tensor(batch["returns"], device=logits.device, dtype=q.dtype).flatten()
-        td = returns - q
-        loss = torch.nn.functional.huber_loss(q, returns) if self._clip_loss_grad else td.pow(2).mean()
-        loss.backward()
+        with torch.enable_grad():
+            logits, _ = self.model(batch["obs"])
+            act = torch.as_tensor(batch["act"], device=logits.device, dtype=torch.long)
+            q = logits[torch.arange(len(act), device=logits.device), act]
+            returns = torch.as_tensor(batch["returns"], device=logits.device, dtype=q.dtype).flatten()
+            td = returns - q
+            loss = torch.nn.functional.huber_loss(q, returns) if self._clip_loss_grad else td.pow(2).mean()
+            loss.backward()
         if grad_hook is not None:
             grad_hook(self.model)
         self.optim.step()

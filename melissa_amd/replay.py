@@ -1,0 +1,116 @@
+"""Device-resident replay for the round-batched loop + n-step return sampling.
+
+Reference: the collectors route each agent's transition into one of ``num_envs x num_agents`` Tianshou
+sub-buffers, waiting for the agent's next observation before the record is complete
+(multi_agent_collector.py:229-271); ``DQNPolicy.process_fn`` then builds n-step returns
+(``estimation_step`` = 4, common.py:28).  In the round-batched loop a whole env round is ONE record
+(``mel_round_replay`` in include/melissa_hip.h) written by ``mel_env_round``: all of the round's agents share
+``obs`` / ``obs_next`` (they observe the same obs_matrix, graph.py:186-188), so a transition is
+``(record, agent)`` and an agent's trajectory is the run of consecutive records of its env in which it acts.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class RoundReplay:
+    def __init__(self, n_envs: int, n_nodes: int, capacity: int, device):
+        self.B, self.n, self.K = n_envs, n_nodes, capacity
+        dev = torch.device(device)
+        self.obs = torch.zeros(n_envs, capacity, 8 * n_nodes, dtype=torch.float32, device=dev)
+        self.obs_next = torch.zeros_like(self.obs)
+        self.acted = torch.zeros(n_envs, capacity, dtype=torch.int64, device=dev)
+        self.done = torch.zeros(n_envs, capacity, dtype=torch.int64, device=dev)
+        self.act = torch.zeros(n_envs, capacity, n_nodes, dtype=torch.int8, device=dev)
+        self.rew = torch.zeros(n_envs, capacity, n_nodes, dtype=torch.float32, device=dev)
+        self.episode = torch.full((n_envs, capacity), -1, dtype=torch.int32, device=dev)
+        self.cursor = torch.zeros(n_envs, dtype=torch.int32, device=dev)
+        s = _lib.MelRoundReplay()
+        s.capacity = capacity
+        s.obs, s.obs_next = self.obs.data_ptr(), self.obs_next.data_ptr()
+        s.acted, s.done, s.act = self.acted.data_ptr(), self.done.data_ptr(), self.act.data_ptr()
+        s.rew, s.episode, s.cursor = self.rew.data_ptr(), self.episode.data_ptr(), self.cursor.data_ptr()
+        self.struct = s
+        self._bits = (torch.ones(1, dtype=torch.int64, device=dev) << torch.arange(n_nodes, device=dev))
+
+    def __len__(self) -> int:
+        """Transitions currently held (synchronises)."""
+        valid = self._valid_slots()
+        return int(self._popcount(self.acted[valid]).sum())
+
+    def _popcount(self, m: torch.Tensor) -> torch.Tensor:
+        return ((m[..., None] & self._bits) != 0).sum(-1)
+
+    def _valid_slots(self) -> torch.Tensor:
+        filled = torch.clamp(self.cursor.long(), max=self.K)                       # [B]
+        return torch.arange(self.K, device=self.cursor.device)[None, :] < filled[:, None]
+
+    def sample(self, batch_size: int, n_step: int, gamma: float, generator: torch.Generator | None = None):
+        """Uniform over (record, acting agent) pairs.  Returns dict of device tensors:
+        obs [bs, 8N+1], act [bs], ret [bs] (discounted n-step reward sum), boot_obs [bs, 8N+1] (observation to
+        bootstrap from), boot_w [bs] (gamma^steps, 0 when the agent terminated inside the window)."""
+        dev = self.obs.device
+        valid = self._valid_slots()
+        # never start a chain in the slot about to be overwritten next
+        cnt = self._popcount(self.acted) * valid
+        flat = cnt.flatten().float()
+        idx = torch.multinomial(flat, batch_size, replacement=True, generator=generator)
+        e, k = idx // self.K, idx % self.K
+        mask = self.acted[e, k]
+        # pick the j-th acting agent uniformly
+        bits = (mask[:, None] & self._bits) != 0                                   # [bs, N]
+        u = torch.rand(batch_size, device=dev, generator=generator)
+        target = (u * bits.sum(1)).floor().long().clamp(max=self.n - 1)
+        order = torch.cumsum(bits.long(), dim=1) - 1
+        agent = ((order == target[:, None]) & bits).float().argmax(dim=1)
+        abit = self._bits[agent]
+        ret = torch.zeros(batch_size, device=dev)
+        boot_w = torch.ones(batch_size, device=dev)
+        alive = torch.ones(batch_size, dtype=torch.bool, device=dev)
+        boot_slot = k.clone()
+        ep0 = self.episode[e, k]
+        newest = (self.cursor[e].long() - 1) % self.K
+        kk = k.clone()
+        for j in range(n_step):
+            ok = alive & (self.episode[e, kk] == ep0) & ((self.acted[e, kk] & abit) != 0) & valid[e, kk]
+            ret = ret + torch.where(ok, (gamma ** j) * self.rew[e, kk, agent], torch.zeros((), device=dev))
+            boot_slot = torch.where(ok, kk, boot_slot)
+            boot_w = torch.where(ok, torch.full((), gamma ** (j + 1), device=dev), boot_w)
+            finished = ok & ((self.done[e, kk] & abit) != 0)
+            boot_w = torch.where(finished, torch.zeros((), device=dev), boot_w)
+            alive = ok & ~finished & (kk != newest)          # cannot walk past the newest record
+            kk = (kk + 1) % self.K
+        idx_col = agent.float()[:, None]
+        obs = torch.cat([self.obs[e, k], idx_col], dim=1)
+        boot_obs = torch.cat([self.obs_next[e, boot_slot], idx_col], dim=1)
+        return dict(obs=obs, act=self.act[e, k, agent].long(), ret=ret, boot_obs=boot_obs, boot_w=boot_w,
+                    env=e, slot=k, agent=agent)
+
+
+class DQNLearner:
+    """n-step DQN update over a :class:`RoundReplay` (the learn half of the reference's training loop,
+    l_dgn.py:246-261 -> [3P] DQNPolicy.process_fn / learn): target = ret + boot_w * max_a Q_target(boot_obs)
+    with the target network evaluated by the HIP forward, then one autograd step (``grad_hook`` = the flat
+    RCCL gradient all-reduce of melissa_amd.parallel)."""
+
+    def __init__(self, policy, replay: RoundReplay, batch_size: int = 32, n_step: int = 4, gamma: float = 0.99,
+                 grad_hook=None, seed: int = 0):
+        self.policy, self.replay = policy, replay
+        self.batch_size, self.n_step, self.gamma, self.grad_hook = batch_size, n_step, gamma, grad_hook
+        self.gen = torch.Generator(device=replay.obs.device)
+        self.gen.manual_seed(seed)
+
+    def step(self) -> dict:
+        b = self.replay.sample(self.batch_size, self.n_step, self.gamma, self.gen)
+        with torch.no_grad():
+            target_net = self.policy.model_old if getattr(self.policy, "_target", False) else self.policy.model
+            q_next = target_net.hip_forward(b["boot_obs"]) if b["boot_obs"].is_cuda else target_net.torch_forward(b["boot_obs"])
+            if self.policy._is_double:                      # double DQN: argmax from the online net
+                online = self.policy.model.hip_forward(b["boot_obs"]) if b["boot_obs"].is_cuda else self.policy.model.torch_forward(b["boot_obs"])
+                best = q_next.gather(1, online.argmax(dim=1, keepdim=True)).squeeze(1)
+            else:
+                best = q_next.max(dim=1).values
+            returns = b["ret"] + b["boot_w"] * best
+        return self.policy.learn(dict(obs=b["obs"], act=b["act"], returns=returns), grad_hook=self.grad_hook)

@@ -65,21 +65,29 @@ def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs, model):
 
 
 def oracle_round(pz, act_of_agent):
-    """Replay one env round on the oracle exactly like mel_env_round: dead steps, then each active agent."""
+    """Replay one env round on the oracle exactly like mel_env_round: dead steps, then each active agent.
+    Returns what the round's world step produced (None if no agent acted): obs_matrix, rewards, terminated."""
     n = pz.env.n
+    outcome = None
     for _ in range(3 * n + 4):
         env = pz.env
         sel = env.agent_selection
         dead = (env.terminated >> sel) & 1
+        moves = env.num_moves
         obs, rew, term, trunc, info = pz.step(0 if dead else int(act_of_agent[sel]))
+        if pz.env.num_moves != moves:
+            # the world step ran (environment_step stays False when the observation right after it raises
+            # explicit_reset, graph.py:205-211, so the move counter is the reliable signal)
+            outcome = dict(obs_next=pz.env.obs_matrix.copy(), rew=list(pz.env.rewards),
+                           terminated=pz.env.terminated)
         if term:
             pz.done_count += 1
             if info.get("explicit_reset") or pz.done_count == n:
                 pz.reset()
                 pz.done_count = 0
-                return
+                return outcome
         if info.get("environment_step"):
-            return
+            return outcome
     raise AssertionError("round did not terminate")
 
 
@@ -98,7 +106,9 @@ def test_round_loop_matches_oracle(n, dynamic):
     net, sd = make_ldgn(n)
     # episodes: the oracle env consumes two samplings while it is constructed, so the device starts at #1
     packed, table = sample_episode_table(venv, 14, seed)
-    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed,
+    from melissa_amd.replay import RoundReplay
+    replay = RoundReplay(B, n, 8, "cuda")
+    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed, replay=replay,
                      episodes=({k: v for k, v in packed.items()}, np.ascontiguousarray(table[:, 1:])))
     refs = []
     for b in range(B):
@@ -110,7 +120,7 @@ def test_round_loop_matches_oracle(n, dynamic):
         env.last()                                    # the observe after reset (clears is_new_round like the device)
         refs.append(pz)
     sets = lambda: venv.node_sets().cpu().numpy().view(np.uint64)
-    checked_rows = 0
+    checked_rows = recorded_rounds = 0
     for it in range(K):
         live = loop.live.cpu().numpy().view(np.uint64).copy()
         for b, pz in enumerate(refs):
@@ -128,10 +138,24 @@ def test_round_loop_matches_oracle(n, dynamic):
             want = no.ldgn_forward(sd, obs_rows, n).numpy()
             np.testing.assert_allclose(logits[:len(rows)], want, atol=TOL, rtol=0)
             checked_rows += len(rows)
+        cursor = replay.cursor.cpu().numpy()
         for b, pz in enumerate(refs):
             np.testing.assert_array_equal(mat[b].reshape(n, 8), pz.env.obs_matrix)
             acts = {a: act[offsets[b] + k] for k, a in enumerate(a for a in range(n) if (int(live[b]) >> a) & 1)}
-            oracle_round(pz, acts)
+            ep_before = pz.env_episode = getattr(pz, "env_episode", 0)
+            outcome = oracle_round(pz, acts)
+            if int(live[b]):                                   # the replay record of this round
+                slot = (int(cursor[b]) - 1) % replay.K
+                assert outcome is not None
+                np.testing.assert_array_equal(replay.obs[b, slot].cpu().numpy(), mat[b])
+                np.testing.assert_array_equal(replay.obs_next[b, slot].cpu().numpy(), outcome["obs_next"].reshape(-1))
+                assert int(replay.acted[b, slot].cpu().numpy().view(np.uint64)) == int(live[b])
+                assert int(replay.done[b, slot].cpu().numpy().view(np.uint64)) == outcome["terminated"] & int(live[b])
+                rec_act, rec_rew = replay.act[b, slot].cpu().numpy(), replay.rew[b, slot].cpu().numpy()
+                for a_id, a_val in acts.items():
+                    assert rec_act[a_id] == a_val
+                    assert rec_rew[a_id] == np.float32(outcome["rew"][a_id])
+                recorded_rounds += 1
         s = sets()
         sc = venv.scalars().cpu().numpy()
         pos = venv.positions().cpu().numpy()
@@ -144,7 +168,7 @@ def test_round_loop_matches_oracle(n, dynamic):
             np.testing.assert_array_equal(pos[b], e.pos)
             assert [int(x) for x in one_hop[b]] == e.adj
     c = loop.counters()
-    assert c["errors"] == 0 and c["episodes"] >= 3 and checked_rows > 100
+    assert c["errors"] == 0 and c["episodes"] >= 3 and checked_rows > 100 and recorded_rounds > 100
 
 
 def test_graph_replay_matches_eager_launches():
@@ -169,3 +193,51 @@ def test_graph_replay_matches_eager_launches():
     np.testing.assert_array_equal(finals[0][1], finals[1][1])
     np.testing.assert_array_equal(finals[0][2], finals[1][2])
     assert finals[0][3] == finals[1][3] and finals[0][3]["errors"] == 0 and finals[0][3]["episodes"] > 20
+
+
+def test_replay_sampling_and_dqn_learner():
+    """Collect with the round loop into the device replay, check the n-step sampler against a slow walk over
+    the records, then take a few DQN steps (target net through the HIP forward, autograd learn step)."""
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import LDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from melissa_amd.replay import DQNLearner, RoundReplay
+    n, B, K, n_step, gamma = 20, 32, 16, 4, 0.99
+    graphs = synthetic_graph_pool(n, 4, first_seed=5)
+    torch.manual_seed(0)
+    net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="auto")
+    policy = DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-3), estimation_step=n_step, target_update_freq=2)
+    venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
+                             construct_like_reference=False)
+    replay = RoundReplay(B, n, K, "cuda")
+    loop = RoundLoop(venv, policy, episodes_per_env=10, seed=3, eps=0.3, replay=replay)
+    with torch.no_grad():
+        loop.run(40)
+    torch.cuda.synchronize()
+    assert len(replay) > 500 and int(replay.cursor.min()) >= K
+    s = replay.sample(256, n_step, gamma, torch.Generator(device="cuda").manual_seed(1))
+    acted = replay.acted.cpu().numpy().view(np.uint64)
+    done = replay.done.cpu().numpy().view(np.uint64)
+    rew, epi, cur = replay.rew.cpu().numpy(), replay.episode.cpu().numpy(), replay.cursor.cpu().numpy()
+    for e, k, a, ret, bw, obs, act in zip(*(s[x].cpu().numpy() for x in ("env", "slot", "agent", "ret", "boot_w", "obs", "act"))):
+        assert (int(acted[e, k]) >> a) & 1 and obs[-1] == a and act == replay.act[e, k, a].item()
+        want, w, kk, newest = 0.0, 1.0, k, (cur[e] - 1) % K
+        for j in range(n_step):
+            if epi[e, kk] != epi[e, k] or not (int(acted[e, kk]) >> a) & 1:
+                break
+            want += gamma ** j * rew[e, kk, a]
+            w = gamma ** (j + 1)
+            if (int(done[e, kk]) >> a) & 1:
+                w = 0.0
+                break
+            if kk == newest:
+                break
+            kk = (kk + 1) % K
+        assert abs(ret - want) < 1e-5 and abs(bw - w) < 1e-6
+    learner = DQNLearner(policy, replay, batch_size=64, n_step=n_step, gamma=gamma, seed=2)
+    before = torch.cat([p.detach().flatten().clone() for p in net.parameters()])
+    losses = [learner.step()["loss"] for _ in range(5)]
+    after = torch.cat([p.detach().flatten() for p in net.parameters()])
+    assert all(np.isfinite(l) for l in losses) and not torch.equal(before, after)
+    assert any(k.startswith("model_old.") for k in policy.state_dict())
