@@ -60,6 +60,22 @@ static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipS
         hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
 }
 
+template <int WM, int WN, int TM, int TN>
+static void gemm_launch_glds(const GemmArgs* gs, int count, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    GemmBatch batch{};
+    batch.count = count;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        batch.start[i] = total;
+        const int tiles = ((gs[i].M + BM - 1) / BM) * (gs[i].N / BN);
+        total += (tiles + 7) & ~7;
+    }
+    batch.start[count] = total;
+    hipLaunchKernelGGL((gemm_f32_glds_kernel<WM, WN, TM, TN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
+}
+
 static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
     if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
         return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
@@ -78,6 +94,8 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
             case 4: gemm_launch_t<4, 2, 1, 2>(&g, 1, mode, stream); break;     // 128 x 128, 8 waves (32x64 each)
             case 5: gemm_launch_t<2, 2, 2, 1>(&g, 1, mode, stream); break;     // 128 x  64, 4 waves
             case 6: gemm_launch_t<2, 2, 1, 2>(&g, 1, mode, stream); break;     //  64 x 128, 4 waves
+            case 21: gemm_launch_glds<2, 2, 1, 1>(&g, 1, stream); break;               // LDS-DMA  64 x  64
+            case 22: gemm_launch_glds<2, 2, 2, 2>(&g, 1, stream); break;               // LDS-DMA 128 x 128
             case 11: gemm_launch_persistent<2, 2, 1, 1>(&g, 1, mode, stream); break;   // persistent  64 x  64
             case 12: gemm_launch_persistent<2, 2, 2, 2>(&g, 1, mode, stream); break;   // persistent 128 x 128
             default: return fail(MEL_ERR_INVALID_ARG, "unknown tile %d", force_tile);
