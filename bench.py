@@ -154,8 +154,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if args.model == "hl_dgn":
-        args.mode = "aec"
     net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph,
                                      args.streams)
     lib = _lib.load()
@@ -190,7 +188,7 @@ def main():
             ploop = loop
             if args.mode == "round":
                 ploop.use_graph = False
-        rows_cap = ploop.rows_cap if args.mode == "round" else 0
+        rows_cap = ploop.rows_cap if (args.mode == "round" and args.model != "hl_dgn") else 0
         torch.cuda.synchronize()
         prof = lib.mel_prof_create(args.steps * 16)
         totals = torch.zeros(args.steps, 3, dtype=torch.int32, device=device)

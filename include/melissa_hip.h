@@ -158,6 +158,13 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
 
+/* HL-DGN for the round-batched loop: logits depend only on the env (hl_dgn.py:108 pools over the graph and
+ * ignores the controlling index), so one row per env serves all of a round's agents.  obs: device fp32
+ * [bs, obs_stride], row b = obs_matrix of env b, obs_stride >= n_nodes*(in_dim+3), index column not read. */
+mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs,
+                                  int32_t n_nodes, int32_t obs_stride, float* logits, void* workspace,
+                                  size_t ws_bytes, void* stream);
+
 /* Debug/parity taps: copies of intermediates after a forward with the same workspace.
  * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
  *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),
@@ -184,6 +191,14 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
 mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row, int64_t rows_cap,
                                   const int32_t* rows_dev, int32_t n_actions, float eps, uint32_t seed,
                                   uint32_t step, const uint32_t* step_dev, int32_t* act, void* stream);
+
+/* Per-(env, agent) action selection from per-env logits (HL-DGN in the round loop): for every agent i in
+ * live[b], act[b, i] = argmax(logits[b]) or, with probability eps, a uniformly random action (same
+ * counter-based stream as mel_select_action_rows, keyed on (seed, step + *step_dev, b*64 + i)).
+ * act: device int32 [bs, n_nodes] (dense layout accepted by mel_env_round when row_offsets is NULL). */
+mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int64_t bs, int32_t n_nodes,
+                                  int32_t n_actions, float eps, uint32_t seed, const uint32_t* step_dev,
+                                  int32_t* act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Environment half.  State of B independent envs lives in caller-owned device memory laid out as
@@ -323,7 +338,8 @@ typedef struct mel_round_replay {
  * episode_table[b, ep_cursor % table_stride]).  State after the call is identical to issuing the same
  * steps one at a time through mel_env_step.
  *   actions     device int32 [rows], one per (env, active agent), ordered by env then agent id
- *   row_offsets device int32 [B+1], first action row of each env (from mel_ldgn_forward_agents)
+ *   row_offsets device int32 [B+1], first action row of each env (from mel_ldgn_forward_agents); NULL =
+ *               actions is the dense layout [B, N] indexed by agent id (mel_select_action_envs)
  *   live        device uint64 [B]; in: the active sets the actions belong to, out: the next round's
  *   first != 0  only publishes the current active sets (call once after mel_env_reset).
  *   round_counter (optional, device uint32): incremented once per call.

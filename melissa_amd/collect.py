@@ -104,11 +104,14 @@ class RoundLoop:
         self.pool = venv.load_pool(packed)
         self.table = torch.from_numpy(table).to(dev)
         self.n_actions = policy.model.output_dim
-        self.rows_cap = int(rows_cap or venv.env_num * venv.n)
+        # HL-DGN's logits do not depend on the agent (hl_dgn.py:108): one row per env, dense action layout
+        self.per_env_logits = policy.model._MODEL == _lib.MODEL_HLDGN
+        self.rows_cap = venv.env_num if self.per_env_logits else int(rows_cap or venv.env_num * venv.n)
         self.live = torch.zeros(venv.env_num, dtype=torch.int64, device=dev)
         self.offsets = torch.zeros(venv.env_num + 1, dtype=torch.int32, device=dev)
         self.logits = torch.zeros(self.rows_cap, self.n_actions, dtype=torch.float32, device=dev)
-        self.act = torch.zeros(self.rows_cap, dtype=torch.int32, device=dev)
+        self.act = torch.zeros(venv.env_num * venv.n if self.per_env_logits else self.rows_cap, dtype=torch.int32,
+                               device=dev)
         self.iterations = 0
         self.rounds = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side round counter (RNG step)
         self._select = _lib.MelSelect()
@@ -127,6 +130,15 @@ class RoundLoop:
         lib = _lib.load()
         net = self.policy.model
         dev = self.venv.device
+        if self.per_env_logits:
+            net.hip_forward_envs(self._obs_matrix, out=self.logits, workspace=self.workspace)
+            _lib.check(lib.mel_select_action_envs(self.logits.data_ptr(), self.live.data_ptr(), self.venv.env_num,
+                                                  self.venv.n, self.n_actions, float(self.eps),
+                                                  self.seed & 0xFFFFFFFF, self.rounds.data_ptr(), self.act.data_ptr(),
+                                                  _lib.current_stream_ptr(dev)), "mel_select_action_envs")
+            self.venv.round_device(self.pool, self.act, None, self.live, self.table, round_counter=self.rounds,
+                                   replay=self.replay)
+            return
         # forward + fused argmax / eps-greedy (the dueling tail writes the action next to the logits)
         net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets,
                                select=self._select, workspace=self.workspace)

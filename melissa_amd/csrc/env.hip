@@ -423,9 +423,12 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     const mel_env_obs none{};
     if (!a.first) {
         const uint64_t live_in = uniform_u64(a.live[b]);
-        const int base = uniform_i32(a.row_offsets[b]);
-        // every agent's action in one coalesced load (lane = agent), read back with v_readlane
-        const int my_action = ((live_in >> lane) & 1ull) ? a.actions[base + rank_below(live_in, lane)] : 0;
+        // every agent's action in one coalesced load (lane = agent), read back with v_readlane; actions are
+        // either packed rows (row_offsets) or the dense [B, N] layout
+        int my_action = 0;
+        if ((live_in >> lane) & 1ull)
+            my_action = a.row_offsets ? a.actions[uniform_i32(a.row_offsets[b]) + rank_below(live_in, lane)]
+                                      : a.actions[(size_t)b * n + lane];
         // replay record of this round (only envs with acting agents): pre-state now, outcome after the world step
         float* rec_next = nullptr;
         size_t rec = 0;
@@ -640,8 +643,8 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     if (mel_status st = check_env(env, env->n_envs)) return st;
     if (mel_status st = check_pool(env, pool)) return st;
     if (!live) return fail(MEL_ERR_INVALID_ARG, "live mask buffer is null");
-    if (!first && (!actions || !row_offsets || !episode_table || table_stride < 1))
-        return fail(MEL_ERR_INVALID_ARG, "round step needs actions, row offsets and an episode table");
+    if (!first && (!actions || !episode_table || table_stride < 1))
+        return fail(MEL_ERR_INVALID_ARG, "round step needs actions and an episode table");
     clear_stale_error();
     RoundArgs a{};
     a.env = *env, a.pool = *pool, a.actions = actions, a.row_offsets = row_offsets, a.live = live;

@@ -196,7 +196,9 @@ __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict
     if (lane < n) p.adj[(size_t)b * n + lane] = src;
     const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
     uint64_t live;
-    if (agent_mask) {
+    if (want_receptive < 0) {              // adjacency only: the row has no index column
+        return;
+    } else if (agent_mask) {
         live = agent_mask[b] & full;
     } else {                               // obs[:, -1].clamp(0, N-1).long()
         float gf = row[n * node_cols];
@@ -700,6 +702,34 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
     act[r] = best;
 }
 
+__global__ __launch_bounds__(256) void select_envs_kernel(const float* __restrict__ logits,
+                                                          const uint64_t* __restrict__ live, long bs, int n, int na,
+                                                          float eps, uint32_t seed, const uint32_t* __restrict__ step_dev,
+                                                          int32_t* __restrict__ act) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= bs * n) return;
+    const long b = t / n;
+    const int i = (int)(t - b * n);
+    if (!((live[b] >> i) & 1ull)) return;
+    const float* q = logits + b * na;
+    int best = 0;
+    float bv = -INFINITY;
+    for (int a = 0; a < na; ++a)
+        if (q[a] > bv) bv = q[a], best = a;
+    if (eps > 0.f) {
+        const uint32_t step = step_dev ? *step_dev : 0u;
+        const uint32_t base = mix32(seed ^ mix32(step * 0x9e3779b9U + (uint32_t)(b * 64 + i)));
+        if (u01(base) < eps) {
+            best = 0, bv = -1.f;
+            for (int a = 0; a < na; ++a) {
+                const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
+                if (u > bv) bv = u, best = a;
+            }
+        }
+    }
+    act[t] = best;
+}
+
 // ------------------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------------------
@@ -1040,9 +1070,10 @@ mel_status mel_dgnr_forward_agents(const mel_weights* w, const float* obs, int64
                              select, workspace, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
-mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
-                             int32_t obs_width, float* logits, void* workspace, size_t ws_bytes, void* stream) {
-    if (mel_status st = validate(w, MEL_MODEL_HLDGN, bs, n, obs_width, true)) return st;
+static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
+                                     int32_t obs_width, bool index_col, float* logits, void* workspace,
+                                     size_t ws_bytes, void* stream) {
+    if (mel_status st = validate(w, MEL_MODEL_HLDGN, bs, n, obs_width, index_col)) return st;
     if (aggregator < MEL_AGG_MAX || aggregator > MEL_AGG_ADD) return fail(MEL_ERR_INVALID_ARG, "aggregator %d", aggregator);
     if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
     const Dims d = make_dims(bs, n, bs, true);
@@ -1058,7 +1089,7 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
         StageScope t(MEL_STAGE_PLAN, s);
         // hl_dgn.py:108 pools over the whole graph: the controlling index is read (and clamped) but unused
         hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
-                           (const uint64_t*)nullptr, L.plan, 0);
+                           (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
         if (mel_status st = check_launch("plan_masks")) return st;
     }
     {
@@ -1090,6 +1121,16 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
     return run_heads(w, L, bs, nullptr, bs, logits, s);
+}
+
+mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
+                             int32_t obs_width, float* logits, void* workspace, size_t ws_bytes, void* stream) {
+    return hldgn_forward_impl(w, aggregator, obs, bs, n, obs_width, true, logits, workspace, ws_bytes, stream);
+}
+
+mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
+                                  int32_t obs_stride, float* logits, void* workspace, size_t ws_bytes, void* stream) {
+    return hldgn_forward_impl(w, aggregator, obs, bs, n, obs_stride, false, logits, workspace, ws_bytes, stream);
 }
 
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
@@ -1187,6 +1228,18 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
     hipLaunchKernelGGL(select_action_kernel, dim3((bs + 255) / 256), dim3(256), 0, s, logits, mask, (long)bs, na, eps,
                        rand_u, rand_q, static_cast<const float*>(scratch), act);
     return check_launch("select_action");
+}
+
+mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int64_t bs, int32_t n, int32_t na,
+                                  float eps, uint32_t seed, const uint32_t* step_dev, int32_t* act, void* stream) {
+    if (!logits || !live || !act || bs <= 0 || n < 1 || n > MEL_MAX_NODES || na < 1)
+        return fail(MEL_ERR_INVALID_ARG, "bad select_action_envs arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    clear_stale_error();
+    StageScope t(MEL_STAGE_SELECT, s);
+    hipLaunchKernelGGL(select_envs_kernel, dim3((bs * n + 255) / 256), dim3(256), 0, s, logits, live, (long)bs, n, na, eps,
+                       seed, step_dev, act);
+    return check_launch("select_action_envs");
 }
 
 mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row, int64_t rows_cap,

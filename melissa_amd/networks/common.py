@@ -219,7 +219,27 @@ class HipForwardMixin:
                                        _lib.current_stream_ptr(ws.device)), "mel_forward_tap")
         return out
 
+    def hip_forward_envs(self, obs_matrix: torch.Tensor, out: torch.Tensor | None = None,
+                         workspace: torch.Tensor | None = None) -> torch.Tensor:
+        """HL-DGN on env rows without an index column (round-batched loop): one logits row per env."""
+        if self._MODEL != _lib.MODEL_HLDGN:
+            raise RuntimeError("hip_forward_envs is the HL-DGN entry point")
+        lib = _lib.load()
+        assert obs_matrix.is_cuda and obs_matrix.dtype == torch.float32 and obs_matrix.stride(-1) == 1
+        bs = obs_matrix.shape[0]
+        w = self._weights()
+        ws = workspace if workspace is not None else self._workspace(w, bs, obs_matrix.device)
+        if out is None:
+            out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
+        st = lib.mel_hldgn_forward_envs(C.byref(w), _lib.AGG[self.aggregator_name], obs_matrix.data_ptr(), bs,
+                                        self.agents_num, obs_matrix.stride(0), out.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+        _lib.check(st, "mel_hldgn_forward_envs")
+        return out
+
     def agents_workspace_bytes(self, bs: int, rows_cap: int) -> int:
+        if self._MODEL == _lib.MODEL_HLDGN:
+            return int(_lib.load().mel_workspace_bytes(C.byref(self._weights()), bs, self.agents_num))
         return int(_lib.load().mel_workspace_bytes_agents(C.byref(self._weights()), bs, self.agents_num, rows_cap))
 
     def hip_forward_agents(self, obs_matrix: torch.Tensor, agent_mask: torch.Tensor, rows_cap: int,

@@ -241,3 +241,53 @@ def test_replay_sampling_and_dqn_learner():
     after = torch.cat([p.detach().flatten() for p in net.parameters()])
     assert all(np.isfinite(l) for l in losses) and not torch.equal(before, after)
     assert any(k.startswith("model_old.") for k in policy.state_dict())
+
+
+def test_hldgn_round_loop_matches_oracle():
+    """HL-DGN in the round loop: one logits row per env (hl_dgn.py:108 ignores the controlling index), dense
+    per-agent actions; env state after every round equals the oracle replaying the same actions."""
+    from melissa_amd import _lib as L
+    from melissa_amd.collect import RoundLoop, sample_episode_table
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import HLDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from oracle import env_oracle as eo
+    from oracle import net_oracle as no
+    n, B, seed, K = 20, 5, 41, 30
+    graphs = synthetic_graph_pool(n, 3, first_seed=50)
+    venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
+                             construct_like_reference=False)
+    sd = no.init_weights("hl_dgn", seed=9, random_conv_bias=True)
+    net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    packed, table = sample_episode_table(venv, 12, seed)
+    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed,
+                     episodes=(packed, np.ascontiguousarray(table[:, 1:])))
+    refs = []
+    for b in range(B):
+        env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in graphs],
+                                dynamic_graph=True,
+                                np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))))
+        pz = eo.OraclePettingZooEnv.__new__(eo.OraclePettingZooEnv)
+        pz.env, pz.n, pz.rewards, pz.done_count = env, n, [0] * n, 0
+        env.last()
+        refs.append(pz)
+    for it in range(K):
+        live = loop.live.cpu().numpy().view(np.uint64).copy()
+        mat = venv.obs_matrix().cpu().numpy().copy()
+        loop.step()
+        torch.cuda.synchronize()
+        logits = loop.logits.cpu().numpy()
+        act = loop.act.cpu().numpy().reshape(B, n)
+        obs_rows = np.concatenate([mat, np.zeros((B, 1), np.float32)], axis=1)
+        want = no.hldgn_forward(sd, obs_rows, n, aggregator="max").numpy()
+        np.testing.assert_allclose(logits, want, atol=TOL, rtol=0)
+        for b, pz in enumerate(refs):
+            acts = {a: act[b, a] for a in range(n) if (int(live[b]) >> a) & 1}
+            assert all(v == int(np.argmax(logits[b])) for v in acts.values())
+            oracle_round(pz, acts)
+        s = venv.node_sets().cpu().numpy().view(np.uint64)
+        for b, pz in enumerate(refs):
+            assert int(s[b, L.SET_HAS_MESSAGE]) == pz.env.has_message and int(s[b, L.SET_AGENTS]) == pz.env.agents
+            np.testing.assert_array_equal(venv.positions()[b].cpu().numpy(), pz.env.pos)
+    assert loop.counters()["errors"] == 0
