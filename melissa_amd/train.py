@@ -1,0 +1,94 @@
+"""Data-parallel DQN training over env shards: the distributed counterpart of ``train_agent``
+(l_dgn.py:131-269 / hl_dgn.py / dgn_r.py: collect ``step_per_collect`` transitions, then
+``update_per_step`` gradient steps).
+
+One process per GPU (``python -m torch.distributed.run --nproc-per-node N -m melissa_amd.train ...``):
+every rank owns ``envs`` independent envs (no data-path collective: rank r steps and evaluates its own
+shard with the HIP kernels, device-resident replay), replicas start from rank 0's weights, and the ONE
+collective of the path is the flat-gradient all-reduce (RCCL over xGMI) between backward and the Adam step,
+so all replicas stay bit-identical.  Target-network sync, eps schedule and counters are replicated locally.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+
+import torch
+
+from . import parallel
+from .collect import RoundLoop
+from .env import HipGraphVectorEnv, synthetic_graph_pool
+from .networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
+from .policy import DQNPolicy
+from .replay import DQNLearner, RoundReplay
+
+
+def build_network(name: str, n_nodes: int, device, hidden=128, heads=4):
+    duel = ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})          # common.py:41-42
+    if name == "l_dgn":
+        return LDGNNetwork(5, hidden, 2, heads, n_nodes, dueling_param=duel, device=device)
+    if name == "hl_dgn":
+        return HLDGNNetwork(5, hidden, 2, heads, n_nodes, aggregator="max", dueling_param=duel, device=device)
+    if name == "dgn_r":
+        return DGNRNetwork(5, hidden, 2, heads, n_nodes, dueling_param=duel, device=device)
+    raise ValueError(name)
+
+
+def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4, batch_size=32, n_step=4,
+          gamma=0.99, lr=1e-3, target_update_freq=500, eps=0.1, replay_rounds=64, seed=9, backend=None, log=print):
+    rank, local_rank, world = parallel.init_distributed(backend)
+    device = torch.device("cuda", local_rank if backend != "gloo" else 0)
+    torch.cuda.set_device(device)
+    torch.manual_seed(seed)                                    # same init everywhere, then broadcast anyway
+    net = build_network(model, n_nodes, device)
+    parallel.broadcast_parameters(net, src=0)
+    policy = DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=lr), discount_factor=gamma,
+                       estimation_step=n_step, target_update_freq=target_update_freq)
+    graphs = synthetic_graph_pool(n_nodes, 16, first_seed=0)
+    venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device, max_moves=48,
+                             seed=1000 + rank * envs, construct_like_reference=False)
+    replay = RoundReplay(envs, n_nodes, replay_rounds, device)
+    loop = RoundLoop(venv, policy, episodes_per_env=16, seed=1000 + rank * envs, eps=eps, replay=replay)
+    learner = DQNLearner(policy, replay, batch_size=batch_size, n_step=n_step, gamma=gamma,
+                         grad_hook=parallel.FlatGradAllReducer(net), seed=seed + rank)
+    with torch.no_grad():
+        loop.run(max(n_step + 1, 8))                           # pre-fill (l_dgn.py:201)
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(updates):
+        with torch.no_grad():
+            loop.run(rounds_per_update)
+        losses.append(learner.step()["loss"])
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    c = loop.counters()
+    checksum = float(torch.cat([p.detach().flatten() for p in net.parameters()]).double().sum())
+    out = dict(rank=rank, world=world, model=model, updates=updates, seconds=dt, loss_first=losses[0],
+               loss_last=losses[-1], decisions=c["decisions"], episodes=c["episodes"], errors=c["errors"],
+               param_checksum=checksum)
+    # replicas must be identical after averaged-gradient steps
+    same = parallel.all_reduce_max(checksum, device) == parallel.all_reduce_max(-checksum, device) * -1
+    out["replicas_identical"] = bool(same)
+    if rank == 0:
+        log(json.dumps(out))
+    parallel.barrier()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="hl_dgn", choices=["l_dgn", "hl_dgn", "dgn_r"])
+    ap.add_argument("--nodes", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=256, help="envs per GPU")
+    ap.add_argument("--updates", type=int, default=20)
+    ap.add_argument("--rounds-per-update", type=int, default=4)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--backend", default=None)
+    a = ap.parse_args()
+    train(model=a.model, n_nodes=a.nodes, envs=a.envs, updates=a.updates, rounds_per_update=a.rounds_per_update,
+          batch_size=a.batch_size, backend=a.backend)
+
+
+if __name__ == "__main__":
+    main()

@@ -291,3 +291,13 @@ def test_hldgn_round_loop_matches_oracle():
             assert int(s[b, L.SET_HAS_MESSAGE]) == pz.env.has_message and int(s[b, L.SET_AGENTS]) == pz.env.agents
             np.testing.assert_array_equal(venv.positions()[b].cpu().numpy(), pz.env.pos)
     assert loop.counters()["errors"] == 0
+
+
+@pytest.mark.parametrize("model", ["hl_dgn", "dgn_r"])
+def test_training_loop_single_rank(model):
+    """collect (HIP) -> device replay -> n-step targets (HIP target net) -> autograd step with the flat-gradient
+    hook, end to end on one rank (the N > 1 gradient averaging itself is covered on CPU with gloo)."""
+    from melissa_amd.train import train
+    out = train(model=model, n_nodes=12, envs=48, updates=4, rounds_per_update=3, batch_size=32, log=lambda *_: None)
+    assert out["errors"] == 0 and out["decisions"] > 200 and out["replicas_identical"]
+    assert np.isfinite(out["loss_first"]) and np.isfinite(out["loss_last"])
