@@ -105,7 +105,9 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     // Measured (tools/gemm_bench.py): the 64x64 tile (4x the workgroups, a quarter of the per-wave MFMA
     // chain, 4 workgroups per CU) wins or ties everywhere except long-K problems with thousands of tiles.
     const long big = ((m_hint + 127) / 128) * (g.N / 128);
-    if (g.N % 128 == 0 && big >= 1536 && g.K >= 512)
+    if (g.M_dev)
+        gemm_launch_persistent<2, 2, 1, 1>(&g, 1, mode, stream);
+    else if (g.N % 128 == 0 && big >= 1536 && g.K >= 512)
         gemm_launch_t<2, 2, 2, 2>(&g, 1, mode, stream);
     else
         gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream);
@@ -124,7 +126,11 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
         n128 = n128 && gs[i].N % 128 == 0;
         long_k = long_k && gs[i].K >= 512;
     }
-    if (n128 && long_k && big >= 1536)
+    bool ragged = false;
+    for (int i = 0; i < count; ++i) ragged = ragged || gs[i].M_dev != nullptr;
+    if (ragged)       // device-side row counts: a fixed grid walks the tiles instead of a worst-case grid exiting
+        gemm_launch_persistent<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
+    else if (n128 && long_k && big >= 1536)
         gemm_launch_t<2, 2, 2, 2>(gs, count, GEMM_MODE_PLAIN, stream);
     else
         gemm_launch_t<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
@@ -142,6 +148,16 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
 //   U2 = union over t in U1 of closed one-hop(t)  - their sources
 // Rows are packed per env in id order, so the packed position of node j is popcount(mask below j).
 // ------------------------------------------------------------------------------------------------
+// everything the attention kernel needs to know about one target row, in one 32-byte load
+struct TargetDesc {
+    uint64_t sources;   // source nodes of the target (closed neighbourhood for GATv2, open for TransformerConv)
+    uint64_t smask;     // node set the source rows are packed by
+    int32_t soff;       // first source row of the env
+    int32_t env;
+    int32_t node;
+    int32_t cat_row;    // conv1: agent row whose head input takes x_1 / x_2 from this target, or -1
+};
+
 struct PlanBuffers {
     uint64_t* adj;      // [bs*N] sources of target i (radius rule, self excluded)
     uint64_t* live;     // [bs]   L: controlling agents of the env
@@ -154,8 +170,8 @@ struct PlanBuffers {
     int32_t* nid2;      // [sum|U2|] global node id (b*N + i) of packed row
     int32_t* arow1;     // [sum|U1|] row of the U2 list holding the same node
     float* dm1;         // [sum|U1|] decision-maker flag of the node (l_dgn.py:128)
-    int32_t* t_env;     // [sum|U1|] env of conv1 target row
-    int32_t* t_node;    // [sum|U1|] node id of conv1 target row
+    TargetDesc* desc1;  // [sum|U1|] conv1 target rows
+    TargetDesc* desc2;  // [R]       conv2 target rows (one per agent row)
     int32_t* row_env;   // [R] env of agent row r
     int32_t* row_agent; // [R] agent (node id) of agent row r
     int32_t* arow_g;    // [R] row of the U1 list holding the agent
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) 
 
 __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
                                                          int obs_stride, int node_cols, PlanBuffers p,
-                                                         int32_t* __restrict__ row_offsets_out) {
+                                                         int32_t* __restrict__ row_offsets_out, int self_loops) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
@@ -271,15 +287,23 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict
         const int r1 = o1 + rank_below(u1, lane);
         p.arow1[r1] = o2 + rank_below(u2, lane);
         p.dm1[r1] = dm;
-        p.t_env[r1] = b;
-        p.t_node[r1] = lane;
     }
-    if ((live >> lane) & 1ull) {
-        const int r = oL + rank_below(live, lane);
-        p.row_env[r] = b;
-        p.row_agent[r] = lane;
-        p.arow_g[r] = o1 + rank_below(u1, lane);
-        p.dm_g[r] = dm;
+    const uint64_t mine = (lane < n) ? (p.adj[(size_t)b * n + lane] | (self_loops ? (1ull << lane) : 0ull)) : 0ull;
+    const bool is_agent = (live >> lane) & 1ull;
+    const int rL = oL + rank_below(live, lane);
+    if ((u1 >> lane) & 1ull) {
+        TargetDesc d;
+        d.sources = mine, d.smask = u2, d.soff = o2, d.env = b, d.node = lane, d.cat_row = is_agent ? rL : -1;
+        p.desc1[o1 + rank_below(u1, lane)] = d;
+    }
+    if (is_agent) {
+        p.row_env[rL] = b;
+        p.row_agent[rL] = lane;
+        p.arow_g[rL] = o1 + rank_below(u1, lane);
+        p.dm_g[rL] = dm;
+        TargetDesc d;
+        d.sources = mine, d.smask = u1, d.soff = o1, d.env = b, d.node = lane, d.cat_row = rL;
+        p.desc2[rL] = d;
     }
     if (row_offsets_out && lane == 0) {
         row_offsets_out[b] = oL;
@@ -323,9 +347,9 @@ struct AttArgs {
     int obs_stride, node_cols, aggregator;
     float* pooled;          // [bs, heads*C]
     // ATT_ROWS / ATT_SINGLE: one wavefront per target row
-    const int32_t* row_env;     // [rows] env of the row
-    const int32_t* row_agent;   // [rows] target node of the row
+    const TargetDesc* desc;     // [rows] per-target descriptor
     const int32_t* rows_dev;    // device-side row count
+    long rows_hint;             // expected rows (grid sizing only)
     int rows_cap, cat_off;
 };
 
@@ -377,7 +401,10 @@ __device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
 }
 
 // attention output of one target for this lane's VPL channels: relu(out + bias).  The source rows are
-// streamed once (online softmax); the next row's load is issued before the current row is consumed.
+// streamed once with an online softmax, FOUR sources per step: their row loads, score dot products and
+// per-head reductions are independent chains (the single-source form is one long dependent chain per source
+// and the launch is latency bound), then one rescale per step:
+//   m' = max(m, s_0..s_3); l = l e^(m-m') + sum_k e^(s_k-m'); acc = acc e^(m-m') + sum_k e^(s_k-m') row_k
 // KIND = MEL_CONV_GATV2:       e = att . leaky_relu(x_r[i] + x_l[j]),          out = sum alpha x_l[j]
 // KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
 template <int VPL, int KIND>
@@ -385,53 +412,66 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
                                                   uint64_t smask, int soff, const Vec<VPL>& att,
                                                   const Vec<VPL>& bias, int lane) {
     constexpr int HC = 64 * VPL;
+    constexpr int G = 4;
     const Vec<VPL> xr = load_vec<VPL>(xr_row + lane * VPL);
     float m = -INFINITY, l = 0.f;
     Vec<VPL> acc;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    if (sources) {                               // TransformerConv adds no self-loop: a target may be isolated
-        const float* base = a.xl + lane * VPL;
-        int j = lowest_bit(sources);
-        sources &= sources - 1;
-        const float* row = base + (size_t)(soff + rank_below(smask, j)) * a.ld_l;
-        Vec<VPL> nxt = load_vec<VPL>(row), nxt_v;
-        if constexpr (KIND == MEL_CONV_TRANSFORMER) nxt_v = load_vec<VPL>(row + HC);
-        for (;;) {
-            const Vec<VPL> xl = nxt;
-            Vec<VPL> xv;
-            if constexpr (KIND == MEL_CONV_TRANSFORMER) xv = nxt_v;
-            const bool more = sources != 0;
-            if (more) {
-                j = lowest_bit(sources);
-                sources &= sources - 1;
-                row = base + (size_t)(soff + rank_below(smask, j)) * a.ld_l;
-                nxt = load_vec<VPL>(row);
-                if constexpr (KIND == MEL_CONV_TRANSFORMER) nxt_v = load_vec<VPL>(row + HC);
-            }
-            float s = 0.f;
+    const float* base = a.xl + lane * VPL;
+    while (sources) {                            // TransformerConv adds no self-loop: a target may be isolated
+        const float* row[G];
+        bool on[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            on[k] = sources != 0;
+            const int j = on[k] ? lowest_bit(sources) : 0;
+            sources &= sources - 1;              // 0 stays 0
+            row[k] = base + (size_t)(soff + (on[k] ? rank_below(smask, j) : 0)) * a.ld_l;    // off slots re-read a valid row
+        }
+        Vec<VPL> xl[G], xv[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            xl[k] = load_vec<VPL>(row[k]);
+            if constexpr (KIND == MEL_CONV_TRANSFORMER) xv[k] = load_vec<VPL>(row[k] + HC);
+        }
+        float sc_[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            float t = 0.f;
             if constexpr (KIND == MEL_CONV_GATV2) {
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) {
-                    float z = xr.v[i] + xl.v[i];
+                    float z = xr.v[i] + xl[k].v[i];
                     z = z > 0.f ? z : 0.2f * z;          // leaky_relu(negative_slope=0.2)
-                    s = fmaf(att.v[i], z, s);
+                    t = fmaf(att.v[i], z, t);
                 }
-                s = head_sum(s, a.lanes_per_head);
             } else {
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) s = fmaf(xr.v[i], xl.v[i], s);
-                s = head_sum(s, a.lanes_per_head) * a.score_scale;
+                for (int i = 0; i < VPL; ++i) t = fmaf(xr.v[i], xl[k].v[i], t);
             }
-            const float mn = fmaxf(m, s);
-            const float sc = expf(m - mn), pe = expf(s - mn);
-            l = l * sc + pe;
-#pragma unroll
-            for (int i = 0; i < VPL; ++i)
-                acc.v[i] = acc.v[i] * sc + pe * (KIND == MEL_CONV_TRANSFORMER ? xv.v[i] : xl.v[i]);
-            m = mn;
-            if (!more) break;
+            sc_[k] = t;
         }
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            sc_[k] = head_sum(sc_[k], a.lanes_per_head);
+            if constexpr (KIND == MEL_CONV_TRANSFORMER) sc_[k] *= a.score_scale;
+            if (!on[k]) sc_[k] = -INFINITY;
+        }
+        const float mn = fmaxf(fmaxf(m, fmaxf(sc_[0], sc_[1])), fmaxf(sc_[2], sc_[3]));
+        const float rs = expf(m - mn);           // slot 0 is always on, so mn is finite
+        float pe[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) pe[k] = expf(sc_[k] - mn);       // exp(-inf) = 0 for the off slots
+        l = l * rs + ((pe[0] + pe[1]) + (pe[2] + pe[3]));
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float t = acc.v[i] * rs;
+#pragma unroll
+            for (int k = 0; k < G; ++k) t = fmaf(pe[k], (KIND == MEL_CONV_TRANSFORMER ? xv[k].v[i] : xl[k].v[i]), t);
+            acc.v[i] = t;
+        }
+        m = mn;
     }
     const float inv = 1.f / (l + 1e-16f);
     Vec<VPL> out;
@@ -457,28 +497,27 @@ __device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
 template <int VPL, int MODE, int KIND>
 __global__ __launch_bounds__(256) void gat_attend_rows_kernel(AttArgs a) {
     const int lane = lane_id();
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= a.rows_cap || r >= *a.rows_dev) return;
+    const int rows = min(*a.rows_dev, a.rows_cap);
     const Vec<VPL> att = load_vec_or_zero<VPL>(a.att, lane);
     const Vec<VPL> bias = load_vec_or_zero<VPL>(a.bias, lane);
-    const int b = a.row_env[r], t = a.row_agent[r];
-    uint64_t sources = a.adj[(size_t)b * a.n + t];
-    if (KIND == MEL_CONV_GATV2) sources |= 1ull << t;              // GATv2Conv adds self-loops
-    const uint64_t smask = a.smask[b];
-    const int soff = a.soff[b];
-    const Vec<VPL> o = attend_target<VPL, KIND>(a, a.xr + (size_t)r * a.ld_r, sources, smask, soff, att, bias, lane);
-    if constexpr (MODE == ATT_SINGLE) {
-        store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
-    } else {
-        store_vec<VPL>(a.out + (size_t)r * a.ldo + lane * VPL, o);
-        const uint64_t live = a.live[b];
-        if ((live >> t) & 1ull) {
-            float* cat = a.xcat + (size_t)(a.loff[b] + rank_below(live, t)) * a.ld_cat;
-            // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
-            store_vec<VPL>(cat + a.hidden + lane * VPL, o);
-            // x_1: its encoder row (l_dgn.py:122)
-            const float* h0 = a.h0 + (size_t)(soff + rank_below(smask, t)) * a.hidden;
-            for (int c = lane; c < a.hidden; c += 64) cat[c] = h0[c];
+    // grid-stride over the target rows: the grid is sized from the expected row count, not the worst case
+    // (a surplus workgroup costs a global-load latency and a CU slot before it can exit)
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        const TargetDesc d = a.desc[r];          // one 32-byte record: no chain of dependent index loads
+        const Vec<VPL> o = attend_target<VPL, KIND>(a, a.xr + (size_t)r * a.ld_r, d.sources, d.smask, d.soff, att,
+                                                    bias, lane);
+        if constexpr (MODE == ATT_SINGLE) {
+            store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
+        } else {
+            store_vec<VPL>(a.out + (size_t)r * a.ldo + lane * VPL, o);
+            if (d.cat_row >= 0) {
+                float* cat = a.xcat + (size_t)d.cat_row * a.ld_cat;
+                // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
+                store_vec<VPL>(cat + a.hidden + lane * VPL, o);
+                // x_1: its encoder row (l_dgn.py:122)
+                const float* h0 = a.h0 + (size_t)(d.soff + rank_below(d.smask, d.node)) * a.hidden;
+                for (int c = lane; c < a.hidden; c += 64) cat[c] = h0[c];
+            }
         }
     }
 }
@@ -536,7 +575,10 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
             default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
         }
     } else {
-        const int grid = (a.rows_cap + 3) / 4;
+        long want = ((a.rows_hint > 0 ? a.rows_hint : a.rows_cap) * 5 / 4 + 3) / 4;     // 25 % head-room, loop covers the rest
+        if (want > (a.rows_cap + 3) / 4) want = (a.rows_cap + 3) / 4;
+        if (want < 256) want = 256 < (a.rows_cap + 3) / 4 ? 256 : (a.rows_cap + 3) / 4;
+        const int grid = (int)want;
 #define MEL_ATT_LAUNCH(V)                                                                                      \
     if (a.kind == MEL_CONV_TRANSFORMER)                                                                        \
         hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); \
@@ -789,8 +831,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         L.plan.nid2 = c.take<int32_t>(d.u2_cap);
         L.plan.arow1 = c.take<int32_t>(d.u1_cap);
         L.plan.dm1 = c.take<float>(d.u1_cap);
-        L.plan.t_env = c.take<int32_t>(d.u1_cap);
-        L.plan.t_node = c.take<int32_t>(d.u1_cap);
+        L.plan.desc1 = c.take<TargetDesc>(d.u1_cap);
+        L.plan.desc2 = c.take<TargetDesc>(R);
         L.plan.row_env = c.take<int32_t>(R);
         L.plan.row_agent = c.take<int32_t>(R);
         L.plan.arow_g = c.take<int32_t>(R);
@@ -947,7 +989,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         if (mel_status st = check_launch("plan_masks")) return st;
         hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
         if (mel_status st = check_launch("plan_scan")) return st;
-        hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out);
+        hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out,
+                           tconv ? 0 : 1);
         if (mel_status st = check_launch("plan_lists")) return st;
     }
     {   // encoder on the U2 rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
@@ -979,7 +1022,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.kind = w->conv1.kind, a.score_scale = 1.0f / sqrtf((float)w->conv1.channels);
         a.adj = L.plan.adj, a.live = L.plan.live, a.smask = L.plan.u2;
         a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
-        a.row_env = L.plan.t_env, a.row_agent = L.plan.t_node, a.rows_dev = n1, a.rows_cap = U1;
+        a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
@@ -1005,7 +1048,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.kind = w->conv2.kind, a.score_scale = 1.0f / sqrtf((float)w->conv2.channels);
         a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
-        a.row_env = L.plan.row_env, a.row_agent = L.plan.row_agent, a.rows_dev = nL, a.rows_cap = R;
+        a.desc = L.plan.desc2, a.rows_dev = nL, a.rows_cap = R, a.rows_hint = hintL;
         a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
         StageScope t(MEL_STAGE_CONV2_ATT, s);
         if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
