@@ -120,7 +120,20 @@ def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
                 obs[k] = o
             iters += 1
     dt = time.perf_counter() - t0
+    # bs = 1 (the --watch configuration, BASELINE config 0): one env, a few seconds
+    one, obs1, d1 = workers[0], None, 0
+    obs1, _ = one.reset()
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t1 < 3.0:
+            a = no.dqn_act(no.ldgn_forward(sd, obs1["obs"][None], n_nodes), np.asarray(obs1["mask"])[None]).numpy()
+            d1 += int(bool(obs1["mask"][0]))
+            obs1, _r, term, _tr, info = one.step(int(a[0]))
+            if term and info.get("explicit_reset"):
+                obs1, _ = one.reset()
+    bs1 = d1 / (time.perf_counter() - t1)
     return {"value": decisions / dt, "unit": "agent-decisions/s", "cores": cores, "kind": "port",
+            "value_bs1": bs1,
             "sample": f"{iters} collector iterations over {envs} envs ({decisions} live decisions, {dt:.1f} s): "
                       f"oracle L-DGN forward (torch CPU fp32, {cores} threads) + Python env restatement, "
                       f"N={n_nodes}, dynamic graph"}
@@ -233,6 +246,19 @@ def main():
                     "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]),
                                         "agent_rows": float(mean_tot[2])}}
 
+    # forward-only rows/s and env-only world-rounds/s, from the same stage timers: agent rows
+    # of one step / the forward stages' time, envs of one step / the env launch's time
+    parts = None
+    if stages:
+        fwd_us = sum(v for k, v in stages.items() if k != "env_step")
+        rows = decisions / args.steps / world if args.mode == "round" else float(args.envs)
+        parts = {"forward_only_rows_per_s": rows / (fwd_us * 1e-6) if fwd_us > 0 else None,
+                 "forward_us": round(fwd_us, 2),
+                 "env_only_world_rounds_per_s": (args.envs / (stages["env_step"] * 1e-6)
+                                                 if args.mode == "round" and stages.get("env_step", 0) > 0 else None),
+                 "env_only_agent_steps_per_s": (args.envs / (stages["env_step"] * 1e-6)
+                                                if args.mode == "aec" and stages.get("env_step", 0) > 0 else None)}
+
     parallel.barrier()
     if rank != 0:
         return
@@ -255,6 +281,7 @@ def main():
                    "env_error_flags": errors},
         "roofline": roofline,
         "stage_us": {k: round(v, 2) for k, v in (stages or {}).items() if v > 0},
+        "parts": parts,
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.nodes)
