@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
 HC = HIDDEN * HEADS
 
@@ -41,7 +42,7 @@ def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
 
 
-def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9):
+def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9, dtype="f32"):
     import torch
     from melissa_amd.collect import DecisionLoop, MultiStreamRoundLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
@@ -54,6 +55,7 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
         net = HLDGNNetwork(5, HIDDEN, 2, HEADS, n_nodes, aggregator="max", dueling_param=dueling(),
                            device=device, backend="hip")
     net.eval()
+    net.set_feature_dtype(dtype)
     graphs = synthetic_graph_pool(n_nodes, 64, first_seed=0)
     make_venv = lambda count, seed: HipGraphVectorEnv(count, n_nodes, graph_pool=graphs, dynamic_graph=True,
                                                       device=device, max_moves=48, seed=seed,
@@ -152,6 +154,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="round mode: sub-batches of the GPU's envs on separate HIP streams (measured: no gain "
                          "in one process, 16.3 vs 16.2 M/s at 2 streams, worse at 3-4)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default): the reference's arithmetic, logits within 1e-4.  bf16: BASELINE's 'bf16 feature "
+                         "path' (feature rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -168,7 +173,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph,
-                                     args.streams)
+                                     args.streams, dtype=args.dtype)
     lib = _lib.load()
 
     loop.run(args.warmup)
@@ -195,7 +200,8 @@ def main():
         # same row counts per launch as a single-stream step; the timed pass above may overlap sub-batches)
         if args.mode == "round" and args.streams > 1:
             torch.cuda.synchronize()
-            _n, _v, ploop = build_workload(device, rank, args.envs, args.nodes, args.model, "round", False, 1)
+            _n, _v, ploop = build_workload(device, rank, args.envs, args.nodes, args.model, "round", False, 1,
+                                           dtype=args.dtype)
             ploop.run(args.warmup)
         else:
             ploop = loop
@@ -233,14 +239,15 @@ def main():
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
         if (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
-                and os.path.exists(pmc_path)):
+                and args.dtype == "f32" and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))["per_launch"]
             key = {"conv1_lin": "conv1 (lin_l+lin_r)", "conv2_lin": "conv2 (lin_l+lin_r)", "head_hidden": None}.get(dom)
             if key in pmc:
                 traffic = pmc[key]["hbm_bytes_corrected"]
         achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": f"gemm_f32_kernel ({dom})", "achieved": round(achieved, 3),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        roofline = {"bound": "mfma", "kernel": f"gemm_{args.dtype}_kernel ({dom})", "achieved": round(achieved, 3),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "avg_launch_us": round(stages[dom], 2),
                     "algorithmic_flops_per_launch": fl[dom],
                     "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]),
@@ -268,9 +275,9 @@ def main():
                   else f"env-steps/s (agent-decisions/s) {args.model} {args.nodes}-node",
         "value": value, "unit": "agent-decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs "
-                               f"per GPU, fp32, dynamic graph, eps=0.001, "
+                               f"per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 feature path'}, dynamic graph, eps=0.001, "
                                + ("round-batched loop (one env round per step)" if args.mode == "round"
                                   else "AEC-order loop (one agent decision per env per step)"),
                    "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),

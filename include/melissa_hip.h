@@ -100,7 +100,18 @@ typedef struct mel_weights {
     mel_gatv2 conv2;       /* unused for HL-DGN                                      */
     mel_mlp   q_head;      /* latent -> ... -> n_actions                             */
     mel_mlp   v_head;      /* latent -> ... -> 1                                     */
+    int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4) or MEL_PREC_BF16 */
+    int32_t reserved;
 } mel_weights;
+
+/* Feature precision of the L-DGN / DGN-R forward (BASELINE config "bf16 feature path").  MEL_PREC_BF16: the
+ * node-feature rows between layers (encoder output, lin_l / lin_r projections, conv outputs, head input and
+ * hidden layers) and the weight matrices of the dense projections are bf16 (the fp32 nn.Parameters are
+ * converted into the workspace by every call), contractions run on the bf16 MFMA with fp32 accumulation;
+ * attention scores / softmax / aggregation, biases, the encoder's first layer, the last head layer and the
+ * logits stay fp32.  Not the reference's arithmetic: expect ~1e-2 absolute on logits (tests state the bound). */
+#define MEL_PREC_F32  0
+#define MEL_PREC_BF16 1
 
 /* Bytes of scratch the forward needs for `bs` observation rows of `n_nodes`-node graphs. */
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes);
@@ -158,6 +169,13 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
 
+/* The same projection on the bf16 feature path: A [M, lda] and W [N, K] device bf16, bias fp32, fp32
+ * accumulation, Y [M, ldy] bf16 (y_f32 = 0) or fp32 (y_f32 = 1); K % 64 == 0, N % 64 == 0, lda % 8 == 0.
+ * mel_convert_bf16: count (multiple of 8) fp32 values -> bf16, round to nearest even. */
+mel_status mel_gemm_bf16(const void* A, int32_t lda, const void* W, const float* bias, void* Y, int32_t ldy,
+                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t y_f32, int32_t tile, void* stream);
+mel_status mel_convert_bf16(const float* src, void* dst, int64_t count, void* stream);
+
 /* HL-DGN for the round-batched loop: logits depend only on the env (hl_dgn.py:108 pools over the graph and
  * ignores the controlling index), so one row per env serves all of a round's agents.  obs: device fp32
  * [bs, obs_stride], row b = obs_matrix of env b, obs_stride >= n_nodes*(in_dim+3), index column not read. */
@@ -167,7 +185,8 @@ mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, cons
 
 /* Debug/parity taps: copies of intermediates after a forward with the same workspace.
  * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
- *       1 = head input fp32 [bs, latent] (L-DGN: x_1|x_2|x_3, l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),
+ *       1 = head input [bs, latent], fp32 (bf16 when w->precision is MEL_PREC_BF16) (L-DGN: x_1|x_2|x_3,
+ *           l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),
  *       2 = int32 [3]: rows the L-DGN GEMMs processed (sum |U1|, sum |U2|, agent rows).
  * rows_cap: 0 for a workspace used by mel_ldgn_forward / mel_hldgn_forward, else the rows_cap given to
  * mel_ldgn_forward_agents.  `out` is a device pointer with room for the requested tensor. */

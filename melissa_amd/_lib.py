@@ -20,11 +20,12 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_hldgn_forward_envs", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+EXPORTS = ("mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
+PREC_F32, PREC_BF16 = 0, 1
 N_STAGES = 14
 STAGE_NAMES = ("plan", "encoder", "conv1_lin", "conv1_lin_r", "conv1_att", "conv2_lin", "conv2_lin_r", "conv2_att",
                "head_hidden", "head_tail", "select", "env_step", "env_reset", "env_observe")
@@ -47,7 +48,7 @@ class MelMlp(C.Structure):
 class MelWeights(C.Structure):
     _fields_ = [("model", C.c_int32), ("in_dim", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32),
                 ("encoder", MelMlp), ("conv1", MelGatv2), ("conv2", MelGatv2), ("q_head", MelMlp),
-                ("v_head", MelMlp)]
+                ("v_head", MelMlp), ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MelSelect(C.Structure):
@@ -127,6 +128,10 @@ def load(build_if_missing: bool = True):
     lib.mel_hldgn_forward.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
     lib.mel_gemm_f32.restype = i32
     lib.mel_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]
+    lib.mel_gemm_bf16.restype = i32
+    lib.mel_gemm_bf16.argtypes = [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp]
+    lib.mel_convert_bf16.restype = i32
+    lib.mel_convert_bf16.argtypes = [vp, vp, i64, vp]
     lib.mel_hldgn_forward_envs.restype = i32
     lib.mel_hldgn_forward_envs.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
     lib.mel_select_action_envs.restype = i32

@@ -4,6 +4,7 @@
 // hl_dgn.py:82-119 and SURVEY.md Appendix A for the third-party operators.
 #include "common.hpp"
 #include "gemm_f32.hpp"
+#include "gemm_bf16.hpp"
 
 namespace mel {
 
@@ -76,9 +77,33 @@ static void gemm_launch_glds(const GemmArgs* gs, int count, hipStream_t s) {
     hipLaunchKernelGGL((gemm_f32_glds_kernel<WM, WN, TM, TN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
 }
 
+// bf16 feature path: one persistent launch for every case (ragged or not)
+template <int WM, int WN, int TM, int TN>
+static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int LDS_WG = (BM + BN) * GEMB_ROW * 16 * 2;
+    constexpr int PER_CU = (160 * 1024) / LDS_WG > 4 ? 4 : (160 * 1024) / LDS_WG;
+    GemmBatch batch{};
+    batch.count = count;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        tiles += ((long)((gs[i].M + BM - 1) / BM) * (gs[i].N / BN) + 7) & ~7L;
+    }
+    long grid = 256L * PER_CU;
+    if (grid > tiles) grid = tiles;
+    if (mode == GEMM_MODE_ENC)
+        hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+}
+
 static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
-    if (g.K % GEMM_BK != 0 || g.N % 64 != 0)
-        return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% 32 == 0 and N %% 64 == 0 (K=%d N=%d)", what, g.K, g.N);
+    const int bk = g.bf16 ? GEMB_BK : GEMM_BK;
+    if (g.K % bk != 0 || g.N % 64 != 0)
+        return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% %d == 0 and N %% 64 == 0 (K=%d N=%d)", what, bk, g.K, g.N);
+    if (g.bf16 && (g.lda % 8 != 0 && g.A))
+        return fail(MEL_ERR_UNSUPPORTED, "%s: bf16 GEMM needs lda %% 8 == 0 (lda=%d)", what, g.lda);
     return MEL_OK;
 }
 
@@ -86,6 +111,11 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     if (g.M <= 0) return MEL_OK;
     if (mel_status st = check_gemm_shape(g, what)) return st;
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
+    if (g.bf16) {
+        if (force_tile == 2 && g.N % 128 == 0) gemm_launch_bf16<2, 2, 2, 2>(&g, 1, mode, stream);
+        else gemm_launch_bf16<2, 2, 1, 1>(&g, 1, mode, stream);
+        return check_launch(what);
+    }
     if (force_tile == 1 || (force_tile >= 2 && g.N % 128 == 0)) {
         switch (force_tile) {
             case 1: gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream); break;     //  64 x  64, 4 waves
@@ -125,6 +155,12 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
         big += ((h + 127) / 128) * (gs[i].N / 128);
         n128 = n128 && gs[i].N % 128 == 0;
         long_k = long_k && gs[i].K >= 512;
+    }
+    if (gs[0].bf16) {
+        for (int i = 1; i < count; ++i)
+            if (!gs[i].bf16) return fail(MEL_ERR_INVALID_ARG, "%s: mixed precisions in one group", what);
+        gemm_launch_bf16<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
+        return check_launch(what);
     }
     bool ragged = false;
     for (int i = 0; i < count; ++i) ragged = ragged || gs[i].M_dev != nullptr;
@@ -351,6 +387,7 @@ struct AttArgs {
     const int32_t* rows_dev;    // device-side row count
     long rows_hint;             // expected rows (grid sizing only)
     int rows_cap, cat_off;
+    int bf16;                   // bf16 feature path: xl / xr / out / xcat / h0 hold bf16 rows (att / bias stay fp32)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -388,6 +425,55 @@ __device__ __forceinline__ void store_vec(float* p, const Vec<VPL>& r) {
     }
 }
 
+// feature rows: fp32, or bf16 on the bf16 feature path (math stays fp32 either way).  idx in elements.
+template <int VPL, bool BF>
+__device__ __forceinline__ Vec<VPL> load_row(const float* base, size_t idx) {
+    if constexpr (!BF) {
+        return load_vec<VPL>(base + idx);
+    } else {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + idx;
+        Vec<VPL> r;
+        if constexpr (VPL >= 8) {
+#pragma unroll
+            for (int c = 0; c < VPL / 8; ++c) {
+                const u32x4 w = reinterpret_cast<const u32x4*>(p)[c];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r.v[8 * c + 2 * i] = bf16_lo(w[i]), r.v[8 * c + 2 * i + 1] = bf16_hi(w[i]);
+            }
+        } else if constexpr (VPL == 4) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+            r.v[0] = bf16_lo(w[0]), r.v[1] = bf16_hi(w[0]), r.v[2] = bf16_lo(w[1]), r.v[3] = bf16_hi(w[1]);
+        } else {
+            static_assert(VPL == 2, "VPL");
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+            r.v[0] = bf16_lo(w), r.v[1] = bf16_hi(w);
+        }
+        return r;
+    }
+}
+
+template <int VPL, bool BF>
+__device__ __forceinline__ void store_row(float* base, size_t idx, const Vec<VPL>& r) {
+    if constexpr (!BF) {
+        store_vec<VPL>(base + idx, r);
+    } else {
+        uint16_t* p = reinterpret_cast<uint16_t*>(base) + idx;
+        if constexpr (VPL >= 8) {
+#pragma unroll
+            for (int c = 0; c < VPL / 8; ++c) {
+                const u32x4 w = {pack_bf16x2(r.v[8 * c], r.v[8 * c + 1]), pack_bf16x2(r.v[8 * c + 2], r.v[8 * c + 3]),
+                                 pack_bf16x2(r.v[8 * c + 4], r.v[8 * c + 5]), pack_bf16x2(r.v[8 * c + 6], r.v[8 * c + 7])};
+                reinterpret_cast<u32x4*>(p)[c] = w;
+            }
+        } else if constexpr (VPL == 4) {
+            const u32x2 w = {pack_bf16x2(r.v[0], r.v[1]), pack_bf16x2(r.v[2], r.v[3])};
+            *reinterpret_cast<u32x2*>(p) = w;
+        } else {
+            *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(r.v[0], r.v[1]);
+        }
+    }
+}
+
 // sum over the lanes of one head (lanes_per_head adjacent lanes).  The common case (16 lanes: C = 128,
 // 8 channels per lane) is four DPP moves inside a 16-lane row; anything else falls back to shuffles.
 __device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
@@ -402,6 +488,8 @@ __device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
     return s;
 }
 
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+
 // attention output of one target for this lane's VPL channels: relu(out + bias).  The source rows are
 // streamed once with an online softmax, FOUR sources per step: their row loads, score dot products and
 // per-head reductions are independent chains (the single-source form is one long dependent chain per source
@@ -409,33 +497,32 @@ __device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
 //   m' = max(m, s_0..s_3); l = l e^(m-m') + sum_k e^(s_k-m'); acc = acc e^(m-m') + sum_k e^(s_k-m') row_k
 // KIND = MEL_CONV_GATV2:       e = att . leaky_relu(x_r[i] + x_l[j]),          out = sum alpha x_l[j]
 // KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
-template <int VPL, int KIND>
-__device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float* xr_row, uint64_t sources,
+template <int VPL, int KIND, bool BF>
+__device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_row, uint64_t sources,
                                                   uint64_t smask, int soff, const Vec<VPL>& att,
                                                   const Vec<VPL>& bias, int lane) {
     constexpr int HC = 64 * VPL;
     constexpr int G = 4;
-    const Vec<VPL> xr = load_vec<VPL>(xr_row + lane * VPL);
+    const Vec<VPL> xr = load_row<VPL, BF>(a.xr, xr_row * a.ld_r + lane * VPL);
     float m = -INFINITY, l = 0.f;
     Vec<VPL> acc;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    const float* base = a.xl + lane * VPL;
     while (sources) {                            // TransformerConv adds no self-loop: a target may be isolated
-        const float* row[G];
+        size_t row[G];                           // element index of this lane's slice of the source row
         bool on[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             on[k] = sources != 0;
             const int j = on[k] ? lowest_bit(sources) : 0;
             sources &= sources - 1;              // 0 stays 0
-            row[k] = base + (size_t)(soff + (on[k] ? rank_below(smask, j) : 0)) * a.ld_l;    // off slots re-read a valid row
+            row[k] = (size_t)(soff + (on[k] ? rank_below(smask, j) : 0)) * a.ld_l + lane * VPL;    // off slots re-read a valid row
         }
         Vec<VPL> xl[G], xv[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) {
-            xl[k] = load_vec<VPL>(row[k]);
-            if constexpr (KIND == MEL_CONV_TRANSFORMER) xv[k] = load_vec<VPL>(row[k] + HC);
+            xl[k] = load_row<VPL, BF>(a.xl, row[k]);
+            if constexpr (KIND == MEL_CONV_TRANSFORMER) xv[k] = load_row<VPL, BF>(a.xl, row[k] + HC);
         }
         float sc_[G];
 #pragma unroll
@@ -472,10 +559,12 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
             if (!on[k]) sc_[k] = -INFINITY;
         }
         const float mn = fmaxf(fmaxf(m, fmaxf(sc_[0], sc_[1])), fmaxf(sc_[2], sc_[3]));
-        const float rs = expf(m - mn);           // slot 0 is always on, so mn is finite
+        // e^x as v_exp_f32(x log2 e): ~1e-6 relative on softmax weights that are later normalised (the libm
+        // expansion was a quarter of this kernel's VALU work, and the kernel is VALU / latency bound)
+        const float rs = fast_exp(m - mn);       // slot 0 is always on, so mn is finite
         float pe[G];
 #pragma unroll
-        for (int k = 0; k < G; ++k) pe[k] = expf(sc_[k] - mn);       // exp(-inf) = 0 for the off slots
+        for (int k = 0; k < G; ++k) pe[k] = fast_exp(sc_[k] - mn);   // exp(-inf) = 0 for the off slots
         l = l * rs + ((pe[0] + pe[1]) + (pe[2] + pe[3]));
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
@@ -486,7 +575,7 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, const float*
         }
         m = mn;
     }
-    const float inv = 1.f / (l + 1e-16f);
+    const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
     Vec<VPL> out;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) out.v[i] = fmaxf(acc.v[i] * inv + bias.v[i], 0.f);
@@ -509,7 +598,7 @@ __device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
 //              logits, l_dgn.py:135), sources = its closed neighbourhood inside U1 -> x_3
 // (256, 2): with the bare bound the register allocator aims at 6 waves per SIMD and SPILLS the source-row
 // pointers (88 B of scratch in front of every row load); two blocks per CU lets it keep ~100 VGPRs.
-template <int VPL, int MODE, int KIND>
+template <int VPL, int MODE, int KIND, bool BF>
 __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
     const int lane = lane_id();
     const int rows = min(*a.rows_dev, a.rows_cap);
@@ -529,19 +618,24 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
         const int r = (blockIdx.x & 7) * span + i;
         if (r >= rows) continue;
         const TargetDesc d = a.desc[r];          // one 32-byte record: no chain of dependent index loads
-        const Vec<VPL> o = attend_target<VPL, KIND>(a, a.xr + (size_t)r * a.ld_r, d.sources, d.smask, d.soff, att,
-                                                    bias, lane);
+        const Vec<VPL> o = attend_target<VPL, KIND, BF>(a, (size_t)r, d.sources, d.smask, d.soff, att, bias, lane);
         if constexpr (MODE == ATT_SINGLE) {
-            store_vec<VPL>(a.xcat + (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
+            store_row<VPL, BF>(a.xcat, (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
         } else {
-            store_vec<VPL>(a.out + (size_t)r * a.ldo + lane * VPL, o);
+            store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, o);
             if (d.cat_row >= 0) {
-                float* cat = a.xcat + (size_t)d.cat_row * a.ld_cat;
+                const size_t cat = (size_t)d.cat_row * a.ld_cat;
                 // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
-                store_vec<VPL>(cat + a.hidden + lane * VPL, o);
+                store_row<VPL, BF>(a.xcat, cat + a.hidden + lane * VPL, o);
                 // x_1: its encoder row (l_dgn.py:122)
-                const float* h0 = a.h0 + (size_t)(d.soff + rank_below(d.smask, d.node)) * a.hidden;
-                for (int c = lane; c < a.hidden; c += 64) cat[c] = h0[c];
+                const size_t h0 = (size_t)(d.soff + rank_below(d.smask, d.node)) * a.hidden;
+                if constexpr (BF) {
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(a.xcat) + cat;
+                    const uint16_t* src = reinterpret_cast<const uint16_t*>(a.h0) + h0;
+                    for (int c = lane; c < a.hidden; c += 64) dst[c] = src[c];
+                } else {
+                    for (int c = lane; c < a.hidden; c += 64) a.xcat[cat + c] = a.h0[h0 + c];
+                }
             }
         }
     }
@@ -549,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
 
 // ATT_POOL (HL-DGN): one workgroup per env (every env has exactly N targets, so this is balanced):
 // conv1 attention for all nodes, decision-maker mask, max / mean / add pool over the graph.
-template <int VPL>
+template <int VPL, bool BF>
 __global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
     constexpr int HC = 64 * VPL;
     __shared__ float part[4][HC];
@@ -564,8 +658,8 @@ __global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
     for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
     for (int t = wave; t < a.n; t += 4) {
         const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
-        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2>(a, a.xr + (size_t)(b * a.n + t) * a.ld_r, sources, full,
-                                                              b * a.n, att, bias, lane);
+        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF>(a, (size_t)(b * a.n + t), sources, full, b * a.n,
+                                                                  att, bias, lane);
         // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
         const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
@@ -585,7 +679,8 @@ __global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
             v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
             if (a.aggregator == MEL_AGG_MEAN) v /= (float)a.n;
         }
-        a.pooled[(size_t)b * HC + c] = v;
+        if constexpr (BF) reinterpret_cast<uint16_t*>(a.pooled)[(size_t)b * HC + c] = (uint16_t)pack_bf16x2(v, 0.f);
+        else a.pooled[(size_t)b * HC + c] = v;
     }
 }
 
@@ -593,10 +688,14 @@ template <int MODE>
 static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const char* what) {
     if constexpr (MODE == ATT_POOL) {
         switch (hc / 64) {
-            case 2: hipLaunchKernelGGL((gat_attend_pool_kernel<2>), dim3(a.bs), dim3(256), 0, s, a); break;
-            case 4: hipLaunchKernelGGL((gat_attend_pool_kernel<4>), dim3(a.bs), dim3(256), 0, s, a); break;
-            case 8: hipLaunchKernelGGL((gat_attend_pool_kernel<8>), dim3(a.bs), dim3(256), 0, s, a); break;
-            case 16: hipLaunchKernelGGL((gat_attend_pool_kernel<16>), dim3(a.bs), dim3(256), 0, s, a); break;
+#define MEL_POOL_LAUNCH(V)                                                                              \
+    if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true>), dim3(a.bs), dim3(256), 0, s, a);  \
+    else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false>), dim3(a.bs), dim3(256), 0, s, a);
+            case 2: MEL_POOL_LAUNCH(2) break;
+            case 4: MEL_POOL_LAUNCH(4) break;
+            case 8: MEL_POOL_LAUNCH(8) break;
+            case 16: MEL_POOL_LAUNCH(16) break;
+#undef MEL_POOL_LAUNCH
             default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
         }
     } else {
@@ -604,11 +703,15 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         if (want > (a.rows_cap + 3) / 4) want = (a.rows_cap + 3) / 4;
         if (want < 256) want = 256;
         const int grid = (int)((want + 7) & ~7L);       // multiple of 8: block id % 8 = XCD
-#define MEL_ATT_LAUNCH(V)                                                                                      \
-    if (a.kind == MEL_CONV_TRANSFORMER)                                                                        \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); \
-    else                                                                                                       \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);
+#define MEL_ATT_LAUNCH(V)                                                                                             \
+    if (a.kind == MEL_CONV_TRANSFORMER && a.bf16)                                                                     \
+        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, true>), dim3(grid), dim3(256), 0, s, a);  \
+    else if (a.kind == MEL_CONV_TRANSFORMER)                                                                          \
+        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, false>), dim3(grid), dim3(256), 0, s, a); \
+    else if (a.bf16)                                                                                                  \
+        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, true>), dim3(grid), dim3(256), 0, s, a);        \
+    else                                                                                                              \
+        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, false>), dim3(grid), dim3(256), 0, s, a);
         switch (hc / 64) {
             case 2: MEL_ATT_LAUNCH(2) break;
             case 4: MEL_ATT_LAUNCH(4) break;
@@ -827,8 +930,44 @@ struct FwdLayout {
     float* xcat;    // head input [rows, latent]
     float* hq[2];   // head hidden ping-pong [rows, qw + vw]
     float* minmax;
+    uint16_t* wb;   // bf16 copies of the projection weights (bf16 feature path)
+    size_t wb_elems;
     size_t bytes;
 };
+
+// the weight matrices the dense projections read, in launch order; fp32 path: the nn.Parameter storages
+// themselves, bf16 path: their bf16 copies in the workspace (refreshed by every call)
+struct ProjWeights {
+    const float* enc1;
+    const float* c1l; const float* c1r; const float* c1v;
+    const float* c2l; const float* c2r; const float* c2v;
+    const float* q[MEL_MAX_HEAD_LAYERS];
+    const float* v[MEL_MAX_HEAD_LAYERS];
+};
+
+static size_t lin_elems(const mel_linear& l) { return l.weight ? (size_t)l.in_dim * l.out_dim : 0; }
+
+// visits every projection weight: f(const mel_linear&, const float** slot)
+template <class F>
+static void for_each_projection(const mel_weights* w, ProjWeights& pw, F f) {
+    f(w->encoder.layer[1], &pw.enc1);
+    f(w->conv1.lin_l, &pw.c1l), f(w->conv1.lin_r, &pw.c1r);
+    if (w->conv1.kind == MEL_CONV_TRANSFORMER) f(w->conv1.lin_v, &pw.c1v);
+    if (w->model != MEL_MODEL_HLDGN) {
+        f(w->conv2.lin_l, &pw.c2l), f(w->conv2.lin_r, &pw.c2r);
+        if (w->conv2.kind == MEL_CONV_TRANSFORMER) f(w->conv2.lin_v, &pw.c2v);
+    }
+    for (int i = 0; i + 1 < w->q_head.n_layers; ++i) f(w->q_head.layer[i], &pw.q[i]);
+    if (w->dueling)
+        for (int i = 0; i + 1 < w->v_head.n_layers; ++i) f(w->v_head.layer[i], &pw.v[i]);
+}
+
+static size_t projection_elems(const mel_weights* w) {
+    ProjWeights pw{};
+    size_t total = 0;
+    for_each_projection(w, pw, [&](const mel_linear& l, const float**) { total += (lin_elems(l) + 7) & ~(size_t)7; });
+    return total;
+}
 
 static int head_hidden_width(const mel_mlp& m) {
     int w = 0;
@@ -878,6 +1017,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.minmax = c.take<float>(64);
+    L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w) : 0;
+    L.wb = c.take<uint16_t>(L.wb_elems ? L.wb_elems : 8);
     L.bytes = c.off;
     return L;
 }
@@ -888,6 +1029,7 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
     if (bs <= 0 || bs > (1 << 24)) return fail(MEL_ERR_INVALID_ARG, "bs=%ld out of range", (long)bs);
     if (n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, %d]", n, MEL_MAX_NODES);
     if (w->in_dim < 1 || w->in_dim > 8) return fail(MEL_ERR_UNSUPPORTED, "in_dim=%d outside [1, 8]", w->in_dim);
+    if (w->precision != MEL_PREC_F32 && w->precision != MEL_PREC_BF16) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
     const int expected = n * (w->in_dim + 3);
     if (index_col) {
         if (obs_stride - 1 != expected)      // networks/common.py:24-29
@@ -942,11 +1084,39 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
     return MEL_OK;
 }
 
+// fp32: alias the parameters.  bf16: convert all projection weights into L.wb with one launch.
+static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, hipStream_t s) {
+    pw = ProjWeights{};
+    if (w->precision != MEL_PREC_BF16) {
+        for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) { *slot = l.weight; });
+        return MEL_OK;
+    }
+    CvtBatch b{};
+    size_t off = 0;
+    int blocks = 0;
+    bool bad = false;
+    for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) {
+        const size_t cnt = lin_elems(l);
+        if (b.n >= CVT_MAX_SEG || cnt % 8 != 0 || !l.weight) { bad = true; return; }
+        b.src[b.n] = l.weight, b.dst[b.n] = L.wb + off, b.count[b.n] = (int)cnt, b.start[b.n] = blocks;
+        *slot = reinterpret_cast<const float*>(L.wb + off);
+        blocks += (int)((cnt / 8 + 255) / 256);
+        off += (cnt + 7) & ~(size_t)7;
+        ++b.n;
+    });
+    if (bad) return fail(MEL_ERR_UNSUPPORTED, "bf16 path: a projection weight is null or its size is not a multiple of 8");
+    b.start[b.n] = blocks;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(blocks), dim3(256), 0, s, b);
+    return check_launch("weights -> bf16");
+}
+
 // dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail.
 // rows_dev (device row count) may be null.
-static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t rows, const int32_t* rows_dev,
-                            long rows_hint, float* logits, hipStream_t s, const mel_select* select = nullptr) {
+static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const FwdLayout& L, int64_t rows,
+                            const int32_t* rows_dev, long rows_hint, float* logits, hipStream_t s,
+                            const mel_select* select = nullptr) {
     const int nl = w->q_head.n_layers;
+    const int bf = w->precision == MEL_PREC_BF16;
     const float* in_q = L.xcat;
     const float* in_v = L.xcat;
     int ld_q = w->q_head.layer[0].in_dim, ld_v = ld_q;
@@ -959,20 +1129,29 @@ static mel_status run_heads(const mel_weights* w, const FwdLayout& L, int64_t ro
         if (i == 0 && q.in_dim == v.in_dim) {       // shared input: one launch, weights split along n
             GemmArgs g;
             g.A = in_q, g.lda = ld_q;
-            g.W = q.weight, g.W_hi = v.weight, g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
+            g.W = pw.q[i], g.W_hi = pw.v[i], g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
             g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
+            g.bf16 = bf, g.y_f32 = (i + 2 == nl);       // the tail reads fp32
             if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint)) return st;
         } else {
             GemmArgs g[2];
-            g[0].A = in_q, g[0].lda = ld_q, g[0].W = q.weight, g[0].bias = q.bias;
+            // element offset of the V half inside a row: in elements of the buffer's type (bf16 halves the bytes)
+            const bool in16 = bf, out32 = !bf || (i + 2 == nl);
+            g[0].A = in_q, g[0].lda = ld_q, g[0].W = pw.q[i], g[0].bias = q.bias;
             g[0].Y = out, g[0].ldy = ldo, g[0].M = (int)rows, g[0].M_dev = rows_dev, g[0].N = q.out_dim, g[0].K = q.in_dim, g[0].relu = 1;
-            g[1].A = in_v, g[1].lda = ld_v, g[1].W = v.weight, g[1].bias = v.bias;
-            g[1].Y = out + q.out_dim, g[1].ldy = ldo, g[1].M = (int)rows, g[1].M_dev = rows_dev, g[1].N = v.out_dim, g[1].K = v.in_dim, g[1].relu = 1;
+            g[1].A = in_v, g[1].lda = ld_v, g[1].W = pw.v[i], g[1].bias = v.bias;
+            g[1].Y = out32 ? out + q.out_dim : reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(out) + q.out_dim);
+            g[1].ldy = ldo, g[1].M = (int)rows, g[1].M_dev = rows_dev, g[1].N = v.out_dim, g[1].K = v.in_dim, g[1].relu = 1;
+            g[0].bf16 = g[1].bf16 = bf, g[0].y_f32 = g[1].y_f32 = (bf && out32);
+            (void)in16;
             const long hints[2] = {rows_hint, rows_hint};
             if (mel_status st = launch_gemm_group(g, hints, w->dueling ? 2 : 1, s, "Q + V hidden")) return st;
         }
-        in_q = out, in_v = out + q.out_dim, ld_q = ld_v = ldo;
+        const bool out16 = bf && !(i + 2 == nl);
+        in_q = out, ld_q = ld_v = ldo;
+        in_v = out16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(out) + q.out_dim) : out + q.out_dim;
     }
+    if (bf && nl < 2) return fail(MEL_ERR_UNSUPPORTED, "bf16 path needs at least one hidden layer in the heads");
     const mel_linear& ql = w->q_head.layer[nl - 1];
     const mel_linear& vl = w->v_head.layer[nl - 1];
     StageScope t(MEL_STAGE_HEAD_TAIL, s);
@@ -1004,6 +1183,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     // (N = 50): one agent per row: |U1| ~ 0.13 N, |U2| ~ 0.25 N; a whole round (about 0.1 N active agents
     // with overlapping neighbourhoods): |U1| ~ 0.21 N, |U2| ~ 0.32 N.
     const bool single = agent_mask == nullptr;
+    const int bf = w->precision == MEL_PREC_BF16;
+    ProjWeights pw;
+    if (mel_status st = resolve_projections(w, L, pw, s)) return st;
     const long hintL = single ? bs : bs * (long)(n < 10 ? 1 : n / 10);
     const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : bs * (long)(n < 5 ? n : 1 + n / 5);
     const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : bs * (long)(n < 3 ? n : 1 + n / 3);
@@ -1022,7 +1204,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         GemmArgs g;
         g.obs = obs, g.obs_width = obs_stride, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
         g.nid = L.plan.nid2, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-        g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
+        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf;
         g.Y = L.h0, g.ldy = hidden, g.M = U2, g.M_dev = n2, g.N = hidden;
         g.K = w->encoder.layer[0].out_dim, g.relu = 1;
         StageScope t(MEL_STAGE_ENCODER, s);
@@ -1030,12 +1212,13 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     }
     {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
         GemmArgs g[2];
-        g[0].A = L.h0, g[0].lda = hidden, g[0].W = w->conv1.lin_l.weight, g[0].bias = w->conv1.lin_l.bias;
+        g[0].bf16 = g[1].bf16 = bf;
+        g[0].A = L.h0, g[0].lda = hidden, g[0].W = pw.c1l, g[0].bias = w->conv1.lin_l.bias;
         g[0].Y = L.xl1, g[0].ldy = srcw, g[0].M = U2, g[0].M_dev = n2, g[0].N = srcw, g[0].K = hidden;
         if (tconv)       // key | value of the sources in one problem (weights split along n)
-            g[0].W_hi = w->conv1.lin_v.weight, g[0].bias_hi = w->conv1.lin_v.bias, g[0].split_n = hc;
+            g[0].W_hi = pw.c1v, g[0].bias_hi = w->conv1.lin_v.bias, g[0].split_n = hc;
         g[1].A = L.h0, g[1].lda = hidden, g[1].arow = L.plan.arow1;
-        g[1].W = w->conv1.lin_r.weight, g[1].bias = w->conv1.lin_r.bias;
+        g[1].W = pw.c1r, g[1].bias = w->conv1.lin_r.bias;
         g[1].Y = L.xr1, g[1].ldy = hc, g[1].M = U1, g[1].M_dev = n1, g[1].N = hc, g[1].K = hidden;
         const long hints[2] = {hint2, hint1};
         StageScope t(MEL_STAGE_CONV1_LIN, s);
@@ -1044,7 +1227,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
         AttArgs a{};
         a.xl = L.xl1, a.ld_l = srcw, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
-        a.kind = w->conv1.kind, a.score_scale = 1.0f / sqrtf((float)w->conv1.channels);
+        a.kind = w->conv1.kind, a.score_scale = 1.0f / sqrtf((float)w->conv1.channels), a.bf16 = bf;
         a.adj = L.plan.adj, a.live = L.plan.live, a.smask = L.plan.u2;
         a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
@@ -1056,12 +1239,13 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv2.lin_l on the U1 rows + conv2.lin_r on the agent rows, one grouped launch; the decision-maker
         // mask (l_dgn.py:128) rides along as a row scale
         GemmArgs g[2];
+        g[0].bf16 = g[1].bf16 = bf;
         g[0].A = L.h1, g[0].lda = hc, g[0].rscale = L.plan.dm1;
-        g[0].W = w->conv2.lin_l.weight, g[0].bias = w->conv2.lin_l.bias;
+        g[0].W = pw.c2l, g[0].bias = w->conv2.lin_l.bias;
         g[0].Y = L.xl2, g[0].ldy = srcw, g[0].M = U1, g[0].M_dev = n1, g[0].N = srcw, g[0].K = hc;
-        if (tconv) g[0].W_hi = w->conv2.lin_v.weight, g[0].bias_hi = w->conv2.lin_v.bias, g[0].split_n = hc;
+        if (tconv) g[0].W_hi = pw.c2v, g[0].bias_hi = w->conv2.lin_v.bias, g[0].split_n = hc;
         g[1].A = L.h1, g[1].lda = hc, g[1].arow = L.plan.arow_g, g[1].rscale = L.plan.dm_g;
-        g[1].W = w->conv2.lin_r.weight, g[1].bias = w->conv2.lin_r.bias;
+        g[1].W = pw.c2r, g[1].bias = w->conv2.lin_r.bias;
         g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;
         const long hints[2] = {hint1, hintL};
         StageScope t(MEL_STAGE_CONV2_LIN, s);
@@ -1070,7 +1254,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv2 attention, one target per agent row -> x_3
         AttArgs a{};
         a.xl = L.xl2, a.ld_l = srcw, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
-        a.kind = w->conv2.kind, a.score_scale = 1.0f / sqrtf((float)w->conv2.channels);
+        a.kind = w->conv2.kind, a.score_scale = 1.0f / sqrtf((float)w->conv2.channels), a.bf16 = bf;
         a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
         a.desc = L.plan.desc2, a.rows_dev = nL, a.rows_cap = R, a.rows_hint = hintL;
@@ -1078,7 +1262,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         StageScope t(MEL_STAGE_CONV2_ATT, s);
         if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
     }
-    return run_heads(w, L, R, nL, hintL, logits, s, select);
+    return run_heads(w, pw, L, R, nL, hintL, logits, s, select);
 }
 
 }  // namespace mel
@@ -1152,6 +1336,9 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     const int node_cols = w->in_dim + 3;
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int M = (int)(bs * n);
+    const int bf = w->precision == MEL_PREC_BF16;
+    ProjWeights pw;
+    if (mel_status st = resolve_projections(w, L, pw, s)) return st;
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -1164,7 +1351,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         GemmArgs g;
         g.obs = obs, g.obs_width = obs_width, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
         g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-        g.W = w->encoder.layer[1].weight, g.bias = w->encoder.layer[1].bias;
+        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf;
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
         StageScope t(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
@@ -1172,7 +1359,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     {   // x_l | x_r for every node in one GEMM (weights split along n)
         GemmArgs g;
         g.A = L.h0, g.lda = hidden;
-        g.W = w->conv1.lin_l.weight, g.W_hi = w->conv1.lin_r.weight;
+        g.W = pw.c1l, g.W_hi = pw.c1r, g.bf16 = bf;
         g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
         g.Y = L.xl1, g.ldy = 2 * hc, g.M = M, g.N = 2 * hc, g.K = hidden;
         StageScope t(MEL_STAGE_CONV1_LIN, s);
@@ -1180,7 +1367,8 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     }
     {
         AttArgs a{};
-        a.xl = L.xl1, a.ld_l = 2 * hc, a.xr = L.xl1 + hc, a.ld_r = 2 * hc;
+        a.xl = L.xl1, a.ld_l = 2 * hc, a.ld_r = 2 * hc, a.bf16 = bf;
+        a.xr = bf ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(L.xl1) + hc) : L.xl1 + hc;
         a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj, a.kind = MEL_CONV_GATV2;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.obs = obs, a.obs_stride = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
@@ -1188,7 +1376,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
-    return run_heads(w, L, bs, nullptr, bs, logits, s);
+    return run_heads(w, pw, L, bs, nullptr, bs, logits, s);
 }
 
 mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
@@ -1211,6 +1399,29 @@ mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float
     return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_f32", -1, tile);
 }
 
+mel_status mel_gemm_bf16(const void* A, int32_t lda, const void* W, const float* bias, void* Y, int32_t ldy,
+                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t y_f32, int32_t tile, void* stream) {
+    if (!A || !W || !Y || M < 0 || M > (1ll << 30) || lda < K || ldy < N)
+        return fail(MEL_ERR_INVALID_ARG, "bad gemm arguments");
+    clear_stale_error();
+    GemmArgs g;
+    g.A = static_cast<const float*>(A), g.lda = lda, g.W = static_cast<const float*>(W), g.bias = bias;
+    g.Y = static_cast<float*>(Y), g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K, g.relu = relu, g.bf16 = 1, g.y_f32 = y_f32;
+    return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_bf16", -1, tile);
+}
+
+mel_status mel_convert_bf16(const float* src, void* dst, int64_t count, void* stream) {
+    if (!src || !dst || count < 0 || count % 8 != 0 || count > (1ll << 30))
+        return fail(MEL_ERR_INVALID_ARG, "mel_convert_bf16: count must be a multiple of 8");
+    if (count == 0) return MEL_OK;
+    clear_stale_error();
+    CvtBatch b{};
+    b.n = 1, b.src[0] = src, b.dst[0] = static_cast<uint16_t*>(dst), b.count[0] = (int)count, b.start[0] = 0;
+    b.start[1] = (int)((count / 8 + 255) / 256);
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(b.start[1]), dim3(256), 0, static_cast<hipStream_t>(stream), b);
+    return check_launch("mel_convert_bf16");
+}
+
 mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n, int64_t rows_cap,
                            const void* workspace, void* out, void* stream) {
     if (!w || !workspace || !out || bs <= 0 || n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "bad tap arguments");
@@ -1222,7 +1433,8 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
     if (kind == 0)
         e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
     else if (kind == 1)
-        e = hipMemcpyAsync(out, L.xcat, (size_t)d.rows_cap * w->q_head.layer[0].in_dim * sizeof(float), hipMemcpyDeviceToDevice, s);
+        e = hipMemcpyAsync(out, L.xcat, (size_t)d.rows_cap * w->q_head.layer[0].in_dim *
+                           (w->precision == MEL_PREC_BF16 ? sizeof(uint16_t) : sizeof(float)), hipMemcpyDeviceToDevice, s);
     else if (kind == 2 && w->model != MEL_MODEL_HLDGN) {
         int32_t* o = static_cast<int32_t*>(out);
         e = hipMemcpyAsync(o, L.plan.off1 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);

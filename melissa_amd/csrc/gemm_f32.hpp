@@ -58,6 +58,10 @@ struct GemmArgs {
     const int32_t* M_dev = nullptr; // optional device-side row count (<= M)
     int N = 0, K = 0;
     int relu = 0;
+    // bf16 feature path (gemm_bf16.hpp): A / W / W_hi point at bf16 data (lda, K in elements), Y at bf16 - or at
+    // fp32 when y_f32 is set.  bias / rscale / obs / enc_* are fp32 on both paths.
+    int bf16 = 0;
+    int y_f32 = 0;
 };
 
 // Up to four independent problems in one launch (e.g. conv.lin_l + conv.lin_r, or the Q and V hidden layers):

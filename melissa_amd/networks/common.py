@@ -136,8 +136,19 @@ class HipForwardMixin:
 
     _MODEL = None          # set by subclasses
 
+    # "f32": the reference's arithmetic (logits within 1e-4).  "bf16": BASELINE's "bf16 feature path" - feature
+    # rows and projection weights in bf16, fp32 accumulation / softmax / logits (include/melissa_hip.h MEL_PREC_*).
+    feature_dtype = "f32"
+
+    def set_feature_dtype(self, name: str):
+        if name not in ("f32", "bf16"):
+            raise ValueError(f"feature_dtype must be 'f32' or 'bf16', got {name!r}")
+        self.feature_dtype = name
+        self._w_cache = None
+        return self
+
     def _param_key(self):
-        return tuple((p.data_ptr(), p.dtype, p.is_contiguous()) for p in self.parameters())
+        return (self.feature_dtype,) + tuple((p.data_ptr(), p.dtype, p.is_contiguous()) for p in self.parameters())
 
     def _weights(self) -> _lib.MelWeights:
         key = self._param_key()
@@ -162,6 +173,7 @@ class HipForwardMixin:
             _mlp(w.q_head, [self.out_linear])
             _mlp(w.v_head, [self.out_linear])     # ignored by the kernels when dueling == 0
             w.v_head.layer[0].out_dim = 1
+        w.precision = _lib.PREC_BF16 if self.feature_dtype == "bf16" else _lib.PREC_F32
         self._w_cache = (key, w)
         return w
 
@@ -212,7 +224,8 @@ class HipForwardMixin:
         if kind == 0:
             out = torch.empty(bs, self.agents_num, dtype=torch.int64, device=ws.device)
         elif kind == 1:
-            out = torch.empty(rows_cap or bs, w.q_head.layer[0].in_dim, dtype=torch.float32, device=ws.device)
+            out = torch.empty(rows_cap or bs, w.q_head.layer[0].in_dim, device=ws.device,
+                              dtype=torch.bfloat16 if self.feature_dtype == "bf16" else torch.float32)
         else:
             out = torch.zeros(3, dtype=torch.int32, device=ws.device)
         _lib.check(lib.mel_forward_tap(C.byref(w), kind, bs, self.agents_num, rows_cap, ws.data_ptr(), out.data_ptr(),

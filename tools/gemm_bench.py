@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--tiles", default="1,2")
+    ap.add_argument("--bf16", action="store_true", help="the bf16 feature-path GEMM (mel_gemm_bf16; tiles 1 / 2)")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda")
@@ -30,20 +31,26 @@ def main():
         W = torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)
         Y = torch.empty(M, N, device=dev)
-        ref = torch.addmm(b, A, W.t())
+        if args.bf16:
+            A, W, Y = A.to(torch.bfloat16), W.to(torch.bfloat16), Y.to(torch.bfloat16)
+            ref = torch.addmm(b, A.float(), W.float().t())
+            gemm = lambda t: lib.mel_gemm_bf16(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, 0, t,
+                                               _lib.current_stream_ptr())
+        else:
+            ref = torch.addmm(b, A, W.t())
+            gemm = lambda t: lib.mel_gemm_f32(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
+                                              _lib.current_stream_ptr())
         res = {}
         for t in tiles:
-            _lib.check(lib.mel_gemm_f32(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
-                                        _lib.current_stream_ptr()))
-            err = (Y - ref).abs().max().item()
+            _lib.check(gemm(t))
+            err = (Y.float() - ref).abs().max().item()
             res[t] = [err, []]
         for _ in range(args.rounds):
             for t in tiles:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(4):
-                    lib.mel_gemm_f32(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
-                                     _lib.current_stream_ptr())
+                    gemm(t)
                 e1.record()
                 e1.synchronize()
                 res[t][1].append(e0.elapsed_time(e1) / 4 * 1e3)
