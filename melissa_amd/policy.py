@@ -132,6 +132,67 @@ class DQNPolicy(nn.Module):
         return {"loss": float(loss.detach())}
 
 
+class DGNPolicy(DQNPolicy):
+    """Counterpart of policies/dgn.py:21-71 (DGN-R training, BASELINE config 5).  The reference loss regresses
+    every sampled experience's n-step return on the SUM of the Q values of all agents that acted in the same env
+    round ("siblings": ``exp.info.indices`` holds their buffer indices, -1 for agents that did not act):
+
+        q_j   = Q(active_obs_j)[act_j]                for every sibling j of experience i   (dgn.py:43-52)
+        loss  = mean_i (returns_i - sum_j q_j)^2 * w   or   huber(sum_j q_j, returns_i)      (dgn.py:57-64)
+
+    The reference evaluates the siblings with one small forward per experience (a 32-iteration Python loop,
+    dgn.py:31-55); here ALL sibling observations of the batch go through ONE forward and a segment sum
+    (SURVEY.md 8(f) #3).  Same loss value and gradients (tests/test_host_logic.py compares with the loop)."""
+
+    def learn(self, batch, grad_hook=None) -> dict:
+        """batch: ``returns`` [B]; ``active_obs`` [M, 8N+1] (all sibling observations, index column = the sibling),
+        ``active_act`` [M], ``segment`` [M] = experience each sibling row belongs to; optional ``weight``."""
+        if self._target and self._iter % self._freq == 0:
+            self.sync_weight()
+        self.optim.zero_grad()
+        with torch.enable_grad():
+            logits, _ = self.model(batch["active_obs"])
+            dev = logits.device
+            act = torch.as_tensor(batch["active_act"], device=dev, dtype=torch.long)
+            seg = torch.as_tensor(batch["segment"], device=dev, dtype=torch.long)
+            returns = torch.as_tensor(batch["returns"], device=dev, dtype=logits.dtype).flatten()
+            q = logits[torch.arange(len(act), device=dev), act]
+            batch_q = torch.zeros_like(returns).index_add(0, seg, q)
+            td = returns - batch_q
+            if self._clip_loss_grad:
+                loss = torch.nn.functional.huber_loss(batch_q.reshape(-1, 1), returns.reshape(-1, 1), reduction="mean")
+            else:
+                weight = batch.get("weight", 1.0) if isinstance(batch, dict) else 1.0
+                weight = torch.as_tensor(weight, device=dev, dtype=logits.dtype)
+                loss = (td.pow(2) * weight).mean()
+            loss.backward()
+        if grad_hook is not None:
+            grad_hook(self.model)
+        self.optim.step()
+        self._iter += 1
+        if isinstance(batch, dict):
+            batch["weight"] = td.detach()            # prio-buffer hook, dgn.py:66
+        return {"loss": float(loss.detach())}
+
+    @staticmethod
+    def segments_from_indices(indices: np.ndarray, active_index: np.ndarray):
+        """The reference's sibling lookup (dgn.py:31-47) as index arrays: ``indices`` [B, N] buffer indices of each
+        experience's siblings (-1 = none), ``active_index`` [M] buffer index of every row of ``batch.active_obs``.
+        Returns (gather [R], segment [R]): sibling row ``active_obs[gather[r]]`` contributes to experience
+        ``segment[r]`` - the first matching row, like ``np.where(index == i)[0][0]``."""
+        indices = np.asarray(indices)
+        active_index = np.asarray(active_index)
+        first = {}
+        for pos, idx in enumerate(active_index.tolist()):
+            first.setdefault(idx, pos)
+        gather, segment = [], []
+        for i, row in enumerate(indices):
+            for idx in row[row >= 0].tolist():
+                gather.append(first[idx])
+                segment.append(i)
+        return np.asarray(gather, dtype=np.int64), np.asarray(segment, dtype=np.int64)
+
+
 class MultiAgentSharedPolicy(nn.Module):
     """One shared policy for every agent id (shared_policy.py:14-31): ``forward`` returns the actions
     in the batch's original order, exactly what the reference's split / stitch produces."""

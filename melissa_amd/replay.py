@@ -89,6 +89,48 @@ class RoundReplay:
                     env=e, slot=k, agent=agent)
 
 
+    def sample_collective(self, batch_size: int, n_step: int, gamma: float, generator: torch.Generator | None = None):
+        """``sample`` plus every sampled transition's SIBLINGS - the agents that acted in the same env round
+        (what collective_experience_collector.py:70-80 records as ``info.indices``): here they are simply the
+        ``acted`` set of the same record.  Adds ``active_obs`` [M, 8N+1], ``active_act`` [M], ``segment`` [M]
+        (rows ordered by experience, then agent id) for :class:`melissa_amd.policy.DGNPolicy`."""
+        b = self.sample(batch_size, n_step, gamma, generator)
+        e, k = b["env"], b["slot"]
+        bits = (self.acted[e, k][:, None] & self._bits) != 0                       # [bs, N]
+        seg, agent = torch.nonzero(bits, as_tuple=True)                            # row-major: by experience, then id
+        obs = torch.cat([self.obs[e[seg], k[seg]], agent.float()[:, None]], dim=1)
+        b.update(active_obs=obs, active_act=self.act[e[seg], k[seg], agent].long(), segment=seg, sibling_mask=self.acted[e, k])
+        return b
+
+    def export_transitions(self):
+        """The buffer in the reference collectors' layout (multi_agent_collector.py:229-271,
+        collective_experience_collector.py:70-80,251-309): one row per (record, acting agent) transition with
+        ``buffer_id = env * N + agent`` (the Tianshou VectorReplayBuffer sub-buffer it is routed to) and
+        ``indices`` [T, N]: row of each SIBLING transition (agent j acted in the same env round) or -1.
+        Rows are ordered by env, record age (oldest first), agent id.  Host NumPy; synchronises."""
+        import numpy as np
+        valid = self._valid_slots()
+        B, K, n = self.B, self.K, self.n
+        # oldest-first slot order per env: the ring's next write position is cursor % K
+        start = torch.where(self.cursor.long() > K, self.cursor.long() % K, torch.zeros_like(self.cursor.long()))
+        order = (start[:, None] + torch.arange(K, device=start.device)[None, :]) % K          # [B, K]
+        env = torch.arange(B, device=start.device)[:, None].expand(B, K)
+        ok = valid.gather(1, order)
+        e, k = env[ok], order[ok]
+        bits = (self.acted[e, k][:, None] & self._bits) != 0
+        rec, agent = torch.nonzero(bits, as_tuple=True)
+        T = rec.numel()
+        row_of = torch.full((e.numel(), n), -1, dtype=torch.int64, device=start.device)
+        row_of[rec, agent] = torch.arange(T, device=start.device)
+        ee, kk = e[rec], k[rec]
+        idx_col = agent.float()[:, None]
+        out = dict(obs=torch.cat([self.obs[ee, kk], idx_col], 1), obs_next_matrix=self.obs_next[ee, kk],
+                   act=self.act[ee, kk, agent].long(), rew=self.rew[ee, kk], rew_agent=self.rew[ee, kk, agent],
+                   done=(self.done[ee, kk] & self._bits[agent]) != 0, env_id=ee, agent_id=agent,
+                   buffer_id=ee * n + agent, record_slot=kk, episode=self.episode[ee, kk].long(), indices=row_of[rec])
+        return {name: t.cpu().numpy() for name, t in out.items()}
+
+
 class DQNLearner:
     """n-step DQN update over a :class:`RoundReplay` (the learn half of the reference's training loop,
     l_dgn.py:246-261 -> [3P] DQNPolicy.process_fn / learn): target = ret + boot_w * max_a Q_target(boot_obs)
@@ -114,3 +156,22 @@ class DQNLearner:
                 best = q_next.max(dim=1).values
             returns = b["ret"] + b["boot_w"] * best
         return self.policy.learn(dict(obs=b["obs"], act=b["act"], returns=returns), grad_hook=self.grad_hook)
+
+
+class DGNLearner(DQNLearner):
+    """DGN-R update (policies/dgn.py): the sampled experiences' n-step returns regress on the summed Q of their
+    siblings; one batched forward over all sibling observations (policy = :class:`melissa_amd.policy.DGNPolicy`)."""
+
+    def step(self) -> dict:
+        b = self.replay.sample_collective(self.batch_size, self.n_step, self.gamma, self.gen)
+        with torch.no_grad():
+            target_net = self.policy.model_old if getattr(self.policy, "_target", False) else self.policy.model
+            fwd = (lambda net, o: net.hip_forward(o)) if b["boot_obs"].is_cuda else (lambda net, o: net.torch_forward(o))
+            q_next = fwd(target_net, b["boot_obs"])
+            if self.policy._is_double:
+                best = q_next.gather(1, fwd(self.policy.model, b["boot_obs"]).argmax(dim=1, keepdim=True)).squeeze(1)
+            else:
+                best = q_next.max(dim=1).values
+            returns = b["ret"] + b["boot_w"] * best
+        return self.policy.learn(dict(active_obs=b["active_obs"], active_act=b["active_act"], segment=b["segment"],
+                                      returns=returns), grad_hook=self.grad_hook)

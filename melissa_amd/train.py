@@ -20,8 +20,8 @@ from . import parallel
 from .collect import RoundLoop
 from .env import HipGraphVectorEnv, synthetic_graph_pool
 from .networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
-from .policy import DQNPolicy
-from .replay import DQNLearner, RoundReplay
+from .policy import DGNPolicy, DQNPolicy
+from .replay import DGNLearner, DQNLearner, RoundReplay
 
 
 def build_network(name: str, n_nodes: int, device, hidden=128, heads=4):
@@ -43,14 +43,16 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     torch.manual_seed(seed)                                    # same init everywhere, then broadcast anyway
     net = build_network(model, n_nodes, device)
     parallel.broadcast_parameters(net, src=0)
-    policy = DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=lr), discount_factor=gamma,
-                       estimation_step=n_step, target_update_freq=target_update_freq)
+    # dgn_r.py trains with DGNPolicy (summed sibling Q, policies/dgn.py); l_dgn.py / hl_dgn.py with DQNPolicy
+    policy_cls, learner_cls = (DGNPolicy, DGNLearner) if model == "dgn_r" else (DQNPolicy, DQNLearner)
+    policy = policy_cls(net, torch.optim.Adam(net.parameters(), lr=lr), discount_factor=gamma,
+                        estimation_step=n_step, target_update_freq=target_update_freq)
     graphs = synthetic_graph_pool(n_nodes, 16, first_seed=0)
     venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device, max_moves=48,
                              seed=1000 + rank * envs, construct_like_reference=False)
     replay = RoundReplay(envs, n_nodes, replay_rounds, device)
     loop = RoundLoop(venv, policy, episodes_per_env=16, seed=1000 + rank * envs, eps=eps, replay=replay)
-    learner = DQNLearner(policy, replay, batch_size=batch_size, n_step=n_step, gamma=gamma,
+    learner = learner_cls(policy, replay, batch_size=batch_size, n_step=n_step, gamma=gamma,
                          grad_hook=parallel.FlatGradAllReducer(net), seed=seed + rank)
     with torch.no_grad():
         loop.run(max(n_step + 1, 8))                           # pre-fill (l_dgn.py:201)

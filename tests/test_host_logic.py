@@ -113,3 +113,134 @@ def test_policy_manager_keeps_batch_order():
     rand_mask = np.random.rand(6) < 1.0
     q = np.random.rand(6, 2) + mask
     assert act.tolist() == q.argmax(1).tolist() and rand_mask.all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# DGN-R learn path (policies/dgn.py) and the collective collector's sibling bookkeeping
+# ---------------------------------------------------------------------------------------------------
+def _filled_round_replay(n_envs=3, n=6, cap=5, rounds=7, seed=0):
+    """A RoundReplay filled on the CPU the way mel_env_round fills it (ring per env, cursor counts writes)."""
+    from melissa_amd.replay import RoundReplay
+    rng = np.random.RandomState(seed)
+    rp = RoundReplay(n_envs, n, cap, "cpu")
+    for r in range(rounds):
+        for e in range(n_envs):
+            k = r % cap
+            acted = rng.choice(n, size=rng.randint(1, n), replace=False)
+            m = 0
+            for a in acted:
+                m |= 1 << int(a)
+            rp.acted[e, k] = m
+            rp.done[e, k] = m if r % 4 == 3 else 0
+            rp.obs[e, k] = torch.from_numpy(rng.uniform(0, 1, 8 * n).astype(np.float32))
+            rp.obs_next[e, k] = torch.from_numpy(rng.uniform(0, 1, 8 * n).astype(np.float32))
+            rp.act[e, k] = torch.from_numpy(rng.randint(0, 2, n).astype(np.int8))
+            rp.rew[e, k] = torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32))
+            rp.episode[e, k] = r // 4
+            rp.cursor[e] = r + 1
+    return rp
+
+
+def test_export_transitions_sibling_indices():
+    """collective_experience_collector.py:70-80: ``indices[j]`` of an experience = buffer index of agent j's
+    transition of the SAME env round, -1 if agent j did not act; buffer_id = env * N + agent (:251-256)."""
+    rp = _filled_round_replay()
+    ex = rp.export_transitions()
+    T = len(ex["act"])
+    assert T == len(rp) and ex["indices"].shape == (T, rp.n)
+    key = list(zip(ex["env_id"].tolist(), ex["record_slot"].tolist()))
+    for t in range(T):
+        e, k, i = int(ex["env_id"][t]), int(ex["record_slot"][t]), int(ex["agent_id"][t])
+        acted = int(rp.acted[e, k])
+        assert ex["buffer_id"][t] == e * rp.n + i and (acted >> i) & 1
+        for j in range(rp.n):
+            s = int(ex["indices"][t, j])
+            if (acted >> j) & 1:
+                assert key[s] == (e, k) and ex["agent_id"][s] == j
+            else:
+                assert s == -1
+        assert ex["indices"][t, i] == t                          # an experience is its own sibling (dgn.py sums it too)
+        np.testing.assert_array_equal(ex["obs"][t, :-1], rp.obs[e, k].numpy())
+        assert ex["obs"][t, -1] == i and ex["act"][t] == int(rp.act[e, k, i])
+        assert ex["rew_agent"][t] == float(rp.rew[e, k, i]) and bool(ex["done"][t]) == bool((int(rp.done[e, k]) >> i) & 1)
+    # oldest first inside an env: record order follows write order
+    for e in range(rp.B):
+        eps = ex["episode"][ex["env_id"] == e]
+        assert (np.diff(eps) >= 0).all()
+
+
+def test_dgn_learn_equals_the_reference_loop():
+    """One batched forward + segment sum == the per-experience loop of policies/dgn.py:31-64 (same loss, same
+    gradients), driven through the reference's own data layout (info.indices + active_obs.index)."""
+    from melissa_amd.policy import DGNPolicy
+    n = 6
+    rp = _filled_round_replay(n=n)
+    ex = rp.export_transitions()
+    rng = np.random.RandomState(1)
+    pick = rng.choice(len(ex["act"]), size=8, replace=False)
+    returns = rng.uniform(-1, 1, size=8).astype(np.float32)
+    # reference layout: batch.active_obs = the buffer rows named by the valid sibling indices (with repeats)
+    indices = ex["indices"][pick]
+    active_index = indices[indices >= 0]
+    active_obs, active_act = ex["obs"][active_index], ex["act"][active_index]
+    gather, segment = DGNPolicy.segments_from_indices(indices, active_index)
+
+    def make():
+        torch.manual_seed(4)
+        net = DGNRNetwork(5, 32, 2, 2, n, dueling_param=({"hidden_sizes": [64]}, {"hidden_sizes": [64]}), device="cpu",
+                          backend="torch")
+        return net
+
+    # (a) the reference's loop
+    net_a = make()
+    batch_q = []
+    for i in range(len(pick)):
+        rows = [int(np.where(active_index == idx)[0][0]) for idx in indices[i][indices[i] >= 0]]
+        q = net_a(torch.from_numpy(active_obs[rows]))[0]
+        batch_q.append(q[torch.arange(len(rows)), torch.from_numpy(active_act[rows])].sum())
+    loss_a = (torch.from_numpy(returns) - torch.stack(batch_q)).pow(2).mean()
+    loss_a.backward()
+    # (b) DGNPolicy.learn (lr = 0: only the gradients matter)
+    net_b = make()
+    pol = DGNPolicy(net_b, torch.optim.SGD(net_b.parameters(), lr=0.0))
+    out = pol.learn(dict(active_obs=torch.from_numpy(active_obs[gather]), active_act=active_act[gather],
+                         segment=segment, returns=returns))
+    assert abs(out["loss"] - float(loss_a.detach())) < 1e-6
+    for (name, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        if pa.grad is None:
+            assert pb.grad is None or float(pb.grad.abs().max()) == 0.0, name      # lin_skip: unused (dgn_r.py)
+            continue
+        torch.testing.assert_close(pb.grad, pa.grad, atol=1e-6, rtol=1e-5)
+    # huber variant (clip_loss_grad, dgn.py:59-62)
+    pol2 = DGNPolicy(make(), None, clip_loss_grad=True)
+    pol2.optim = torch.optim.SGD(pol2.model.parameters(), lr=0.0)
+    out2 = pol2.learn(dict(active_obs=torch.from_numpy(active_obs[gather]), active_act=active_act[gather],
+                           segment=segment, returns=returns))
+    want = torch.nn.functional.huber_loss(torch.stack(batch_q).detach().reshape(-1, 1), torch.from_numpy(returns).reshape(-1, 1))
+    assert abs(out2["loss"] - float(want)) < 1e-6
+
+
+def test_sample_collective_siblings_and_dgn_learner_step():
+    from melissa_amd.policy import DGNPolicy
+    from melissa_amd.replay import DGNLearner
+    n = 6
+    rp = _filled_round_replay(n=n)
+    g = torch.Generator().manual_seed(3)
+    b = rp.sample_collective(16, n_step=2, gamma=0.9, generator=g)
+    bits = ((b["sibling_mask"][:, None] >> torch.arange(n)) & 1).bool()
+    assert b["segment"].numel() == int(bits.sum()) and (torch.bincount(b["segment"], minlength=16) == bits.sum(1)).all()
+    for r in range(b["segment"].numel()):
+        i = int(b["segment"][r])
+        e, k, j = int(b["env"][i]), int(b["slot"][i]), int(b["active_obs"][r, -1])
+        assert bits[i, j] and int(b["active_act"][r]) == int(rp.act[e, k, j])
+        assert torch.equal(b["active_obs"][r, :-1], rp.obs[e, k])
+    assert all(bool(bits[i, int(b["agent"][i])]) for i in range(16))             # the experience itself is a sibling
+    torch.manual_seed(0)
+    net = DGNRNetwork(5, 32, 2, 2, n, dueling_param=({"hidden_sizes": [64]}, {"hidden_sizes": [64]}), device="cpu",
+                      backend="torch")
+    pol = DGNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-3), target_update_freq=2)
+    learner = DGNLearner(pol, rp, batch_size=8, n_step=2, gamma=0.9, seed=1)
+    before = [p.detach().clone() for p in net.parameters()]
+    losses = [learner.step()["loss"] for _ in range(3)]
+    assert all(np.isfinite(losses))
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
