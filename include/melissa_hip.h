@@ -176,6 +176,33 @@ mel_status mel_gemm_bf16(const void* A, int32_t lda, const void* W, const float*
                          int64_t M, int32_t N, int32_t K, int32_t relu, int32_t y_f32, int32_t tile, void* stream);
 mel_status mel_convert_bf16(const float* src, void* dst, int64_t count, void* stream);
 
+/* ---- learn path: attention and pool with hand-written backward ---------------------------
+ * Wrapped by torch.autograd.Function in melissa_amd/networks/autograd_ops.py; all buffers device fp32, row-major,
+ * rows = bs * n_nodes (row b*n + i = node i of graph b), HC = heads * channels in {128, 256, 512, 1024}.
+ *
+ * mel_radius_graph: adj[b*n + i] = sources of target i ([3P] radius_graph on the fp32 obs positions,
+ *   networks/common.py:47-48: strict <, first 33 hits, self excluded) - the mask the forward kernels build.
+ * mel_gat_forward: out = relu(conv(x) + bias) given the projections (kind MEL_CONV_GATV2: xl = lin_l(x) sources,
+ *   xr = lin_r(x) targets, att [HC], self-loops added, l_dgn.py:125-126; MEL_CONV_TRANSFORMER: xl = keys,
+ *   xv = values, xr = queries, no self-loops, bias null, dgn_r.py:103-104).
+ * mel_gat_backward: grad_out -> dxl (dxv) dxr datt dbias; dxl / dxv / datt / dbias must be ZERO on entry (they
+ *   are accumulated with fp32 atomics, so their last bits depend on the order of arrival).
+ * mel_pool_forward / backward: hl_dgn.py:105-108, pooled[b] = max / mean / add over nodes of x * dm;
+ *   arg [bs, HC] int32 = node of the first maximum (max only). */
+mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n_nodes, int32_t obs_stride, int32_t in_dim,
+                            uint64_t* adj, void* stream);
+mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, const float* att, const float* bias,
+                           const uint64_t* adj, int64_t bs, int32_t n_nodes, int32_t heads, int32_t channels,
+                           int32_t kind, float* out, void* stream);
+mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, const float* att, const uint64_t* adj,
+                            const float* out, const float* grad_out, int64_t bs, int32_t n_nodes, int32_t heads,
+                            int32_t channels, int32_t kind, float* dxl, float* dxv, float* dxr, float* datt,
+                            float* dbias, void* stream);
+mel_status mel_pool_forward(const float* x, const float* dm, int64_t bs, int32_t n_nodes, int32_t hc,
+                            int32_t aggregator, float* pooled, int32_t* arg, void* stream);
+mel_status mel_pool_backward(const float* grad_pooled, const float* dm, const int32_t* arg, int64_t bs,
+                             int32_t n_nodes, int32_t hc, int32_t aggregator, float* dx, void* stream);
+
 /* HL-DGN for the round-batched loop: logits depend only on the env (hl_dgn.py:108 pools over the graph and
  * ignores the controlling index), so one row per env serves all of a round's agents.  obs: device fp32
  * [bs, obs_stride], row b = obs_matrix of env b, obs_stride >= n_nodes*(in_dim+3), index column not read. */

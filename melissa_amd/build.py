@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmelissa_hip.so")
-SOURCES = ["fwd.hip", "env.hip"]
-HEADERS = ["common.hpp", "gemm_f32.hpp", os.path.join("..", "..", "include", "melissa_hip.h")]
+SOURCES = ["fwd.hip", "env.hip", "grad.hip"]
+HEADERS = ["common.hpp", "gemm_f32.hpp", "gemm_bf16.hpp", os.path.join("..", "..", "include", "melissa_hip.h")]
 
 
 def _hipcc() -> str:

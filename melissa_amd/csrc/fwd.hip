@@ -230,6 +230,21 @@ __device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, i
     return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
 }
 
+// standalone adjacency for the learn path (one wave per observation row)
+__global__ __launch_bounds__(256) void radius_graph_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
+                                                           int node_cols, uint64_t* __restrict__ adj) {
+    const int lane = lane_id();
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    float x = 0.f, y = 0.f;
+    if (lane < n) {
+        const float* p = obs + (size_t)b * obs_stride + lane * node_cols;
+        x = p[0], y = p[1];
+    }
+    const uint64_t m = radius_sources(x, y, lane, n);
+    if (lane < n) adj[(size_t)b * n + lane] = m;
+}
+
 // agent_mask == null: one agent per row, taken from the index column (common.py:63)
 __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict__ obs, int bs, int n,
                                                          int obs_stride, int node_cols,
@@ -1397,6 +1412,17 @@ mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float
     GemmArgs g;
     g.A = A, g.lda = lda, g.W = W, g.bias = bias, g.Y = Y, g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K, g.relu = relu;
     return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_f32", -1, tile);
+}
+
+mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n, int32_t obs_stride, int32_t in_dim, uint64_t* adj,
+                            void* stream) {
+    if (!obs || !adj || bs < 1 || bs > (1 << 24) || n < 1 || n > MEL_MAX_NODES || in_dim < 1 || in_dim > 8 ||
+        obs_stride < n * (in_dim + 3))
+        return fail(MEL_ERR_INVALID_ARG, "mel_radius_graph: bad arguments");
+    clear_stale_error();
+    hipLaunchKernelGGL(radius_graph_kernel, dim3((bs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), obs, (int)bs, n,
+                       obs_stride, in_dim + 3, adj);
+    return check_launch("mel_radius_graph");
 }
 
 mel_status mel_gemm_bf16(const void* A, int32_t lda, const void* W, const float* bias, void* Y, int32_t ldy,

@@ -1,0 +1,363 @@
+// Learn-path kernels: the edge-softmax + aggregate of GATv2Conv / TransformerConv over FULL
+// graphs with a hand-written backward, and the global max / mean / add pool with its backward.  The Python side
+// wraps them in torch.autograd.Function (melissa_amd/networks/autograd_ops.py); the dense projections around
+// them are plain library GEMMs under torch autograd.
+//
+//   forward   out[i] = relu( sum_j alpha_ij s_j + bias )          alpha = softmax_j(e_ij), eps 1e-16 (PyG)
+//     GATv2        e_ij = att . leaky_relu(x_r[i] + x_l[j], 0.2),  s_j = x_l[j],  j in adj(i) + {i}   (A.1)
+//     Transformer  e_ij = (q[i] . k[j]) / sqrt(C),                 s_j = v[j],    j in adj(i)         (A.2)
+//   backward (g = grad_out * (out > 0)):
+//     d alpha_ij = g . s_j (per head)        S_i = sum_j alpha_ij d alpha_ij       d e_ij = alpha_ij (d alpha_ij - S_i)
+//     GATv2        dz = d e_ij * att * leaky'(z),  d x_r[i] += dz,  d x_l[j] += alpha_ij g + dz,
+//                  d att += d e_ij * leaky(z),     d bias += g
+//     Transformer  d q[i] += d e_ij k[j] / sqrt(C),  d k[j] += d e_ij q[i] / sqrt(C),  d v[j] += alpha_ij g
+//
+// One wavefront per target row, 64 lanes x VPL channels = heads x C (same mapping as the inference kernels of
+// fwd.hip).  The backward makes three passes over the target's source rows (softmax statistics, S_i, gradients)
+// instead of storing per-edge coefficients; source-row gradients are accumulated with fp32 global atomics (each
+// row receives from ~deg targets), so their summation order - not their value beyond rounding - varies.
+#include "common.hpp"
+
+namespace mel {
+
+template <int VPL>
+struct GVec {
+    float v[VPL];
+};
+
+template <int VPL>
+__device__ __forceinline__ GVec<VPL> gload(const float* p) {
+    GVec<VPL> r;
+    if constexpr (VPL >= 4) {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(p)[i];
+            r.v[4 * i] = t.x, r.v[4 * i + 1] = t.y, r.v[4 * i + 2] = t.z, r.v[4 * i + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) r.v[i] = p[i];
+    }
+    return r;
+}
+
+template <int VPL>
+__device__ __forceinline__ void gstore(float* p, const GVec<VPL>& r) {
+    if constexpr (VPL >= 4) {
+#pragma unroll
+        for (int i = 0; i < VPL / 4; ++i)
+            reinterpret_cast<float4*>(p)[i] = make_float4(r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) p[i] = r.v[i];
+    }
+}
+
+// sum over the lanes of one head (lanes_per_head adjacent lanes, a power of two)
+__device__ __forceinline__ float head_total(float s, int lanes_per_head) {
+    for (int o = lanes_per_head >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+
+struct GradArgs {
+    const float* xl;        // GATv2: x_l (sources);  Transformer: keys
+    const float* xv;        // Transformer: values (GATv2: = xl)
+    const float* xr;        // GATv2: x_r (targets);  Transformer: queries
+    const float* att;       // [HC] GATv2 only
+    const float* bias;      // [HC] or null
+    const uint64_t* adj;    // [rows] sources of target row (bit j = node j of the same graph), self excluded
+    int rows, n, lanes_per_head, kind;
+    float scale;            // Transformer: 1 / sqrt(C)
+    float* out;             // [rows, HC] relu(out + bias)
+    // backward
+    const float* gout;      // [rows, HC]
+    float* dxl;             // zero-initialised by the caller (atomics)
+    float* dxv;
+    float* dxr;
+    float* datt;            // [HC] zero-initialised
+    float* dbias;           // [HC] zero-initialised, or null
+};
+
+template <int VPL, int KIND>
+__device__ __forceinline__ float edge_score(const GradArgs& a, const GVec<VPL>& xr, const GVec<VPL>& xl, const GVec<VPL>& att) {
+    float t = 0.f;
+    if constexpr (KIND == MEL_CONV_GATV2) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float z = xr.v[i] + xl.v[i];
+            t = fmaf(att.v[i], fmaxf(z, 0.2f * z), t);
+        }
+        return head_total(t, a.lanes_per_head);
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) t = fmaf(xr.v[i], xl.v[i], t);
+        return head_total(t, a.lanes_per_head) * a.scale;
+    }
+}
+
+// closed neighbourhood for GATv2 (self-loop added, A.1), open for TransformerConv (A.2)
+template <int KIND>
+__device__ __forceinline__ uint64_t sources_of(const GradArgs& a, int r) {
+    const uint64_t m = a.adj[r];
+    return KIND == MEL_CONV_GATV2 ? (m | (1ull << (r % a.n))) : m;
+}
+
+template <int VPL, int KIND>
+__global__ __launch_bounds__(256) void gat_full_forward_kernel(GradArgs a) {
+    constexpr int HC = 64 * VPL;
+    const int lane = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.rows) return;
+    const int g0 = (r / a.n) * a.n;                          // first row of this graph
+    GVec<VPL> att, bias;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) att.v[i] = 0.f, bias.v[i] = 0.f;
+    if (KIND == MEL_CONV_GATV2) att = gload<VPL>(a.att + lane * VPL);
+    if (a.bias) bias = gload<VPL>(a.bias + lane * VPL);
+    const GVec<VPL> xr = gload<VPL>(a.xr + (size_t)r * HC + lane * VPL);
+    float m = -INFINITY, l = 0.f;
+    GVec<VPL> acc;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
+    for (uint64_t s = sources_of<KIND>(a, r); s; s &= s - 1) {
+        const size_t row = (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL;
+        const GVec<VPL> xl = gload<VPL>(a.xl + row);
+        const float e = edge_score<VPL, KIND>(a, xr, xl, att);
+        const float mn = fmaxf(m, e);
+        const float rs = expf(m - mn), pe = expf(e - mn);
+        l = l * rs + pe;
+        const GVec<VPL> sv = (KIND == MEL_CONV_GATV2) ? xl : gload<VPL>(a.xv + row);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc.v[i] = fmaf(pe, sv.v[i], acc.v[i] * rs);
+        m = mn;
+    }
+    const float inv = 1.f / (l + 1e-16f);
+    GVec<VPL> o;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) o.v[i] = fmaxf(acc.v[i] * inv + bias.v[i], 0.f);
+    gstore<VPL>(a.out + (size_t)r * HC + lane * VPL, o);
+}
+
+template <int VPL, int KIND>
+__global__ __launch_bounds__(256) void gat_full_backward_kernel(GradArgs a) {
+    constexpr int HC = 64 * VPL;
+    const int lane = lane_id();
+    GVec<VPL> att, datt, dbias;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) att.v[i] = 0.f, datt.v[i] = 0.f, dbias.v[i] = 0.f;
+    if (KIND == MEL_CONV_GATV2) att = gload<VPL>(a.att + lane * VPL);
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < a.rows; r += gridDim.x * 4) {
+        const int g0 = (r / a.n) * a.n;
+        const size_t me = (size_t)r * HC + lane * VPL;
+        const GVec<VPL> xr = gload<VPL>(a.xr + me);
+        GVec<VPL> g = gload<VPL>(a.gout + me);
+        {
+            const GVec<VPL> o = gload<VPL>(a.out + me);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                g.v[i] = o.v[i] > 0.f ? g.v[i] : 0.f;          // relu'
+                dbias.v[i] += g.v[i];
+            }
+        }
+        const uint64_t src = sources_of<KIND>(a, r);
+        // pass 1: softmax statistics
+        float m = -INFINITY, l = 0.f;
+        for (uint64_t s = src; s; s &= s - 1) {
+            const GVec<VPL> xl = gload<VPL>(a.xl + (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL);
+            const float e = edge_score<VPL, KIND>(a, xr, xl, att);
+            const float mn = fmaxf(m, e);
+            l = l * expf(m - mn) + expf(e - mn);
+            m = mn;
+        }
+        const float inv = 1.f / (l + 1e-16f);
+        // pass 2: S = sum_j alpha_ij (g . s_j)
+        float S = 0.f;
+        for (uint64_t s = src; s; s &= s - 1) {
+            const size_t row = (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL;
+            const GVec<VPL> xl = gload<VPL>(a.xl + row);
+            const float alpha = expf(edge_score<VPL, KIND>(a, xr, xl, att) - m) * inv;
+            const GVec<VPL> sv = (KIND == MEL_CONV_GATV2) ? xl : gload<VPL>(a.xv + row);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) d = fmaf(g.v[i], sv.v[i], d);
+            S = fmaf(alpha, head_total(d, a.lanes_per_head), S);
+        }
+        // pass 3: gradients
+        GVec<VPL> dxr;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) dxr.v[i] = 0.f;
+        for (uint64_t s = src; s; s &= s - 1) {
+            const size_t row = (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL;
+            const GVec<VPL> xl = gload<VPL>(a.xl + row);
+            const float alpha = expf(edge_score<VPL, KIND>(a, xr, xl, att) - m) * inv;
+            const GVec<VPL> sv = (KIND == MEL_CONV_GATV2) ? xl : gload<VPL>(a.xv + row);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) d = fmaf(g.v[i], sv.v[i], d);
+            const float de = alpha * (head_total(d, a.lanes_per_head) - S);
+            if constexpr (KIND == MEL_CONV_GATV2) {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    const float z = xr.v[i] + xl.v[i];
+                    const float dz = de * att.v[i] * (z > 0.f ? 1.f : 0.2f);
+                    datt.v[i] = fmaf(de, fmaxf(z, 0.2f * z), datt.v[i]);
+                    dxr.v[i] += dz;
+                    atomicAdd(a.dxl + row + i, fmaf(alpha, g.v[i], dz));
+                }
+            } else {
+                const float des = de * a.scale;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                    dxr.v[i] = fmaf(des, xl.v[i], dxr.v[i]);
+                    atomicAdd(a.dxl + row + i, des * xr.v[i]);
+                    atomicAdd(a.dxv + row + i, alpha * g.v[i]);
+                }
+            }
+        }
+        gstore<VPL>(a.dxr + me, dxr);
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        if (KIND == MEL_CONV_GATV2) atomicAdd(a.datt + lane * VPL + i, datt.v[i]);
+        if (a.dbias) atomicAdd(a.dbias + lane * VPL + i, dbias.v[i]);
+    }
+}
+
+// ---- global pool over the graph of (x * dm): hl_dgn.py:105-108 -------------------------------------------
+// one thread per (graph, channel); arg = node of the first maximum (max only)
+__global__ __launch_bounds__(256) void pool_forward_kernel(const float* __restrict__ x, const float* __restrict__ dm,
+                                                           int bs, int n, int hc, int agg, float* __restrict__ pooled,
+                                                           int32_t* __restrict__ arg) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)bs * hc) return;
+    const int b = (int)(t / hc), c = (int)(t % hc);
+    float best = (agg == MEL_AGG_MAX) ? -INFINITY : 0.f;
+    int at = 0;
+    for (int i = 0; i < n; ++i) {
+        const float v = x[((size_t)b * n + i) * hc + c] * dm[(size_t)b * n + i];
+        if (agg == MEL_AGG_MAX) {
+            if (v > best) best = v, at = i;
+        } else {
+            best += v;
+        }
+    }
+    if (agg == MEL_AGG_MEAN) best /= (float)n;
+    pooled[t] = best;
+    if (arg) arg[t] = at;
+}
+
+__global__ __launch_bounds__(256) void pool_backward_kernel(const float* __restrict__ g, const float* __restrict__ dm,
+                                                            const int32_t* __restrict__ arg, int bs, int n, int hc, int agg,
+                                                            float* __restrict__ dx) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)bs * n * hc) return;
+    const int c = (int)(t % hc);
+    const long row = t / hc;
+    const int b = (int)(row / n), i = (int)(row % n);
+    const float gv = g[(size_t)b * hc + c];
+    float v;
+    if (agg == MEL_AGG_MAX) v = (arg[(size_t)b * hc + c] == i) ? gv : 0.f;
+    else if (agg == MEL_AGG_MEAN) v = gv / (float)n;
+    else v = gv;
+    dx[t] = v * dm[row];
+}
+
+static mel_status check_gat(const float* xl, const float* xr, const uint64_t* adj, int64_t bs, int n, int heads, int channels,
+                            int kind, const float* att, const float* xv) {
+    if (!xl || !xr || !adj) return fail(MEL_ERR_INVALID_ARG, "gat: null pointer");
+    if (bs < 1 || n < 1 || n > MEL_MAX_NODES || bs * n > (1ll << 28)) return fail(MEL_ERR_INVALID_ARG, "gat: bs=%ld n=%d", (long)bs, n);
+    const int hc = heads * channels;
+    if (hc != 128 && hc != 256 && hc != 512 && hc != 1024)
+        return fail(MEL_ERR_UNSUPPORTED, "gat: heads*channels = %d not in {128,256,512,1024}", hc);
+    const int vpl = hc / 64;
+    if (channels % vpl != 0 || ((channels / vpl) & (channels / vpl - 1)))
+        return fail(MEL_ERR_UNSUPPORTED, "gat: channels per head (%d) must be a power-of-two multiple of %d", channels, vpl);
+    if (kind == MEL_CONV_GATV2 && !att) return fail(MEL_ERR_INVALID_ARG, "gat: att is null");
+    if (kind == MEL_CONV_TRANSFORMER && !xv) return fail(MEL_ERR_INVALID_ARG, "gat: values are null");
+    if (kind != MEL_CONV_GATV2 && kind != MEL_CONV_TRANSFORMER) return fail(MEL_ERR_INVALID_ARG, "gat: kind %d", kind);
+    return MEL_OK;
+}
+
+#define MEL_GRAD_DISPATCH(KERNEL, grid)                                                                      \
+    switch (hc / 64) {                                                                                        \
+        case 2: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<2, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
+                else hipLaunchKernelGGL((KERNEL<2, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
+        case 4: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<4, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
+                else hipLaunchKernelGGL((KERNEL<4, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
+        case 8: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<8, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
+                else hipLaunchKernelGGL((KERNEL<8, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
+        default: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<16, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a); \
+                 else hipLaunchKernelGGL((KERNEL<16, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;          \
+    }
+
+}  // namespace mel
+
+using namespace mel;
+
+extern "C" {
+
+mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, const float* att, const float* bias,
+                           const uint64_t* adj, int64_t bs, int32_t n, int32_t heads, int32_t channels, int32_t kind,
+                           float* out, void* stream) {
+    if (mel_status st = check_gat(xl, xr, adj, bs, n, heads, channels, kind, att, xv)) return st;
+    if (!out) return fail(MEL_ERR_INVALID_ARG, "gat: out is null");
+    clear_stale_error();
+    const int hc = heads * channels;
+    GradArgs a{};
+    a.xl = xl, a.xv = (kind == MEL_CONV_GATV2) ? xl : xv, a.xr = xr, a.att = att, a.bias = bias, a.adj = adj;
+    a.rows = (int)(bs * n), a.n = n, a.lanes_per_head = channels / (hc / 64), a.kind = kind;
+    a.scale = 1.0f / sqrtf((float)channels), a.out = out;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int grid = (a.rows + 3) / 4;
+    MEL_GRAD_DISPATCH(gat_full_forward_kernel, grid)
+    return check_launch("mel_gat_forward");
+}
+
+mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, const float* att, const uint64_t* adj,
+                            const float* out, const float* grad_out, int64_t bs, int32_t n, int32_t heads,
+                            int32_t channels, int32_t kind, float* dxl, float* dxv, float* dxr, float* datt,
+                            float* dbias, void* stream) {
+    if (mel_status st = check_gat(xl, xr, adj, bs, n, heads, channels, kind, att, xv)) return st;
+    if (!out || !grad_out || !dxl || !dxr || (kind == MEL_CONV_GATV2 && !datt) || (kind == MEL_CONV_TRANSFORMER && !dxv))
+        return fail(MEL_ERR_INVALID_ARG, "gat backward: null gradient buffer");
+    clear_stale_error();
+    const int hc = heads * channels;
+    GradArgs a{};
+    a.xl = xl, a.xv = (kind == MEL_CONV_GATV2) ? xl : xv, a.xr = xr, a.att = att, a.adj = adj;
+    a.rows = (int)(bs * n), a.n = n, a.lanes_per_head = channels / (hc / 64), a.kind = kind;
+    a.scale = 1.0f / sqrtf((float)channels);
+    a.out = const_cast<float*>(out), a.gout = grad_out, a.dxl = dxl, a.dxv = dxv, a.dxr = dxr, a.datt = datt, a.dbias = dbias;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int grid = (a.rows + 3) / 4;
+    if (grid > 2048) grid = 2048;                 // grid-stride: bounds the number of datt / dbias atomics
+    MEL_GRAD_DISPATCH(gat_full_backward_kernel, grid)
+    return check_launch("mel_gat_backward");
+}
+
+mel_status mel_pool_forward(const float* x, const float* dm, int64_t bs, int32_t n, int32_t hc, int32_t aggregator,
+                            float* pooled, int32_t* arg, void* stream) {
+    if (!x || !dm || !pooled || bs < 1 || n < 1 || hc < 1 || bs * n * (int64_t)hc > (1ll << 31))
+        return fail(MEL_ERR_INVALID_ARG, "pool: bad arguments");
+    if (aggregator < MEL_AGG_MAX || aggregator > MEL_AGG_ADD) return fail(MEL_ERR_INVALID_ARG, "aggregator %d", aggregator);
+    if (aggregator == MEL_AGG_MAX && !arg) return fail(MEL_ERR_INVALID_ARG, "pool: max needs the arg buffer");
+    clear_stale_error();
+    const long total = (long)bs * hc;
+    hipLaunchKernelGGL(pool_forward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, dm,
+                       (int)bs, n, hc, aggregator, pooled, arg);
+    return check_launch("mel_pool_forward");
+}
+
+mel_status mel_pool_backward(const float* grad_pooled, const float* dm, const int32_t* arg, int64_t bs, int32_t n,
+                             int32_t hc, int32_t aggregator, float* dx, void* stream) {
+    if (!grad_pooled || !dm || !dx || bs < 1 || n < 1 || hc < 1 || bs * n * (int64_t)hc > (1ll << 31))
+        return fail(MEL_ERR_INVALID_ARG, "pool backward: bad arguments");
+    if (aggregator < MEL_AGG_MAX || aggregator > MEL_AGG_ADD) return fail(MEL_ERR_INVALID_ARG, "aggregator %d", aggregator);
+    if (aggregator == MEL_AGG_MAX && !arg) return fail(MEL_ERR_INVALID_ARG, "pool backward: max needs the arg buffer");
+    clear_stale_error();
+    const long total = (long)bs * n * hc;
+    hipLaunchKernelGGL(pool_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       grad_pooled, dm, arg, (int)bs, n, hc, aggregator, dx);
+    return check_launch("mel_pool_backward");
+}
+
+}  // extern "C"

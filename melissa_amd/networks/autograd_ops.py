@@ -1,0 +1,108 @@
+"""torch.autograd.Function wrappers of the learn-path HIP kernels (csrc/grad.hip).
+
+``gat_attention``  relu(GATv2Conv / TransformerConv) given the dense projections, forward AND backward in HIP
+                   (edge softmax + aggregation; l_dgn.py:125-126,133-134, hl_dgn.py:101-102, dgn_r.py:103-113);
+``graph_pool``     (x * dm) -> global max / mean / add pool with its backward (hl_dgn.py:105-108);
+``radius_graph``   the fp32 radius adjacency as uint64 source masks (networks/common.py:47-48), no gradient.
+
+The projections (lin_l / lin_r / key / query / value, encoder, heads) stay ``nn.Linear`` under torch autograd -
+plain library GEMMs.  These ops need a ROCm device and fail loudly without the library: no CPU fallback (the
+CPU autograd formulation is ``gatv2_dense`` / ``transformer_dense`` in common.py).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+
+def _stream(t: torch.Tensor):
+    return _lib.current_stream_ptr(t.device)
+
+
+def radius_graph(obs: torch.Tensor, n_nodes: int, in_dim: int) -> torch.Tensor:
+    """obs: CUDA fp32 [bs, >= n*(in_dim+3)] -> int64 [bs*n] bit patterns (bit j = node j is a source)."""
+    assert obs.is_cuda and obs.dtype == torch.float32 and obs.stride(-1) == 1
+    bs = obs.shape[0]
+    adj = torch.empty(bs * n_nodes, dtype=torch.int64, device=obs.device)
+    _lib.check(_lib.load().mel_radius_graph(obs.data_ptr(), bs, n_nodes, obs.stride(0), in_dim, adj.data_ptr(), _stream(obs)),
+               "mel_radius_graph")
+    return adj
+
+
+class _GatAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xl, xv, xr, att, bias, adj, n_nodes, heads, channels, kind):
+        lib = _lib.load()
+        xl, xr = xl.contiguous(), xr.contiguous()
+        xv = xv.contiguous() if xv is not None else None
+        rows = xl.shape[0]
+        out = torch.empty(rows, heads * channels, dtype=torch.float32, device=xl.device)
+        _lib.check(lib.mel_gat_forward(xl.data_ptr(), xv.data_ptr() if xv is not None else None, xr.data_ptr(),
+                                       att.data_ptr() if att is not None else None,
+                                       bias.data_ptr() if bias is not None else None, adj.data_ptr(), rows // n_nodes,
+                                       n_nodes, heads, channels, kind, out.data_ptr(), _stream(xl)), "mel_gat_forward")
+        ctx.save_for_backward(xl, xv, xr, att, adj, out)
+        ctx.meta = (n_nodes, heads, channels, kind, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        xl, xv, xr, att, adj, out = ctx.saved_tensors
+        n_nodes, heads, channels, kind, has_bias = ctx.meta
+        grad_out = grad_out.contiguous()
+        dxl, dxr = torch.zeros_like(xl), torch.empty_like(xr)
+        dxv = torch.zeros_like(xv) if xv is not None else None
+        datt = torch.zeros(heads * channels, dtype=torch.float32, device=xl.device) if att is not None else None
+        dbias = torch.zeros(heads * channels, dtype=torch.float32, device=xl.device) if has_bias else None
+        p = lambda t: t.data_ptr() if t is not None else None
+        _lib.check(lib.mel_gat_backward(xl.data_ptr(), p(xv), xr.data_ptr(), p(att), adj.data_ptr(), out.data_ptr(),
+                                        grad_out.data_ptr(), xl.shape[0] // n_nodes, n_nodes, heads, channels, kind,
+                                        dxl.data_ptr(), p(dxv), dxr.data_ptr(), p(datt), p(dbias), _stream(xl)),
+                   "mel_gat_backward")
+        if datt is not None:
+            datt = datt.view_as(att)
+        return dxl, dxv, dxr, datt, dbias, None, None, None, None, None
+
+
+def gat_attention(xl, xr, att, bias, adj, n_nodes: int, heads: int, channels: int) -> torch.Tensor:
+    """relu(GATv2 attention + bias): xl = lin_l(x) (sources), xr = lin_r(x) (targets), [bs*n, heads*channels]."""
+    return _GatAttention.apply(xl, None, xr, att, bias, adj, n_nodes, heads, channels, _lib.CONV_GATV2)
+
+
+def transformer_attention(k, v, q, adj, n_nodes: int, heads: int, channels: int) -> torch.Tensor:
+    """relu(TransformerConv(root_weight=False)) given key / value / query projections."""
+    return _GatAttention.apply(k, v, q, None, None, adj, n_nodes, heads, channels, _lib.CONV_TRANSFORMER)
+
+
+class _GraphPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dm, n_nodes, aggregator):
+        lib = _lib.load()
+        x, dm = x.contiguous(), dm.contiguous().float()
+        hc = x.shape[1]
+        bs = x.shape[0] // n_nodes
+        pooled = torch.empty(bs, hc, dtype=torch.float32, device=x.device)
+        arg = torch.empty(bs, hc, dtype=torch.int32, device=x.device) if aggregator == 0 else None
+        _lib.check(lib.mel_pool_forward(x.data_ptr(), dm.data_ptr(), bs, n_nodes, hc, aggregator, pooled.data_ptr(),
+                                        arg.data_ptr() if arg is not None else None, _stream(x)), "mel_pool_forward")
+        ctx.save_for_backward(dm, arg)
+        ctx.meta = (bs, n_nodes, hc, aggregator)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, grad_pooled):
+        lib = _lib.load()
+        dm, arg = ctx.saved_tensors
+        bs, n_nodes, hc, aggregator = ctx.meta
+        grad_pooled = grad_pooled.contiguous()
+        dx = torch.empty(bs * n_nodes, hc, dtype=torch.float32, device=grad_pooled.device)
+        _lib.check(lib.mel_pool_backward(grad_pooled.data_ptr(), dm.data_ptr(), arg.data_ptr() if arg is not None else None,
+                                         bs, n_nodes, hc, aggregator, dx.data_ptr(), _stream(grad_pooled)), "mel_pool_backward")
+        return dx, None, None, None
+
+
+def graph_pool(x: torch.Tensor, dm: torch.Tensor, n_nodes: int, aggregator: str) -> torch.Tensor:
+    """x [bs*n, HC], dm [bs*n] decision-maker flags (no gradient) -> [bs, HC]."""
+    return _GraphPool.apply(x, dm.reshape(-1), n_nodes, _lib.AGG[aggregator])

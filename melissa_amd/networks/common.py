@@ -346,6 +346,32 @@ def transformer_dense(conv: TransformerConv, x: torch.Tensor, adj: torch.Tensor)
     return torch.einsum("bijh,bjhc->bihc", alpha, v).reshape(bs * n, h * c)
 
 
+def use_hip_autograd(module, obs: torch.Tensor) -> bool:
+    """Learn path on a ROCm device: edge softmax / aggregation / pool run as HIP kernels with hand-written
+    backward (autograd_ops.py) unless the module opts out with ``learn_kernels = "dense"``; CPU tensors always take
+    the dense torch formulation."""
+    return obs.is_cuda and getattr(module, "learn_kernels", "hip") == "hip"
+
+
+def learn_adjacency(obs: torch.Tensor, pos: torch.Tensor, n: int, input_dim: int, hip: bool):
+    if hip:
+        from .autograd_ops import radius_graph
+        return radius_graph(obs.float().contiguous(), n, input_dim)
+    return radius_adjacency(pos)
+
+
+def conv_relu(conv, x: torch.Tensor, adj, n: int, hip: bool) -> torch.Tensor:
+    """relu(conv(x)) for a GATv2Conv / TransformerConv over full graphs (adj: uint64 masks when hip, else dense)."""
+    if hip:
+        from .autograd_ops import gat_attention, transformer_attention
+        if isinstance(conv, TransformerConv):
+            return transformer_attention(conv.lin_key(x), conv.lin_value(x), conv.lin_query(x), adj, n, conv.heads,
+                                         conv.out_channels)
+        return gat_attention(conv.lin_l(x), conv.lin_r(x), conv.att, conv.bias, adj, n, conv.heads, conv.out_channels)
+    dense = transformer_dense if isinstance(conv, TransformerConv) else gatv2_dense
+    return F.relu(dense(conv, x, adj))
+
+
 def unpack(obs: torch.Tensor, input_dim: int, n: int):
     bs = obs.shape[0]
     node = obs[:, :-1].reshape(bs, n, input_dim + 3).float()

@@ -10,7 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from .common import MLP, GATv2Conv, HipForwardMixin, gatv2_dense, radius_adjacency, unpack
+from .common import (MLP, GATv2Conv, HipForwardMixin, conv_relu, gatv2_dense, learn_adjacency, radius_adjacency, unpack,
+                     use_hip_autograd)
 
 
 class HLDGNNetwork(HipForwardMixin, nn.Module):
@@ -51,7 +52,15 @@ class HLDGNNetwork(HipForwardMixin, nn.Module):
         pos, feats, dm, _g = unpack(obs, self.input_dim, self.agents_num)
         bs, n = pos.shape[:2]
         x = F.relu(self.encoder.model(feats.reshape(bs * n, -1)))
-        x = F.relu(gatv2_dense(self.conv1, x, radius_adjacency(pos)))
+        hip = use_hip_autograd(self, obs)
+        x = conv_relu(self.conv1, x, learn_adjacency(obs, pos, n, self.input_dim, hip), n, hip)
+        if hip:
+            from .autograd_ops import graph_pool
+            pooled = graph_pool(x, dm, n, self.aggregator_name)
+            if self.use_dueling:
+                q, v = self.Q.model(pooled), self.V.model(pooled)
+                return q - q.mean(dim=1, keepdim=True) + v
+            return self.out_linear(pooled)
         x = (x * dm.reshape(bs * n, 1)).view(bs, n, -1)
         if self.aggregator_name == "max":
             pooled = x.max(dim=1).values

@@ -14,7 +14,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib
-from .common import MLP, GATv2Conv, HipForwardMixin, gatv2_dense, radius_adjacency, unpack
+from .common import (MLP, GATv2Conv, HipForwardMixin, conv_relu, gatv2_dense, learn_adjacency, radius_adjacency, unpack,
+                     use_hip_autograd)
 
 
 class LDGNNetwork(HipForwardMixin, nn.Module):
@@ -56,14 +57,15 @@ class LDGNNetwork(HipForwardMixin, nn.Module):
         obs = obs.to(self.device)
         pos, feats, dm, g = unpack(obs, self.input_dim, self.agents_num)
         bs, n = pos.shape[:2]
-        adj = radius_adjacency(pos)
+        hip = use_hip_autograd(self, obs)
+        adj = learn_adjacency(obs, pos, n, self.input_dim, hip)
         x = F.relu(self.encoder.model(feats.reshape(bs * n, -1)))
         gi = torch.arange(bs, device=x.device) * n + g
         x_1 = x[gi]
-        x = F.relu(gatv2_dense(self.conv1, x, adj))
+        x = conv_relu(self.conv1, x, adj, n, hip)
         x_2 = x[gi]
         x = x * dm.reshape(bs * n, 1)
-        x = F.relu(gatv2_dense(self.conv2, x, adj))
+        x = conv_relu(self.conv2, x, adj, n, hip)
         x_cat = torch.cat([x_1, x_2, x[gi]], dim=1)
         if self.use_dueling:
             q, v = self.Q.model(x_cat), self.V.model(x_cat)
