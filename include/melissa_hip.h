@@ -257,7 +257,7 @@ mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int
 #define MEL_SET_HAS_MESSAGE    0   /* State.has_message                        core.py:18        */
 #define MEL_SET_ORIGIN         1   /* State.message_origin                     core.py:16        */
 #define MEL_SET_INTERESTED     2   /* Agent.is_interested                      core.py:71        */
-#define MEL_SET_SCRIPTED       3   /* Agent.is_scripted (always 0: out of scope)                 */
+#define MEL_SET_SCRIPTED       3   /* Agent.is_scripted                        core.py:69,404    */
 #define MEL_SET_TRUNCATED      4   /* Agent.truncated                          graph.py:333      */
 #define MEL_SET_ALIVE          5   /* keys of GraphEnv.terminations            graph.py:282-286  */
 #define MEL_SET_TERMINATED     6   /* terminations[a] == True                  graph.py:334      */
@@ -289,6 +289,8 @@ typedef struct mel_env_batch {
     int32_t dynamic_graph;     /* core.py:256                                                    */
     int32_t has_local_ratio;   /* graph.py:376,380                                               */
     double  local_ratio;
+    int32_t heuristic;         /* MEL_HEURISTIC_* run by the scripted agents (core.py:226-234)    */
+    int32_t is_testing;        /* evaluation mode: scripted agents stay in the active set (graph.py:244,340) */
     double*   pos;             /* [B, N, 2] float64 positions (graph node attr "pos")            */
     uint64_t* one_hop;         /* [B, N]    Agent.one_hop_neighbours_ids as bit masks            */
     uint64_t* two_hop;         /* [B, N]    Agent.two_hop_neighbours_ids                         */
@@ -321,7 +323,16 @@ typedef struct mel_episode_pool {
     const uint64_t* interested;/* [E]                                                            */
     const int32_t*  origin;    /* [E]                                                            */
     const double*   moves;     /* [E, max_moves, 2, N] 0.06*U(-1,1): all x then all y (core.py:316-319) */
+    const uint64_t* scripted;  /* [E] World.scripted_indices (core.py:197-221), or NULL = no scripted agents */
 } mel_episode_pool;
+
+/* Scripted agents (scripted_agents_ratio > 0): the deterministic heuristics of
+ * graph_env/env/utils/heuristics/core.py.  The probabilistic ones (probabilistic_gossip / _relay) draw from the
+ * process-global np.random and "mpr" does not return a HeuristicResult: not offered. */
+#define MEL_HEURISTIC_NONE                  0
+#define MEL_HEURISTIC_SIMPLE_BROADCAST      1   /* action = 0 if has_taken_action else 1     heuristics/core.py:13-18 */
+#define MEL_HEURISTIC_BROADCAST_IF_INTERESTED 2 /* action = number_interested_neighbors > 0  :45-53 */
+#define MEL_HEURISTIC_SILENT                3   /* action = 0                                :56-62 */
 
 /* Outputs of last() + [3P] PettingZooEnv packing, one row per listed env (device; any may be NULL). */
 typedef struct mel_env_obs {
@@ -429,6 +440,10 @@ void       mel_prof_reset(void* prof);
 int32_t    mel_prof_read(void* prof, double* ms_sum, int64_t* count);
 
 const char* mel_last_error(void);
+/* sizeof() of the structs of this header as the library was compiled, for binding authors to check their mirrors
+ * against: which = 0 mel_linear, 1 mel_gatv2, 2 mel_mlp, 3 mel_weights, 4 mel_select, 5 mel_env_batch,
+ * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay; 0 for anything else. */
+size_t mel_abi_sizeof(int32_t which);
 const char* mel_version(void);
 
 #ifdef __cplusplus

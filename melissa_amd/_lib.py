@@ -20,13 +20,14 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
+EXPORTS = ("mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
            "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
 PREC_F32, PREC_BF16 = 0, 1
+HEURISTICS = {None: 0, "simple_broadcast": 1, "broadcast_if_any_interested": 2, "silent": 3}
 N_STAGES = 14
 STAGE_NAMES = ("plan", "encoder", "conv1_lin", "conv1_lin_r", "conv1_att", "conv2_lin", "conv2_lin_r", "conv2_att",
                "head_hidden", "head_tail", "select", "env_step", "env_reset", "env_observe")
@@ -65,6 +66,7 @@ class MelRoundReplay(C.Structure):
 class MelEnvBatch(C.Structure):
     _fields_ = [("n_envs", C.c_int32), ("n_nodes", C.c_int32), ("dynamic_graph", C.c_int32),
                 ("has_local_ratio", C.c_int32), ("local_ratio", C.c_double),
+                ("heuristic", C.c_int32), ("is_testing", C.c_int32),
                 ("pos", C.c_void_p), ("one_hop", C.c_void_p), ("two_hop", C.c_void_p),
                 ("node_sets", C.c_void_p), ("sel_sets", C.c_void_p), ("scalars", C.c_void_p),
                 ("agent_msgs", C.c_void_p), ("received", C.c_void_p), ("two_hop_cover", C.c_void_p),
@@ -76,7 +78,8 @@ class MelEnvBatch(C.Structure):
 class MelEpisodePool(C.Structure):
     _fields_ = [("n_episodes", C.c_int32), ("n_nodes", C.c_int32), ("max_moves", C.c_int32),
                 ("reserved", C.c_int32), ("pos", C.c_void_p), ("one_hop", C.c_void_p),
-                ("interested", C.c_void_p), ("origin", C.c_void_p), ("moves", C.c_void_p)]
+                ("interested", C.c_void_p), ("origin", C.c_void_p), ("moves", C.c_void_p),
+                ("scripted", C.c_void_p)]
 
 
 class MelEnvObs(C.Structure):
@@ -133,6 +136,8 @@ def load(build_if_missing: bool = True):
     lib.mel_gemm_bf16.argtypes = [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp]
     lib.mel_convert_bf16.restype = i32
     lib.mel_convert_bf16.argtypes = [vp, vp, i64, vp]
+    lib.mel_abi_sizeof.restype = C.c_size_t
+    lib.mel_abi_sizeof.argtypes = [i32]
     lib.mel_radius_graph.restype = i32
     lib.mel_radius_graph.argtypes = [vp, i64, i32, i32, i32, vp, vp]
     lib.mel_gat_forward.restype = i32

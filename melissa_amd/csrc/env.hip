@@ -11,7 +11,7 @@
 //   World.step / relay_message / move_graph / update_*_hop / reset       graph_env/env/utils/core.py:225-437
 //   CustomSelector                                                       graph_env/env/utils/selector.py
 //   [3P] AECEnv._deads_step_first / _was_dead_step, tianshou PettingZooEnv.step
-// Scripted (heuristic) agents are out of scope: the scripted set is always empty.
+// Scripted agents run the deterministic heuristics of heuristics/core.py (MEL_HEURISTIC_*).
 #include "common.hpp"
 
 namespace mel {
@@ -132,10 +132,23 @@ __device__ __forceinline__ void selector_enable(Env& s, uint64_t agents, int lan
     s.sel_active = (s.sel_active & ~agents) | (agents & can);
 }
 
-// World.step core.py:225-266 (no scripted agents)
+// World.step core.py:225-266
 __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env& s,
                                            int lane) {
     const int n = e.n_nodes;
+    // :226-234 scripted agents: action = heuristic(agent) (the heuristics offered return no relay mask, so the
+    // relays_for pass :236-243 never fires)
+    // (no heuristic: Agent.action_callback stays None, World.scripted_agents is empty, nothing is overridden)
+    const bool scripted_lane = e.heuristic != MEL_HEURISTIC_NONE && lane < n && ((s.scripted >> lane) & 1ull);
+    if (scripted_lane) {
+        if (e.heuristic == MEL_HEURISTIC_SIMPLE_BROADCAST) s.act = ((s.taken_action >> lane) & 1ull) ? 0 : 1;
+        // Agent.number_interested_neighbors: counted at reset (core.py:401) but zeroed again by agent.reset() ->
+        // Agent.__init__ (:412-416, :68); only move_graph recomputes it (:286-287), so it is 0 until the episode's
+        // first move and tracks the current graph afterwards (one_hop changes only in moves)
+        else if (e.heuristic == MEL_HEURISTIC_BROADCAST_IF_INTERESTED)
+            s.act = (e.dynamic_graph && s.move_cursor > 0 && (s.one_hop & s.interested)) ? 1 : 0;
+        else s.act = 0;                                          // silent
+    }
     // :246 the source always transmits on its first opportunity
     const int origin_msgs = lane_i32(s.msgs, s.origin);
     if (lane == s.origin && origin_msgs == 0) s.act = 1;
@@ -171,6 +184,7 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
     }
     // :260-261 -> Agent.update_two_hop_cover_from_one_hopper (core.py:94-102)
     s.cover = __popcll(s.two_hop & (s.has_msg | s.origin_set));
+    if (scripted_lane) s.act = 0;                                // :264-266
 }
 
 // graph.py:254-271 (copy: optional second destination, the replay's obs_next slot)
@@ -286,7 +300,7 @@ __device__ __forceinline__ bool env_step(const mel_env_batch& e, const mel_episo
             const uint64_t expire = __ballot(lane < n && s.steps >= MAX_AGENT_STEPS) & s.agents & ~s.truncated;
             s.truncated |= expire;                                      // :330-334
             s.terminated |= expire;
-            s.agents = s.has_msg & s.alive & ~s.scripted;               // :336-341
+            s.agents = s.has_msg & s.alive & (e.is_testing ? ~0ull : ~s.scripted);   // :336-341
             selector_enable(s, s.agents, lane);                         // :342
             s.sel_selected = 0;                                         // :343
             s.new_round = 1;                                            // :344
@@ -323,7 +337,7 @@ __device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_epis
     s.two_hop = two_hop_of(s.one_hop, lane, n);                         // core.py:421
     s.origin = uniform_i32(pool.origin[episode]);
     s.interested = uniform_u64(pool.interested[episode]) & full;
-    s.scripted = 0;
+    s.scripted = pool.scripted ? (uniform_u64(pool.scripted[episode]) & full) : 0ull;   // core.py:395,404
     s.world_msgs = 0;
     s.has_msg = bit(s.origin);                                          // :432-434
     s.origin_set = bit(s.origin);
@@ -342,7 +356,7 @@ __device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_epis
     s.episode_rewards = 0.0;
     s.done_count = 0;
     write_obs_matrix(e, b, s, lane);
-    s.agents = s.has_msg & ~s.scripted;                                 // :242-245
+    s.agents = s.has_msg & (e.is_testing ? ~0ull : ~s.scripted);        // :242-245
     selector_enable(s, s.agents, lane);
     s.sel = selector_next(s, lane);                                     // :247
     s.skip = SKIP_NONE;
@@ -594,10 +608,11 @@ mel_status mel_env_bind(mel_env_batch* env, int32_t n_envs, int32_t n_nodes, voi
     if (n_envs < 1 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_envs=%d n_nodes=%d", n_envs, n_nodes);
     if (reinterpret_cast<uintptr_t>(state) & 255) return fail(MEL_ERR_INVALID_ARG, "state must be 256-byte aligned");
     const EnvLayout L = carve_env(n_envs, n_nodes, state);
-    const int32_t dyn = env->dynamic_graph, hlr = env->has_local_ratio;
+    const int32_t dyn = env->dynamic_graph, hlr = env->has_local_ratio, heu = env->heuristic, tst = env->is_testing;
     const double lr = env->local_ratio;
+    if (heu < MEL_HEURISTIC_NONE || heu > MEL_HEURISTIC_SILENT) return fail(MEL_ERR_INVALID_ARG, "heuristic %d", heu);
     *env = L.e;
-    env->dynamic_graph = dyn, env->has_local_ratio = hlr, env->local_ratio = lr;
+    env->dynamic_graph = dyn, env->has_local_ratio = hlr, env->local_ratio = lr, env->heuristic = heu, env->is_testing = tst;
     return MEL_OK;
 }
 

@@ -1287,6 +1287,20 @@ using namespace mel;
 extern "C" {
 
 const char* mel_last_error(void) { return g_err; }
+size_t mel_abi_sizeof(int32_t which) {
+    switch (which) {
+        case 0: return sizeof(mel_linear);
+        case 1: return sizeof(mel_gatv2);
+        case 2: return sizeof(mel_mlp);
+        case 3: return sizeof(mel_weights);
+        case 4: return sizeof(mel_select);
+        case 5: return sizeof(mel_env_batch);
+        case 6: return sizeof(mel_episode_pool);
+        case 7: return sizeof(mel_env_obs);
+        case 8: return sizeof(mel_round_replay);
+        default: return 0;
+    }
+}
 const char* mel_version(void) { return "melissa_hip 0.2 (gfx950)"; }
 
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {

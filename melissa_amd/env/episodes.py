@@ -90,20 +90,66 @@ class Episode:
     origin: int
     interested: int              # bit mask
     movement_seed: int
+    scripted: int = 0            # bit mask (World.scripted_indices, core.py:197-221)
 
 
 class EpisodeSampler:
-    """The RNG protocol of World.reset in training mode (core.py:371-395), one instance per env."""
+    """The RNG protocol of World.reset (core.py:343-395), one instance per env.  Training mode draws the episode
+    seed and the graph from the env's generator; testing mode (``is_testing``, core.py:182-187,348-370) walks a
+    fixed list of ``num_test_episodes`` seeds derived from ``RandomState(17)`` in strict order, picks the graph
+    with the episode's own RNG from the (sorted) test pool and cycles the interest density through 0.1 .. 1.0."""
 
     def __init__(self, n: int, np_random: np.random.Generator, pool_size: int, fixed_graph: bool,
-                 fixed_interest_density=None):
+                 fixed_interest_density=None, is_testing: bool = False, num_test_episodes: int = 10,
+                 scripted_agents_ratio: float = 0.0):
+        if not (0.0 <= scripted_agents_ratio <= 1.0):                                   # core.py:143-144
+            raise ValueError("`scripted_agents_ratio` must be in [0.0, 1.0].")
+        self.scripted_agents_ratio = float(scripted_agents_ratio)
         self.n, self.np_random, self.pool_size, self.fixed_graph = n, np_random, pool_size, fixed_graph
         self.fixed_interest_density = fixed_interest_density
+        self.is_testing, self.num_test_episodes = bool(is_testing), int(num_test_episodes)
+        self.test_episode_index = 0
+        self.test_seeds_list = []
+        if self.is_testing:
+            gen = np.random.RandomState(17)                                             # core.py:184-187
+            self.test_seeds_list = [gen.randint(0, 1e9) for _ in range(self.num_test_episodes)]
 
     def seed(self, seed=None):
         self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))   # graph.py:145-146
 
+    def _sample_scripted(self, origin: int) -> int:
+        """World._sample_scripted_agents (core.py:197-215): ``round(ratio * N)`` vertices drawn without replacement
+        from the ENV's generator; the origin is never scripted unless every agent is (ratio == 1)."""
+        n_scripted = int(round(self.scripted_agents_ratio * self.n))
+        chosen = self.np_random.choice(self.n, size=n_scripted, replace=False)
+        mask = 0
+        for i in chosen:
+            mask |= 1 << int(i)
+        if self.scripted_agents_ratio < 1.0:
+            mask &= ~(1 << origin)
+        return mask
+
+    def _sample_testing(self) -> Episode:
+        n = self.n
+        if not self.test_seeds_list:                                                    # core.py:349-350
+            raise ValueError("No test seeds have been generated! Check num_test_episodes.")
+        episode_seed = self.test_seeds_list[self.test_episode_index]                    # :351
+        self.test_episode_index = (self.test_episode_index + 1) % self.num_test_episodes   # :352
+        ep_rng = np.random.RandomState(episode_seed)                                    # :353
+        graph_index = int(ep_rng.randint(0, self.pool_size))      # :357 ep_rng.choice(test_graphs): same draw
+        movement_seed = ep_rng.randint(0, 1e9)                                          # :361
+        origin = int(ep_rng.randint(0, n))                                              # :364
+        density = [i / 10.0 for i in range(1, 11)][self.test_episode_index % 10]        # :365-366 (index already bumped)
+        chosen = ep_rng.choice(n, size=int(density * n), replace=False)                 # :393-394
+        scripted = self._sample_scripted(origin)                                        # :395
+        mask = 0
+        for i in chosen:
+            mask |= 1 << int(i)
+        return Episode(graph_index, origin, mask, int(movement_seed), scripted)
+
     def sample(self) -> Episode:
+        if self.is_testing:
+            return self._sample_testing()
         n = self.n
         episode_seed = self.np_random.integers(0, 1e9)                                  # core.py:372
         ep_rng = np.random.RandomState(episode_seed)                                    # :373
@@ -115,11 +161,11 @@ class EpisodeSampler:
         density = (ep_rng.uniform(0.1, 1.0) if self.fixed_interest_density is None
                    else self.fixed_interest_density)                                    # :385
         chosen = ep_rng.choice(n, size=int(density * n), replace=False)                 # :393-394
-        self.np_random.choice(n, size=0, replace=False)                                 # :395 (scripted ratio 0)
+        scripted = self._sample_scripted(origin)                                        # :395
         mask = 0
         for i in chosen:
             mask |= 1 << int(i)
-        return Episode(graph_index, origin, mask, int(movement_seed))
+        return Episode(graph_index, origin, mask, int(movement_seed), scripted)
 
 
 def movement_offsets(movement_seed: int, n: int, max_moves: int) -> np.ndarray:
@@ -135,12 +181,13 @@ def pack_episodes(episodes, graphs, n: int, max_moves: int, dynamic: bool):
     pos = np.zeros((e, n, 2), dtype=np.float64)
     one_hop = np.zeros((e, n), dtype=np.uint64)
     interested = np.zeros(e, dtype=np.uint64)
+    scripted = np.zeros(e, dtype=np.uint64)
     origin = np.zeros(e, dtype=np.int32)
     moves = np.zeros((e, max_moves if dynamic else 1, 2, n), dtype=np.float64)
     for k, ep in enumerate(episodes):
         g = graphs[ep.graph_index]
         pos[k], one_hop[k] = g.pos, g.one_hop
-        interested[k], origin[k] = np.uint64(ep.interested), ep.origin
+        interested[k], origin[k], scripted[k] = np.uint64(ep.interested), ep.origin, np.uint64(ep.scripted)
         if dynamic:
             moves[k] = movement_offsets(ep.movement_seed, n, max_moves)
-    return dict(pos=pos, one_hop=one_hop, interested=interested, origin=origin, moves=moves)
+    return dict(pos=pos, one_hop=one_hop, interested=interested, origin=origin, moves=moves, scripted=scripted)

@@ -56,6 +56,7 @@ class DevicePool:
         s = self.struct
         s.pos, s.one_hop, s.interested = t["pos"].data_ptr(), t["one_hop"].data_ptr(), t["interested"].data_ptr()
         s.origin, s.moves = t["origin"].data_ptr(), t["moves"].data_ptr()
+        s.scripted = t["scripted"].data_ptr() if "scripted" in t else None
 
     def write(self, slot_ids: np.ndarray, packed: dict):
         idx = torch.as_tensor(slot_ids, dtype=torch.long, device=self.tensors["origin"].device)
@@ -90,12 +91,26 @@ class HipGraphVectorEnv:
 
     def __init__(self, env_num: int, number_of_agents: int, graph_pool=None, graph: Graph | None = None,
                  dynamic_graph: bool = False, local_ratio=None, device="cuda", max_moves: int = 64,
-                 seed=None, fixed_interest_density=None, construct_like_reference: bool = True):
+                 seed=None, fixed_interest_density=None, construct_like_reference: bool = True,
+                 is_testing: bool = False, num_test_episodes: int = 10, scripted_agents_ratio: float = 0.0,
+                 heuristic: str | None = None):
         """``graph`` fixes one graph for every episode (GraphEnv(graph=...)); ``graph_pool`` is a list of
         ``Graph`` standing for the ``graph_topologies/training_N/*`` files.  ``seed`` seeds env k's
         generator with ``seed + k`` (tianshou ``BaseVectorEnv.seed``).  ``construct_like_reference``
         replays the two episode samplings the reference performs while constructing a GraphEnv
-        (core.py:190, graph.py:118) so RNG streams line up with a reference run."""
+        (core.py:190, graph.py:118) so RNG streams line up with a reference run.  ``is_testing``: the
+        reference's evaluation schedule (GraphEnv(is_testing=True, num_test_episodes=...), core.py:182-187,348-370);
+        ``graph_pool`` then stands for the sorted ``graph_topologies/testing_N/*`` files."""
+        if is_testing and graph is not None:
+            raise ValueError("testing mode draws its graph from graph_pool (core.py:355-359)")
+        # core.py:143-148: the same argument checks, same messages
+        if not (0.0 <= scripted_agents_ratio <= 1.0):
+            raise ValueError("`scripted_agents_ratio` must be in [0.0, 1.0].")
+        if scripted_agents_ratio == 0.0 and heuristic is not None:
+            raise ValueError("If `scripted_agents_ratio` is 0.0, no heuristic can be set.")
+        if heuristic not in _lib.HEURISTICS:         # None with a ratio > 0: scripted nodes never act (no callback)
+            raise ValueError(f"Unknown heuristic policy: {heuristic} (the HIP env offers the deterministic ones: "
+                             f"{[k for k in _lib.HEURISTICS if k]})")
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("HipGraphVectorEnv needs a ROCm GPU; there is no CPU fallback")
@@ -108,7 +123,9 @@ class HipGraphVectorEnv:
         self.action_space = [Discrete(2) for _ in range(self.env_num)]
         seeds = [None] * self.env_num if seed is None else [seed + k for k in range(self.env_num)]
         self.samplers = [EpisodeSampler(self.n, np.random.Generator(np.random.PCG64(np.random.SeedSequence(s))),
-                                        len(self.graphs), self.fixed_graph, fixed_interest_density)
+                                        len(self.graphs), self.fixed_graph, fixed_interest_density,
+                                        is_testing=is_testing, num_test_episodes=num_test_episodes,
+                                        scripted_agents_ratio=scripted_agents_ratio)
                          for s in seeds]
         # device state
         nbytes = int(self.lib.mel_env_state_bytes(self.env_num, self.n))
@@ -117,6 +134,7 @@ class HipGraphVectorEnv:
         self.env.dynamic_graph = int(self.dynamic_graph)
         self.env.has_local_ratio = int(local_ratio is not None)
         self.env.local_ratio = float(local_ratio) if local_ratio is not None else 0.0
+        self.env.heuristic, self.env.is_testing = _lib.HEURISTICS[heuristic], int(bool(is_testing))
         _lib.check(self.lib.mel_env_bind(C.byref(self.env), self.env_num, self.n, self.state.data_ptr()), "mel_env_bind")
         # one staging pool slot per env for the host-sampled ("tianshou compatible") reset path
         empty = pack_episodes([], self.graphs, self.n, self.max_moves, self.dynamic_graph)

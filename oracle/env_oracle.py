@@ -21,8 +21,8 @@ graphs / action tapes and stores every per-step output in ``tests/golden/env_tra
 (tests/unit/graph_env/env/utils/test_core.py:97-169) are replayed in the same test file.  The [3P]
 sliver (pettingzoo/tianshou wrappers, versions unpinned/absent) is "parity unpinned".
 
-Scripted (heuristic) agents are out of scope: ``scripted_agents_ratio`` is 0,
-so ``dm_flag`` is 1 for every node and ``World.step``'s scripted branches (core.py:226-243,264-266)
+Scripted agents (``scripted_agents_ratio`` > 0) run the deterministic heuristics of heuristics/core.py; with the
+default ratio 0 ``dm_flag`` is 1 for every node and ``World.step``'s scripted branches (core.py:226-243,264-266)
 are empty loops.
 
 Representation: node sets are Python ints used as N-bit masks (bit i = node i); this is exactly the
@@ -116,8 +116,25 @@ class OracleGraphEnv:
 
     def __init__(self, number_of_agents, graph: GraphSpec | None = None, graph_pool=None,
                  radius=RADIUS_OF_INFLUENCE, local_ratio=None, dynamic_graph=False,
-                 np_random: np.random.Generator | None = None, fixed_interest_density=None):
+                 np_random: np.random.Generator | None = None, fixed_interest_density=None,
+                 is_testing=False, num_test_episodes=10, scripted_agents_ratio=0.0, heuristic=None):
         self.n = int(number_of_agents)
+        # core.py:143-163: scripted agents run one of the heuristics of heuristics/core.py (the deterministic ones;
+        # the probabilistic ones draw from the process-global np.random and cannot be pinned)
+        if not (0.0 <= scripted_agents_ratio <= 1.0):
+            raise ValueError("`scripted_agents_ratio` must be in [0.0, 1.0].")
+        elif scripted_agents_ratio == 0.0 and heuristic is not None:
+            raise ValueError("If `scripted_agents_ratio` is 0.0, no heuristic can be set.")
+        if heuristic not in (None, "simple_broadcast", "broadcast_if_any_interested", "silent"):
+            raise ValueError(f"Unknown heuristic policy: {heuristic}")
+        self.scripted_agents_ratio, self.heuristic = scripted_agents_ratio, heuristic
+        # testing mode (core.py:178-187): fixed list of per-episode seeds, walked in strict order
+        self.is_testing, self.num_test_episodes = bool(is_testing), int(num_test_episodes)
+        self.test_episode_index = 0
+        self.test_seeds_list = []
+        if self.is_testing:
+            testing_generator = np.random.RandomState(17)
+            self.test_seeds_list = [testing_generator.randint(0, 1e9) for _ in range(self.num_test_episodes)]
         assert 1 <= self.n <= 64
         self.full = (1 << self.n) - 1
         self.radius = radius
@@ -146,26 +163,46 @@ class OracleGraphEnv:
     # ------------------------------------------------------------------ World.reset core.py:343-437
     def _world_reset(self):
         n = self.n
-        episode_seed = self.np_random.integers(0, 1e9)                       # core.py:372
-        ep_rng = np.random.RandomState(episode_seed)                         # :373
-        if not self.is_graph_fixed:                                          # :377-379
-            self.selected_graph = self.np_random.choice(len(self.graph_pool), replace=True)
+        if self.is_testing:                                                  # core.py:348-370
+            if not self.test_seeds_list:
+                raise ValueError("No test seeds have been generated! Check num_test_episodes.")
+            episode_seed = self.test_seeds_list[self.test_episode_index]
+            self.test_episode_index = (self.test_episode_index + 1) % self.num_test_episodes
+            ep_rng = np.random.RandomState(episode_seed)
+            # :357 ep_rng.choice(self.test_graphs) over the sorted file list = one randint over the pool
+            self.selected_graph = ep_rng.choice(len(self.graph_pool))
             self.graph = self.graph_pool[int(self.selected_graph)].copy()
-        movement_seed = ep_rng.randint(0, 1e9)                               # :381
-        self.movement_np_random = np.random.RandomState(movement_seed)       # :382
-        chosen_source_id = ep_rng.randint(0, n)                              # :384
-        interest_density = (ep_rng.uniform(0.1, 1.0) if self.fixed_interest_density is None
-                            else self.fixed_interest_density)                # :385
+            movement_seed = ep_rng.randint(0, 1e9)                           # :361
+            self.movement_np_random = np.random.RandomState(movement_seed)
+            chosen_source_id = ep_rng.randint(0, n)                          # :364
+            fixed_interest_densities = [i / 10.0 for i in range(1, 11)]     # :365-366
+            interest_density = fixed_interest_densities[self.test_episode_index % len(fixed_interest_densities)]
+        else:
+            episode_seed = self.np_random.integers(0, 1e9)                   # core.py:372
+            ep_rng = np.random.RandomState(episode_seed)                     # :373
+            if not self.is_graph_fixed:                                      # :377-379
+                self.selected_graph = self.np_random.choice(len(self.graph_pool), replace=True)
+                self.graph = self.graph_pool[int(self.selected_graph)].copy()
+            movement_seed = ep_rng.randint(0, 1e9)                           # :381
+            self.movement_np_random = np.random.RandomState(movement_seed)   # :382
+            chosen_source_id = ep_rng.randint(0, n)                          # :384
+            interest_density = (ep_rng.uniform(0.1, 1.0) if self.fixed_interest_density is None
+                                else self.fixed_interest_density)            # :385
         self.messages_transmitted = 0                                        # :389
         self.origin_agent = int(chosen_source_id)                            # :390
         num_interested = int(interest_density * n)                           # :393
         interested_indices = ep_rng.choice(n, size=num_interested, replace=False)  # :394
-        # :395 _apply_scripted_mask -> np_random.choice(n, size=0, replace=False): consumes nothing
-        self.np_random.choice(n, size=0, replace=False)
+        # :395 _apply_scripted_mask -> _sample_scripted_agents (core.py:197-215), from the ENV's generator
+        n_scripted = int(round(self.scripted_agents_ratio * n))
+        scripted_draw = self.np_random.choice(n, size=n_scripted, replace=False)
         self.interested = 0
         for i in interested_indices:
             self.interested |= 1 << int(i)
         self.scripted = 0
+        for i in scripted_draw:
+            self.scripted |= 1 << int(i)
+        if self.scripted_agents_ratio < 1.0:                                  # :212-214 origin is never scripted
+            self.scripted &= ~(1 << self.origin_agent)
         # Agent(...) / state.reset / agent.reset (core.py:398-425)
         self.pos = self.graph.pos            # shared with the graph object (mutated in place)
         self.adj = list(self.graph.adj)                                       # update_one_hop :321-332
@@ -180,6 +217,9 @@ class OracleGraphEnv:
         self.truncated = 0                  # Agent.truncated = False :425
         self.two_hop_cover = [0] * n
         self.gained_two_hop_cover = [0] * n
+        # update_one_hop_neighbors_info counts them (:401,:326-327) but agent.reset() re-runs Agent.__init__ right
+        # after (:412-416 -> core.py:68), so the count is 0 until the first move_graph of the episode recomputes it
+        self.number_interested_neighbors = [0] * n
         # source (core.py:432-435)
         s = self.origin_agent
         self.message_origin |= 1 << s
@@ -191,6 +231,15 @@ class OracleGraphEnv:
     def _world_step(self):
         n = self.n
         s = self.origin_agent
+        callback = self.heuristic is not None                                 # Agent.action_callback, core.py:428-429
+        if callback:
+            for i in bits(self.scripted):                                     # :226-234 (no relay masks, so :236-243 is idle)
+                if self.heuristic == "simple_broadcast":                      # heuristics/core.py:13-18
+                    self.agent_action[i] = 0 if (self.has_taken_action >> i) & 1 else 1
+                elif self.heuristic == "broadcast_if_any_interested":         # :45-53
+                    self.agent_action[i] = 1 if self.number_interested_neighbors[i] > 0 else 0
+                else:                                                         # silent :56-62
+                    self.agent_action[i] = 0
         if self.agent_msgs[s] == 0:                                           # :246
             self.agent_action[s] = 1
         for i in range(n):                                                    # :249-254 (id order)
@@ -202,6 +251,9 @@ class OracleGraphEnv:
             cover = popcount(self.two_hop[i] & (self.has_message | self.message_origin))
             self.gained_two_hop_cover[i] = cover - self.two_hop_cover[i]
             self.two_hop_cover[i] = cover
+        if callback:
+            for i in bits(self.scripted):                                     # :264-266
+                self.agent_action[i] = 0
 
     def _relay_message(self, i):                                              # core.py:268-279
         self.messages_transmitted += 1
@@ -221,6 +273,7 @@ class OracleGraphEnv:
             self.pos[k, 1] = self.pos[k, 1] + oy[k]
         self.adj = geometric_adjacency(self.pos, RADIUS_OF_INFLUENCE)         # :311-314
         self.graph.adj = list(self.adj)
+        self.number_interested_neighbors = [popcount(a & self.interested) for a in self.adj]   # :286-287 -> :321-327
         self.two_hop = two_hop_masks(self.adj)
 
     # ------------------------------------------------------------------ GraphEnv.reset graph.py:222-248
@@ -241,7 +294,7 @@ class OracleGraphEnv:
         self._world_reset()
         self.episode_rewards_sum = 0.0
         self._update_obs_matrix()
-        self.agents = self.has_message & ~self.scripted                       # :242-245
+        self.agents = self.has_message & (self.full if self.is_testing else ~self.scripted)   # :242-245
         # selector.enable(on_reset=True) (selector.py:39-44)
         self.sel_steps[self.origin_agent] += 1
         self._selector_enable(self.agents)
@@ -365,7 +418,7 @@ class OracleGraphEnv:
                 if self.steps_taken[i] >= MAX_AGENT_STEPS and not (self.truncated >> i) & 1:
                     self.truncated |= 1 << i
                     self.terminated |= 1 << i
-            self.agents = self.has_message & self.alive & ~self.scripted      # :336-341
+            self.agents = self.has_message & self.alive & (self.full if self.is_testing else ~self.scripted)   # :336-341
             self._selector_enable(self.agents)                                # :342
             self.sel_selected = 0                                             # :343
             self.is_new_round = True                                          # :344

@@ -103,6 +103,7 @@ def record(rows, pz, packed, n):
     rows["terminated_mask"].append(np.uint64(mask_of(k for k, v in env.terminations.items() if v)))
     rows["has_message_mask"].append(np.uint64(mask_of(a.name for a in w.agents if a.state.has_message)))
     rows["interested_mask"].append(np.uint64(mask_of(a.name for a in w.agents if a.is_interested)))
+    rows["scripted_mask"].append(np.uint64(mask_of(a.name for a in w.agents if a.is_scripted)))
     rows["origin"].append(int(w.origin_agent))
     rows["pos"].append(np.array([a.pos for a in w.agents], dtype=np.float64))
     rows["one_hop"].append(np.array([mask_of(np.where(a.one_hop_neighbours_ids)[0]) for a in w.agents],
@@ -111,8 +112,10 @@ def record(rows, pz, packed, n):
                                     dtype=np.uint64))
 
 
-def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=None, n_graphs=6):
+def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=None, n_graphs=6, num_test_episodes=None,
+              scripted_agents_ratio=0.0, heuristic=None):
     """mode: 'pool' (graph_topologies/training_N/* files written here from synthetic RGGs),
+    'testing' (is_testing=True over graph_topologies/testing_N/*, core.py:348-370),
     'fixed' (graph= argument, one RGG), 'fixture12' (the reference's test graph)."""
     ref_graph, _ = ref_standins.import_reference()
     ref_standins.DEFAULT_SEED = env_seed
@@ -121,14 +124,27 @@ def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=No
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)
         try:
-            if mode == "pool":
+            if mode == "testing":
+                os.makedirs(f"graph_topologies/testing_{n}")
+                graphs = connected_rggs(n, n_graphs, first_seed=300 * n)
+                for s, g in graphs:
+                    with open(f"graph_topologies/testing_{n}/rgg_{s:05d}.gpickle", "wb") as f:
+                        pickle.dump(g, f)     # a file this script wrote, not a reference artefact
+                env = ref_graph.GraphEnv(graph=None, number_of_agents=n, radius=0.2, dynamic_graph=dynamic,
+                                         local_ratio=local_ratio, is_testing=True, num_test_episodes=num_test_episodes,
+                                         scripted_agents_ratio=scripted_agents_ratio, heuristic=heuristic)
+                order = [os.path.basename(p) for p in env.world.test_graphs]          # sorted glob (core.py:170-172)
+                by_name = {f"rgg_{s:05d}.gpickle": g for s, g in graphs}
+                pool = [by_name[o] for o in order]
+            elif mode == "pool":
                 os.makedirs(f"graph_topologies/training_{n}")
                 graphs = connected_rggs(n, n_graphs, first_seed=100 * n)
                 for s, g in graphs:
                     with open(f"graph_topologies/training_{n}/rgg_{s:05d}.gpickle", "wb") as f:
                         pickle.dump(g, f)     # a file this script wrote, not a reference artefact
                 env = ref_graph.GraphEnv(graph=None, number_of_agents=n, radius=0.2,
-                                         dynamic_graph=dynamic, local_ratio=local_ratio)
+                                         dynamic_graph=dynamic, local_ratio=local_ratio,
+                                         scripted_agents_ratio=scripted_agents_ratio, heuristic=heuristic)
                 order = [os.path.basename(p) for p in env.world.train_graphs]
                 by_name = {f"rgg_{s:05d}.gpickle": g for s, g in graphs}
                 pool = [by_name[o] for o in order]          # glob order = choice index order
@@ -149,7 +165,7 @@ def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=No
             tape = np.random.RandomState(tape_seed).randint(0, 2, size=steps).astype(np.int8)
             rows = {k: [] for k in ("agent_id obs mask rew term trunc env_step environment_step "
                                     "explicit_reset active_nb has_stats stats agents_mask alive_mask "
-                                    "terminated_mask has_message_mask interested_mask origin pos "
+                                    "terminated_mask has_message_mask interested_mask scripted_mask origin pos "
                                     "one_hop two_hop was_reset").split()}
             packed = pz.reset()
             record(rows, pz, packed, n)
@@ -172,7 +188,9 @@ def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=No
     out = {k: np.array(v) for k, v in rows.items()}
     out.update(meta)
     out.update(n=np.int64(n), dynamic=np.bool_(dynamic), env_seed=np.int64(env_seed), tape=tape,
-               fixed_graph=np.bool_(mode != "pool"),
+               fixed_graph=np.bool_(mode not in ("pool", "testing")), is_testing=np.bool_(mode == "testing"),
+               num_test_episodes=np.int64(num_test_episodes or 0),
+               scripted_agents_ratio=np.float64(scripted_agents_ratio), heuristic=np.str_(heuristic or ""),
                local_ratio=np.float64(-1.0 if local_ratio is None else local_ratio))
     path = os.path.join(HERE, f"env_trace_{name}.npz")
     np.savez_compressed(path, **out)
@@ -188,6 +206,16 @@ def main():
     run_trace("n20_fixed_dynamic", 20, "fixed", True, 400, env_seed=15, tape_seed=5)
     run_trace("n12_fixture_static", 12, "fixture12", False, 300, env_seed=16, tape_seed=6)
     run_trace("n12_fixture_dynamic", 12, "fixture12", True, 300, env_seed=17, tape_seed=7)
+    run_trace("n20_testing_dynamic", 20, "testing", True, 900, env_seed=18, tape_seed=8, num_test_episodes=7)
+    # scripted agents (heuristics/core.py): training mode keeps them out of the active set, testing mode steps them
+    run_trace("n20_scripted_broadcast", 20, "pool", True, 600, env_seed=19, tape_seed=9,
+              scripted_agents_ratio=0.3, heuristic="simple_broadcast")
+    run_trace("n50_scripted_interested", 50, "pool", False, 500, env_seed=20, tape_seed=10,
+              scripted_agents_ratio=0.4, heuristic="broadcast_if_any_interested")
+    run_trace("n20_scripted_interested_dynamic", 20, "pool", True, 500, env_seed=22, tape_seed=12,
+              scripted_agents_ratio=0.4, heuristic="broadcast_if_any_interested")
+    run_trace("n20_scripted_silent_testing", 20, "testing", True, 500, env_seed=21, tape_seed=11, num_test_episodes=5,
+              scripted_agents_ratio=0.5, heuristic="silent")
 
 
 if __name__ == "__main__":

@@ -28,9 +28,12 @@ def test_struct_sizes_match_header(lib):
     # layout sanity of the ctypes mirrors (8-byte pointers, natural alignment)
     assert C.sizeof(_lib.MelLinear) == 24
     assert C.sizeof(_lib.MelMlp) == 24 * _lib.MAX_HEAD_LAYERS + 8
-    assert C.sizeof(_lib.MelEpisodePool) == 16 + 5 * 8
-    assert C.sizeof(_lib.MelEnvObs) == 9 * 8
-    assert C.sizeof(_lib.MelEnvBatch) == 24 + 18 * 8
+    # every mirror against sizeof() as the library was compiled
+    mirrors = [_lib.MelLinear, _lib.MelGatv2, _lib.MelMlp, _lib.MelWeights, _lib.MelSelect, _lib.MelEnvBatch,
+               _lib.MelEpisodePool, _lib.MelEnvObs, _lib.MelRoundReplay]
+    for which, cls in enumerate(mirrors):
+        assert C.sizeof(cls) == lib.mel_abi_sizeof(which), cls.__name__
+    assert lib.mel_abi_sizeof(99) == 0
 
 
 def test_validation_errors_without_gpu(lib):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.trace_replay import replay
+from tests.trace_replay import replay, scripted_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,8 @@ class OneEnvAdapter:
         from melissa_amd import _lib as L
         return dict(agents_mask=sets[L.SET_AGENTS], alive_mask=sets[L.SET_ALIVE],
                     terminated_mask=sets[L.SET_TERMINATED], has_message_mask=sets[L.SET_HAS_MESSAGE],
-                    interested_mask=sets[L.SET_INTERESTED], origin=int(v.scalars()[k, L.S_ORIGIN]),
+                    interested_mask=sets[L.SET_INTERESTED], scripted_mask=sets[L.SET_SCRIPTED],
+                    origin=int(v.scalars()[k, L.S_ORIGIN]),
                     pos=v.positions()[k].cpu().numpy(), one_hop=v.one_hop()[k].cpu().numpy().view(np.uint64),
                     two_hop=v.two_hop()[k].cpu().numpy().view(np.uint64))
 
@@ -48,6 +49,9 @@ def build_venv(tr, env_num=1, slot=0):
     lr = float(tr["local_ratio"])
     kw = dict(env_num=env_num, number_of_agents=n, dynamic_graph=bool(tr["dynamic"]),
               local_ratio=None if lr < 0 else lr, seed=int(tr["env_seed"]) - slot, max_moves=64)
+    kw.update(scripted_kwargs(tr))
+    if "is_testing" in tr.files and bool(tr["is_testing"]):          # core.py:348-370 evaluation schedule
+        kw.update(is_testing=True, num_test_episodes=int(tr["num_test_episodes"]))
     if bool(tr["fixed_graph"]):
         return HipGraphVectorEnv(graph=graphs[0], **kw)
     return HipGraphVectorEnv(graph_pool=graphs, **kw)
@@ -84,3 +88,29 @@ def test_hip_env_trace_in_a_busy_batch():
     busy = Busy(venv, 5)
     rows = replay(tr, busy, busy.state)
     assert rows > 300
+
+
+def test_scripted_argument_checks_and_partition():
+    """core.py:143-152 argument errors; scripted | decision makers = all nodes, origin never scripted, dm column =
+    not scripted, scripted nodes never selected in training mode (test_mixed_scripted_learned_agents.py:29-100)."""
+    from melissa_amd import _lib as L
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    pool = synthetic_graph_pool(20, 4, 10)
+    for bad in (-0.1, 1.1):
+        with pytest.raises(ValueError, match=r"must be in \[0.0, 1.0\]"):
+            HipGraphVectorEnv(2, 20, graph_pool=pool, scripted_agents_ratio=bad)
+    with pytest.raises(ValueError, match="no heuristic can be set"):
+        HipGraphVectorEnv(2, 20, graph_pool=pool, heuristic="silent")
+    with pytest.raises(ValueError, match="Unknown heuristic policy"):
+        HipGraphVectorEnv(2, 20, graph_pool=pool, scripted_agents_ratio=0.5, heuristic="probabilistic_gossip")
+    venv = HipGraphVectorEnv(16, 20, graph_pool=pool, scripted_agents_ratio=0.5, heuristic="simple_broadcast", seed=3)
+    for _ in range(3):
+        venv.reset()
+        sets = venv.node_sets().cpu().numpy().view(np.uint64)
+        origin = venv.scalars()[:, L.S_ORIGIN].cpu().numpy()
+        dm = venv.obs_matrix().cpu().numpy()[:, :, 7]
+        for b in range(16):
+            scripted = int(sets[b, L.SET_SCRIPTED])
+            assert bin(scripted).count("1") in (9, 10) and not (scripted >> int(origin[b])) & 1
+            assert int(sets[b, L.SET_AGENTS]) & scripted == 0
+            np.testing.assert_array_equal(dm[b], [0.0 if (scripted >> i) & 1 else 1.0 for i in range(20)])

@@ -14,14 +14,18 @@ from oracle import net_oracle as no
 DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
 
 
-def test_sampler_matches_oracle_world_reset():
+@pytest.mark.parametrize("testing", [False, True])
+def test_sampler_matches_oracle_world_reset(testing):
+    """training mode (core.py:371-395) and the evaluation schedule (is_testing, core.py:348-370; the oracle is
+    pinned to the real reference in both by the golden traces)."""
     pool = synthetic_graph_pool(20, 3, 400)
     opool = [eo.GraphSpec(p.pos.copy(), [int(m) for m in p.one_hop]) for p in pool]
     mk = lambda: np.random.Generator(np.random.PCG64(np.random.SeedSequence(5)))
-    env = eo.OracleGraphEnv(20, graph_pool=opool, dynamic_graph=True, np_random=mk())
-    s = EpisodeSampler(20, mk(), 3, False)
+    kw = dict(is_testing=True, num_test_episodes=3) if testing else {}
+    env = eo.OracleGraphEnv(20, graph_pool=opool, dynamic_graph=True, np_random=mk(), **kw)
+    s = EpisodeSampler(20, mk(), 3, False, **kw)
     s.sample()
-    for _ in range(4):
+    for _ in range(7 if testing else 4):          # testing: walks the 3-seed list more than twice (wrap-around)
         ep = s.sample()
         assert (ep.origin, ep.interested, ep.graph_index) == (env.origin_agent, env.interested, int(env.selected_graph))
         # first movement of the episode = the one consumed by the forced source step of reset

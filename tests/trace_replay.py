@@ -30,6 +30,8 @@ def check_row(tr, r, obs, rew, term, trunc, info, state=None):
         for key in ("agents_mask", "alive_mask", "terminated_mask", "has_message_mask",
                     "interested_mask"):
             assert int(state[key]) == int(tr[key][r]), f"{ctx} {key}"
+        if "scripted_mask" in tr.files and "scripted_mask" in state:
+            assert int(state["scripted_mask"]) == int(tr["scripted_mask"][r]), f"{ctx} scripted_mask"
         assert int(state["origin"]) == int(tr["origin"][r]), ctx
         np.testing.assert_array_equal(np.asarray(state["pos"], dtype=np.float64), tr["pos"][r], err_msg=ctx)
         np.testing.assert_array_equal(np.asarray(state["one_hop"], dtype=np.uint64), tr["one_hop"][r], err_msg=ctx)
@@ -62,3 +64,10 @@ def replay(tr, pz, state_fn=None):
                 done_count = 0
     assert r == len(tr["agent_id"])
     return r
+
+
+def scripted_kwargs(tr):
+    """scripted_agents_ratio / heuristic a trace was recorded with (absent in the older traces: ratio 0)."""
+    if "scripted_agents_ratio" not in tr.files or float(tr["scripted_agents_ratio"]) == 0.0:
+        return {}
+    return dict(scripted_agents_ratio=float(tr["scripted_agents_ratio"]), heuristic=str(tr["heuristic"]) or None)
