@@ -108,7 +108,7 @@ def test_scripted_argument_checks_and_partition():
         venv.reset()
         sets = venv.node_sets().cpu().numpy().view(np.uint64)
         origin = venv.scalars()[:, L.S_ORIGIN].cpu().numpy()
-        dm = venv.obs_matrix().cpu().numpy()[:, :, 7]
+        dm = venv.obs_matrix().cpu().numpy().reshape(16, 20, 8)[:, :, 7]
         for b in range(16):
             scripted = int(sets[b, L.SET_SCRIPTED])
             assert bin(scripted).count("1") in (9, 10) and not (scripted >> int(origin[b])) & 1
