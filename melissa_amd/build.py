@@ -30,6 +30,7 @@ HASH_PATH = LIB_PATH + ".srchash"
 
 def source_hash() -> str:
     h = hashlib.sha256()
+    h.update(os.environ.get("MEL_HIPCC_FLAGS", "").encode())
     for rel in SOURCES + HEADERS:
         path = os.path.join(CSRC, rel)
         if os.path.exists(path):
@@ -54,8 +55,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # -ffp-contract=off: the env's float64 arithmetic and the fp32 radius rule must round exactly like
     # the reference's Python/NumPy expressions (no fused multiply-add unless written as fmaf).
     tmp = f"{LIB_PATH}.tmp.{os.getpid()}"          # atomic publish: concurrent ranks never see a partial file
+    extra = os.environ.get("MEL_HIPCC_FLAGS", "").split()         # tuning experiments (-DMEL_ATT_G=8 ...)
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", *srcs, "-o", tmp]
+           "-ffp-contract=off", *extra, *srcs, "-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -111,9 +111,17 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     if (g.M <= 0) return MEL_OK;
     if (mel_status st = check_gemm_shape(g, what)) return st;
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
+    // encoder (ENC producer): a 64 x 128 tile spans the whole hidden width, so the first layer (VALU work inside the
+    // A-tile producer) is evaluated once per row instead of once per 64-column tile
+    const bool enc_wide = g.bf16 && mode == GEMM_MODE_ENC && force_tile == 0 && g.N % 128 == 0;   // fp32: measured slower (21 vs 18 us)
     if (g.bf16) {
         if (force_tile == 2 && g.N % 128 == 0) gemm_launch_bf16<2, 2, 2, 2>(&g, 1, mode, stream);
+        else if (enc_wide) gemm_launch_bf16<2, 2, 1, 2>(&g, 1, mode, stream);
         else gemm_launch_bf16<2, 2, 1, 1>(&g, 1, mode, stream);
+        return check_launch(what);
+    }
+    if (enc_wide) {
+        gemm_launch_persistent<2, 2, 1, 2>(&g, 1, mode, stream);
         return check_launch(what);
     }
     if (force_tile == 1 || (force_tile >= 2 && g.N % 128 == 0)) {
@@ -325,12 +333,27 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) 
 
 __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
                                                          int obs_stride, int node_cols, PlanBuffers p,
-                                                         int32_t* __restrict__ row_offsets_out, int self_loops) {
+                                                         int32_t* __restrict__ row_offsets_out, int self_loops,
+                                                         int inline_scan) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
     const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
-    const int oL = p.offL[b], o1 = p.off1[b], o2 = p.off2[b];
+    int oL, o1, o2;
+    if (inline_scan) {
+        // exclusive prefix of the three per-env counts, recomputed by every wave from the cnt array (a few KB out
+        // of L2): cheaper than a separate single-workgroup scan launch between the two plan kernels
+        int sL = 0, s1 = 0, s2 = 0;
+        for (int i = lane; i < b; i += 64) sL += p.cnt[i], s1 += p.cnt[bs + i], s2 += p.cnt[2 * bs + i];
+        oL = wave_sum_i32_dpp(sL), o1 = wave_sum_i32_dpp(s1), o2 = wave_sum_i32_dpp(s2);
+        if (lane == 0) {
+            p.offL[b] = oL, p.off1[b] = o1, p.off2[b] = o2;
+            if (b == bs - 1)
+                p.offL[bs] = oL + p.cnt[b], p.off1[bs] = o1 + p.cnt[bs + b], p.off2[bs] = o2 + p.cnt[2 * bs + b];
+        }
+    } else {
+        oL = p.offL[b], o1 = p.off1[b], o2 = p.off2[b];
+    }
     const float* row = obs + (size_t)b * obs_stride;
     const float dm = (lane < n) ? row[lane * node_cols + node_cols - 1] : 0.f;
     if ((u2 >> lane) & 1ull) p.nid2[o2 + rank_below(u2, lane)] = b * n + lane;
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict
     }
     if (row_offsets_out && lane == 0) {
         row_offsets_out[b] = oL;
-        if (b == bs - 1) row_offsets_out[bs] = p.offL[bs];
+        if (b == bs - 1) row_offsets_out[bs] = oL + p.cnt[b];
     }
 }
 
@@ -517,7 +540,10 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
                                                   uint64_t smask, int soff, const Vec<VPL>& att,
                                                   const Vec<VPL>& bias, int lane) {
     constexpr int HC = 64 * VPL;
-    constexpr int G = 4;
+#ifndef MEL_ATT_G
+#define MEL_ATT_G 4      // measured 2 / 3 / 4 / 8 sources per step: 24.9 / 25.9 / 25.7 / 29.9 us (conv1, round loop)
+#endif
+    constexpr int G = MEL_ATT_G;
     const Vec<VPL> xr = load_row<VPL, BF>(a.xr, xr_row * a.ld_r + lane * VPL);
     float m = -INFINITY, l = 0.f;
     Vec<VPL> acc;
@@ -573,14 +599,19 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
             if constexpr (KIND == MEL_CONV_TRANSFORMER) sc_[k] *= a.score_scale;
             if (!on[k]) sc_[k] = -INFINITY;
         }
-        const float mn = fmaxf(fmaxf(m, fmaxf(sc_[0], sc_[1])), fmaxf(sc_[2], sc_[3]));
+        float mn = m;
+#pragma unroll
+        for (int k = 0; k < G; ++k) mn = fmaxf(mn, sc_[k]);
         // e^x as v_exp_f32(x log2 e): ~1e-6 relative on softmax weights that are later normalised (the libm
         // expansion was a quarter of this kernel's VALU work, and the kernel is VALU / latency bound)
         const float rs = fast_exp(m - mn);       // slot 0 is always on, so mn is finite
         float pe[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) pe[k] = fast_exp(sc_[k] - mn);   // exp(-inf) = 0 for the off slots
-        l = l * rs + ((pe[0] + pe[1]) + (pe[2] + pe[3]));
+        float ps = 0.f;
+#pragma unroll
+        for (int k = 0; k < G; ++k) ps += pe[k];
+        l = l * rs + ps;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             float t = acc.v[i] * rs;
@@ -1209,10 +1240,13 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         StageScope t(MEL_STAGE_PLAN, s);
         hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
         if (mel_status st = check_launch("plan_masks")) return st;
-        hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
-        if (mel_status st = check_launch("plan_scan")) return st;
+        const int inline_scan = bs <= 8192;           // beyond that the per-wave re-scan (O(bs^2 / 64) loads) loses
+        if (!inline_scan) {
+            hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
+            if (mel_status st = check_launch("plan_scan")) return st;
+        }
         hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out,
-                           tconv ? 0 : 1);
+                           tconv ? 0 : 1, inline_scan);
         if (mel_status st = check_launch("plan_lists")) return st;
     }
     {   // encoder on the U2 rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)

@@ -77,7 +77,7 @@ def test_hldgn_matches_golden(path, agg):
 
 
 @pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])
-@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (1, 5), (7, 1)])
+@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (1, 5), (7, 1), (5, 9000)])   # 9000 > 8192: separate scan launch
 def test_matches_oracle_on_random_batches(model, n, bs):
     """Fresh seeded inputs at sizes the oracle finishes in seconds (incl. ragged / tiny / max-N cases)."""
     from oracle import net_oracle as no
