@@ -237,7 +237,7 @@ def main():
         # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied there); only valid for the
         # workload those passes were taken on.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
         if (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
                 and args.dtype == "f32" and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))["per_launch"]
@@ -246,7 +246,13 @@ def main():
                 traffic = pmc[key]["hbm_bytes_corrected"]
         achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        roofline = {"bound": "mfma", "kernel": f"gemm_{args.dtype}_kernel ({dom})", "achieved": round(achieved, 3),
+        # name as it appears in rocprofv3 summaries (fp32 round loop: the persistent kernel tagged per call site)
+        tag = {"conv1_lin": 1, "conv2_lin": 2, "head_hidden": 3}.get(dom, 0)
+        if args.dtype == "f32" and args.mode == "round" and args.model != "hl_dgn" and dom != "encoder":
+            kname = f"mel::gemm_f32_persistent_kernel<2, 2, 1, 1, 0, {tag}> ({dom})"
+        else:
+            kname = f"gemm_{args.dtype} ({dom})"
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 3),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "avg_launch_us": round(stages[dom], 2),
                     "algorithmic_flops_per_launch": fl[dom],

@@ -41,7 +41,7 @@ static void gemm_launch_t(const GemmArgs* gs, int count, int mode, hipStream_t s
         hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int TAG = 0>
 static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDS_STAGE = (BM + BN) * GEMM_LDS_STRIDE * 4 * 2;
@@ -58,7 +58,17 @@ static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipS
     if (mode == GEMM_MODE_ENC)
         hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
     else
-        hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+        hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+}
+
+// ragged 64 x 64 launches of the round step, named per call site
+static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int tag) {
+    switch (tag) {
+        case 1: gemm_launch_persistent<2, 2, 1, 1, 1>(gs, count, GEMM_MODE_PLAIN, s); break;
+        case 2: gemm_launch_persistent<2, 2, 1, 1, 2>(gs, count, GEMM_MODE_PLAIN, s); break;
+        case 3: gemm_launch_persistent<2, 2, 1, 1, 3>(gs, count, GEMM_MODE_PLAIN, s); break;
+        default: gemm_launch_persistent<2, 2, 1, 1, 0>(gs, count, GEMM_MODE_PLAIN, s); break;
+    }
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -107,7 +117,8 @@ static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
     return MEL_OK;
 }
 
-mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint, int force_tile) {
+mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint, int force_tile,
+                       int tag) {
     if (g.M <= 0) return MEL_OK;
     if (mel_status st = check_gemm_shape(g, what)) return st;
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
@@ -143,7 +154,9 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     // Measured (tools/gemm_bench.py): the 64x64 tile (4x the workgroups, a quarter of the per-wave MFMA
     // chain, 4 workgroups per CU) wins or ties everywhere except long-K problems with thousands of tiles.
     const long big = ((m_hint + 127) / 128) * (g.N / 128);
-    if (g.M_dev)
+    if (g.M_dev && mode == GEMM_MODE_PLAIN)
+        gemm_launch_ragged(&g, 1, stream, tag);
+    else if (g.M_dev)
         gemm_launch_persistent<2, 2, 1, 1>(&g, 1, mode, stream);
     else if (g.N % 128 == 0 && big >= 1536 && g.K >= 512)
         gemm_launch_t<2, 2, 2, 2>(&g, 1, mode, stream);
@@ -152,7 +165,8 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     return check_launch(what);
 }
 
-mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, hipStream_t stream, const char* what) {
+mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, hipStream_t stream, const char* what,
+                             int tag) {
     if (count < 1 || count > GEMM_MAX_GROUP) return fail(MEL_ERR_INVALID_ARG, "%s: group of %d", what, count);
     long big = 0;
     bool n128 = true, long_k = true;
@@ -173,7 +187,7 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
     bool ragged = false;
     for (int i = 0; i < count; ++i) ragged = ragged || gs[i].M_dev != nullptr;
     if (ragged)       // device-side row counts: a fixed grid walks the tiles instead of a worst-case grid exiting
-        gemm_launch_persistent<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
+        gemm_launch_ragged(gs, count, stream, tag);
     else if (n128 && long_k && big >= 1536)
         gemm_launch_t<2, 2, 2, 2>(gs, count, GEMM_MODE_PLAIN, stream);
     else
@@ -1178,7 +1192,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             g.W = pw.q[i], g.W_hi = pw.v[i], g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
             g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
             g.bf16 = bf, g.y_f32 = (i + 2 == nl);       // the tail reads fp32
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint)) return st;
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint, 0, 3)) return st;
         } else {
             GemmArgs g[2];
             // element offset of the V half inside a row: in elements of the buffer's type (bf16 halves the bytes)
@@ -1191,7 +1205,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             g[0].bf16 = g[1].bf16 = bf, g[0].y_f32 = g[1].y_f32 = (bf && out32);
             (void)in16;
             const long hints[2] = {rows_hint, rows_hint};
-            if (mel_status st = launch_gemm_group(g, hints, w->dueling ? 2 : 1, s, "Q + V hidden")) return st;
+            if (mel_status st = launch_gemm_group(g, hints, w->dueling ? 2 : 1, s, "Q + V hidden", 3)) return st;
         }
         const bool out16 = bf && !(i + 2 == nl);
         in_q = out, ld_q = ld_v = ldo;
@@ -1271,7 +1285,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g[1].Y = L.xr1, g[1].ldy = hc, g[1].M = U1, g[1].M_dev = n1, g[1].N = hc, g[1].K = hidden;
         const long hints[2] = {hint2, hint1};
         StageScope t(MEL_STAGE_CONV1_LIN, s);
-        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r")) return st;
+        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r", 1)) return st;
     }
     {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
         AttArgs a{};
@@ -1298,7 +1312,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;
         const long hints[2] = {hint1, hintL};
         StageScope t(MEL_STAGE_CONV2_LIN, s);
-        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv2.lin_l + lin_r")) return st;
+        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv2.lin_l + lin_r", 2)) return st;
     }
     {   // conv2 attention, one target per agent row -> x_3
         AttArgs a{};

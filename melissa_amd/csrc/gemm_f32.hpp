@@ -288,7 +288,9 @@ struct TileCtx {
     int m0, n0, M, pi, KT;
 };
 
-template <int WM, int WN, int TM, int TN, int MODE>
+// TAG only names the call site (1 = conv1, 2 = conv2, 3 = head hidden layers, 0 = anything else) so that profiler
+// summaries list the launches of one step separately instead of averaging them under one kernel name.
+template <int WM, int WN, int TM, int TN, int MODE, int TAG = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(GemmBatch batch) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN;
     constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;
@@ -647,8 +649,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_glds_kernel(GemmBatc
 // Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.  `m_hint` is the row
 // count the caller expects (ragged lists are sized on the device; the grid still covers g.M rows).
 mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1,
-                       int force_tile = 0);
+                       int force_tile = 0, int tag = 0);
 // Several PLAIN problems in one launch; hints[i] = expected rows of problem i (-1 = g.M).
-mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, hipStream_t stream, const char* what);
+mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, hipStream_t stream, const char* what,
+                             int tag = 0);
 
 }  // namespace mel
