@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="round mode: sub-batches of the GPU's envs on separate HIP streams (measured: no gain "
                          "in one process, 16.3 vs 16.2 M/s at 2 streams, worse at 3-4)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"],
                     help="f32 (default): the reference's arithmetic, logits within 1e-4.  bf16: BASELINE's 'bf16 feature "
                          "path' (feature rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,7 +245,8 @@ def main():
             if key in pmc:
                 traffic = pmc[key]["hbm_bytes_corrected"]
         achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        # f32s: six bf16 MFMAs per product term set -> the matrix-pipe ceiling for fp32-accurate FLOPs is 2.5 PF / 6
+        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
         # name as it appears in rocprofv3 summaries (fp32 round loop: the persistent kernel tagged per call site)
         tag = {"conv1_lin": 1, "conv2_lin": 2, "head_hidden": 3}.get(dom, 0)
         if args.dtype == "f32" and args.mode == "round" and args.model != "hl_dgn" and dom != "encoder":
@@ -283,7 +284,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs "
-                               f"per GPU, {'fp32' if args.dtype == 'f32' else 'bf16 feature path'}, dynamic graph, eps=0.001, "
+                               f"per GPU, {dict(f32='fp32', bf16='bf16 feature path', f32s='fp32 via split-bf16 MFMA')[args.dtype]}, dynamic graph, eps=0.001, "
                                + ("round-batched loop (one env round per step)" if args.mode == "round"
                                   else "AEC-order loop (one agent decision per env per step)"),
                    "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),

@@ -100,7 +100,7 @@ typedef struct mel_weights {
     mel_gatv2 conv2;       /* unused for HL-DGN                                      */
     mel_mlp   q_head;      /* latent -> ... -> n_actions                             */
     mel_mlp   v_head;      /* latent -> ... -> 1                                     */
-    int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4) or MEL_PREC_BF16 */
+    int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4), MEL_PREC_BF16 or MEL_PREC_F32_SPLIT */
     int32_t reserved;
 } mel_weights;
 
@@ -112,6 +112,11 @@ typedef struct mel_weights {
  * logits stay fp32.  Not the reference's arithmetic: expect ~1e-2 absolute on logits (tests state the bound). */
 #define MEL_PREC_F32  0
 #define MEL_PREC_BF16 1
+/* MEL_PREC_F32_SPLIT: fp32 features and fp32-accurate results, with the dense projections evaluated on the bf16 matrix
+ * cores by operand splitting (x = hi + mid + lo in bf16, exactly; six of the nine partial products, each exact in
+ * fp32, accumulated in fp32).  As close to the exact dot product as a native fp32 GEMM (csrc/gemm_split.hpp); the
+ * reference's parity bar (logits <= 1e-4) holds with the same margin as MEL_PREC_F32. */
+#define MEL_PREC_F32_SPLIT 2
 
 /* Bytes of scratch the forward needs for `bs` observation rows of `n_nodes`-node graphs. */
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes);

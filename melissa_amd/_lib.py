@@ -26,7 +26,7 @@ EXPORTS = ("mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_bac
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
 HEURISTICS = {None: 0, "simple_broadcast": 1, "broadcast_if_any_interested": 2, "silent": 3}
 N_STAGES = 14
 STAGE_NAMES = ("plan", "encoder", "conv1_lin", "conv1_lin_r", "conv1_att", "conv2_lin", "conv2_lin_r", "conv2_att",

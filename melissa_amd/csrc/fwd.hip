@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "gemm_f32.hpp"
 #include "gemm_bf16.hpp"
+#include "gemm_split.hpp"
 
 namespace mel {
 
@@ -108,7 +109,34 @@ static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_
         hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
 }
 
+// split path: one persistent 64 x 64 kernel, named per call site like the fp32 one
+template <int TAG>
+static void gemm_launch_split_t(const GemmArgs* gs, int count, int mode, hipStream_t s) {
+    GemmBatch batch{};
+    batch.count = count;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        tiles += ((long)((gs[i].M + 63) / 64) * (gs[i].N / 64) + 7) & ~7L;
+    }
+    long grid = 256L * 3;                          // 53 KB of LDS per workgroup: three per CU
+    if (grid > tiles) grid = tiles;
+    if (mode == GEMM_MODE_ENC)
+        hipLaunchKernelGGL((gemm_split_kernel<GEMM_MODE_ENC, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
+    else
+        hipLaunchKernelGGL((gemm_split_kernel<GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
+}
+static void gemm_launch_split(const GemmArgs* gs, int count, int mode, hipStream_t s, int tag) {
+    switch (tag) {
+        case 1: gemm_launch_split_t<1>(gs, count, mode, s); break;
+        case 2: gemm_launch_split_t<2>(gs, count, mode, s); break;
+        case 3: gemm_launch_split_t<3>(gs, count, mode, s); break;
+        default: gemm_launch_split_t<0>(gs, count, mode, s); break;
+    }
+}
+
 static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
+    if (g.split && g.K < 128) return fail(MEL_ERR_UNSUPPORTED, "%s: the split path needs K >= 128 (K=%d)", what, g.K);
     const int bk = g.bf16 ? GEMB_BK : GEMM_BK;
     if (g.K % bk != 0 || g.N % 64 != 0)
         return fail(MEL_ERR_UNSUPPORTED, "%s: GEMM needs K %% %d == 0 and N %% 64 == 0 (K=%d N=%d)", what, bk, g.K, g.N);
@@ -122,6 +150,10 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     if (g.M <= 0) return MEL_OK;
     if (mel_status st = check_gemm_shape(g, what)) return st;
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
+    if (g.split) {
+        gemm_launch_split(&g, 1, mode, stream, tag);
+        return check_launch(what);
+    }
     // encoder (ENC producer): a 64 x 128 tile spans the whole hidden width, so the first layer (VALU work inside the
     // A-tile producer) is evaluated once per row instead of once per 64-column tile
     const bool enc_wide = g.bf16 && mode == GEMM_MODE_ENC && force_tile == 0 && g.N % 128 == 0;   // fp32: measured slower (21 vs 18 us)
@@ -177,6 +209,12 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
         big += ((h + 127) / 128) * (gs[i].N / 128);
         n128 = n128 && gs[i].N % 128 == 0;
         long_k = long_k && gs[i].K >= 512;
+    }
+    if (gs[0].split) {
+        for (int i = 1; i < count; ++i)
+            if (!gs[i].split) return fail(MEL_ERR_INVALID_ARG, "%s: mixed precisions in one group", what);
+        gemm_launch_split(gs, count, GEMM_MODE_PLAIN, stream, tag);
+        return check_launch(what);
     }
     if (gs[0].bf16) {
         for (int i = 1; i < count; ++i)
@@ -1077,7 +1115,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.minmax = c.take<float>(64);
-    L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w) : 0;
+    L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
+                 : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
     L.wb = c.take<uint16_t>(L.wb_elems ? L.wb_elems : 8);
     L.bytes = c.off;
     return L;
@@ -1089,7 +1128,7 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
     if (bs <= 0 || bs > (1 << 24)) return fail(MEL_ERR_INVALID_ARG, "bs=%ld out of range", (long)bs);
     if (n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, %d]", n, MEL_MAX_NODES);
     if (w->in_dim < 1 || w->in_dim > 8) return fail(MEL_ERR_UNSUPPORTED, "in_dim=%d outside [1, 8]", w->in_dim);
-    if (w->precision != MEL_PREC_F32 && w->precision != MEL_PREC_BF16) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
+    if (w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_SPLIT) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
     const int expected = n * (w->in_dim + 3);
     if (index_col) {
         if (obs_stride - 1 != expected)      // networks/common.py:24-29
@@ -1147,6 +1186,25 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
 // fp32: alias the parameters.  bf16: convert all projection weights into L.wb with one launch.
 static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, hipStream_t s) {
     pw = ProjWeights{};
+    if (w->precision == MEL_PREC_F32_SPLIT) {        // [rows][3][K] bf16 planes of every projection weight
+        SplitBatch b{};
+        size_t off = 0;
+        int blocks = 0;
+        bool bad = false;
+        for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) {
+            const size_t cnt = lin_elems(l);
+            if (b.n >= CVT_MAX_SEG || cnt % 8 != 0 || l.in_dim % 32 != 0 || !l.weight) { bad = true; return; }
+            b.src[b.n] = l.weight, b.dst[b.n] = L.wb + off, b.count[b.n] = (int)cnt, b.K[b.n] = l.in_dim, b.start[b.n] = blocks;
+            *slot = reinterpret_cast<const float*>(L.wb + off);
+            blocks += (int)((cnt / 4 + 255) / 256);
+            off += 3 * ((cnt + 7) & ~(size_t)7);
+            ++b.n;
+        });
+        if (bad) return fail(MEL_ERR_UNSUPPORTED, "split path: a projection weight is null or its shape is unsupported");
+        b.start[b.n] = blocks;
+        hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, s, b);
+        return check_launch("weights -> bf16 planes");
+    }
     if (w->precision != MEL_PREC_BF16) {
         for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) { *slot = l.weight; });
         return MEL_OK;
@@ -1177,6 +1235,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
                             const mel_select* select = nullptr) {
     const int nl = w->q_head.n_layers;
     const int bf = w->precision == MEL_PREC_BF16;
+    const int sp = w->precision == MEL_PREC_F32_SPLIT;
     const float* in_q = L.xcat;
     const float* in_v = L.xcat;
     int ld_q = w->q_head.layer[0].in_dim, ld_v = ld_q;
@@ -1191,7 +1250,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             g.A = in_q, g.lda = ld_q;
             g.W = pw.q[i], g.W_hi = pw.v[i], g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
             g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
-            g.bf16 = bf, g.y_f32 = (i + 2 == nl);       // the tail reads fp32
+            g.bf16 = bf, g.split = sp, g.y_f32 = (i + 2 == nl);       // the tail reads fp32
             if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint, 0, 3)) return st;
         } else {
             GemmArgs g[2];
@@ -1202,7 +1261,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             g[1].A = in_v, g[1].lda = ld_v, g[1].W = pw.v[i], g[1].bias = v.bias;
             g[1].Y = out32 ? out + q.out_dim : reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(out) + q.out_dim);
             g[1].ldy = ldo, g[1].M = (int)rows, g[1].M_dev = rows_dev, g[1].N = v.out_dim, g[1].K = v.in_dim, g[1].relu = 1;
-            g[0].bf16 = g[1].bf16 = bf, g[0].y_f32 = g[1].y_f32 = (bf && out32);
+            g[0].bf16 = g[1].bf16 = bf, g[0].split = g[1].split = sp, g[0].y_f32 = g[1].y_f32 = (bf && out32);
             (void)in16;
             const long hints[2] = {rows_hint, rows_hint};
             if (mel_status st = launch_gemm_group(g, hints, w->dueling ? 2 : 1, s, "Q + V hidden", 3)) return st;
@@ -1244,6 +1303,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     // with overlapping neighbourhoods): |U1| ~ 0.21 N, |U2| ~ 0.32 N.
     const bool single = agent_mask == nullptr;
     const int bf = w->precision == MEL_PREC_BF16;
+    const int sp = w->precision == MEL_PREC_F32_SPLIT;
     ProjWeights pw;
     if (mel_status st = resolve_projections(w, L, pw, s)) return st;
     const long hintL = single ? bs : bs * (long)(n < 10 ? 1 : n / 10);
@@ -1267,7 +1327,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         GemmArgs g;
         g.obs = obs, g.obs_width = obs_stride, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
         g.nid = L.plan.nid2, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf;
+        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
         g.Y = L.h0, g.ldy = hidden, g.M = U2, g.M_dev = n2, g.N = hidden;
         g.K = w->encoder.layer[0].out_dim, g.relu = 1;
         StageScope t(MEL_STAGE_ENCODER, s);
@@ -1275,7 +1335,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     }
     {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
         GemmArgs g[2];
-        g[0].bf16 = g[1].bf16 = bf;
+        g[0].bf16 = g[1].bf16 = bf, g[0].split = g[1].split = sp;
         g[0].A = L.h0, g[0].lda = hidden, g[0].W = pw.c1l, g[0].bias = w->conv1.lin_l.bias;
         g[0].Y = L.xl1, g[0].ldy = srcw, g[0].M = U2, g[0].M_dev = n2, g[0].N = srcw, g[0].K = hidden;
         if (tconv)       // key | value of the sources in one problem (weights split along n)
@@ -1302,7 +1362,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     {   // conv2.lin_l on the U1 rows + conv2.lin_r on the agent rows, one grouped launch; the decision-maker
         // mask (l_dgn.py:128) rides along as a row scale
         GemmArgs g[2];
-        g[0].bf16 = g[1].bf16 = bf;
+        g[0].bf16 = g[1].bf16 = bf, g[0].split = g[1].split = sp;
         g[0].A = L.h1, g[0].lda = hc, g[0].rscale = L.plan.dm1;
         g[0].W = pw.c2l, g[0].bias = w->conv2.lin_l.bias;
         g[0].Y = L.xl2, g[0].ldy = srcw, g[0].M = U1, g[0].M_dev = n1, g[0].N = srcw, g[0].K = hc;
@@ -1414,6 +1474,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int M = (int)(bs * n);
     const int bf = w->precision == MEL_PREC_BF16;
+    const int sp = w->precision == MEL_PREC_F32_SPLIT;
     ProjWeights pw;
     if (mel_status st = resolve_projections(w, L, pw, s)) return st;
 
@@ -1428,7 +1489,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         GemmArgs g;
         g.obs = obs, g.obs_width = obs_width, g.n_nodes = n, g.in_dim = w->in_dim, g.node_cols = node_cols;
         g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf;
+        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
         StageScope t(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
@@ -1436,7 +1497,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     {   // x_l | x_r for every node in one GEMM (weights split along n)
         GemmArgs g;
         g.A = L.h0, g.lda = hidden;
-        g.W = pw.c1l, g.W_hi = pw.c1r, g.bf16 = bf;
+        g.W = pw.c1l, g.W_hi = pw.c1r, g.bf16 = bf, g.split = sp;
         g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
         g.Y = L.xl1, g.ldy = 2 * hc, g.M = M, g.N = 2 * hc, g.K = hidden;
         StageScope t(MEL_STAGE_CONV1_LIN, s);

@@ -62,6 +62,8 @@ struct GemmArgs {
     // fp32 when y_f32 is set.  bias / rscale / obs / enc_* are fp32 on both paths.
     int bf16 = 0;
     int y_f32 = 0;
+    // split path (gemm_split.hpp): A / Y fp32 as usual, W / W_hi point at [N][3][K] bf16 planes (hi | mid | lo)
+    int split = 0;
 };
 
 // Up to four independent problems in one launch (e.g. conv.lin_l + conv.lin_r, or the Q and V hidden layers):

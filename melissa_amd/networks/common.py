@@ -137,12 +137,13 @@ class HipForwardMixin:
     _MODEL = None          # set by subclasses
 
     # "f32": the reference's arithmetic (logits within 1e-4).  "bf16": BASELINE's "bf16 feature path" - feature
-    # rows and projection weights in bf16, fp32 accumulation / softmax / logits (include/melissa_hip.h MEL_PREC_*).
+    # rows and projection weights in bf16, fp32 accumulation / softmax / logits.  "f32s": fp32 features and
+    # fp32-accurate projections evaluated on the bf16 matrix cores by operand splitting (MEL_PREC_F32_SPLIT).
     feature_dtype = "f32"
 
     def set_feature_dtype(self, name: str):
-        if name not in ("f32", "bf16"):
-            raise ValueError(f"feature_dtype must be 'f32' or 'bf16', got {name!r}")
+        if name not in ("f32", "bf16", "f32s"):
+            raise ValueError(f"feature_dtype must be 'f32', 'bf16' or 'f32s', got {name!r}")
         self.feature_dtype = name
         self._w_cache = None
         return self
@@ -173,7 +174,7 @@ class HipForwardMixin:
             _mlp(w.q_head, [self.out_linear])
             _mlp(w.v_head, [self.out_linear])     # ignored by the kernels when dueling == 0
             w.v_head.layer[0].out_dim = 1
-        w.precision = _lib.PREC_BF16 if self.feature_dtype == "bf16" else _lib.PREC_F32
+        w.precision = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f32s": _lib.PREC_F32_SPLIT}[self.feature_dtype]
         self._w_cache = (key, w)
         return w
 

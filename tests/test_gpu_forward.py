@@ -170,3 +170,45 @@ def test_non_dueling_head_and_select_action():
     base = got.argmax(1)
     expect = torch.where(ru < 0.5, rq.argmax(1), base)
     assert act.cpu().tolist() == expect.cpu().tolist()
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])
+@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (7, 1)])
+def test_split_precision_meets_the_fp32_bar(model, n, bs):
+    """MEL_PREC_F32_SPLIT ("f32s"): fp32 features, projections on the bf16 matrix cores by exact operand splitting
+    (csrc/gemm_split.hpp).  Same bar as the native fp32 path: logits within 1e-4 of the oracle; measured error is
+    reported next to the native path's."""
+    from oracle import net_oracle as no
+    rng = np.random.RandomState(400 + n + bs)
+    obs = np.zeros((bs, 8 * n + 1), dtype=np.float32)
+    m = obs[:, :-1].reshape(bs, n, 8)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2] = rng.randint(0, 9, size=(bs, n))
+    m[:, :, 3] = rng.randint(0, 4, size=(bs, n))
+    m[:, :, 4:7] = rng.randint(0, 2, size=(bs, n, 3))
+    m[:, :, 7] = (rng.uniform(size=(bs, n)) > 0.1)
+    obs[:, -1] = rng.randint(0, n, size=bs)
+    net, sd = make_net(model, n, seed=31)
+    with torch.no_grad():
+        native = net(obs)[0].cpu().numpy()
+        net.set_feature_dtype("f32s")
+        got = net(obs)[0].cpu().numpy()
+        torch.set_num_threads(8)
+        fwd = {"l_dgn": no.ldgn_forward, "hl_dgn": no.hldgn_forward, "dgn_r": no.dgnr_forward}[model]
+        want = fwd(sd, obs, n).numpy()
+    print(f"{model} N={n}: max |logit error| split {np.abs(got - want).max():.2e}, native fp32 MFMA {np.abs(native - want).max():.2e}")
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+    assert not np.array_equal(got, native) or bs == 1          # a different summation: the split path really ran
+
+
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[11:-4] for p in GOLDENS])
+def test_split_precision_matches_golden(path):
+    g = np.load(path)
+    n, obs = int(g["n"]), g["obs"]
+    net, _ = make_net("l_dgn", n, int(g["weight_seed"]))
+    net.set_feature_dtype("f32s")
+    with torch.no_grad():
+        logits, _ = net(obs)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["ldgn_logits"], atol=TOL, rtol=0)
+    xcat = net.hip_tap(1, obs.shape[0]).cpu().numpy()
+    np.testing.assert_allclose(xcat, np.concatenate([g["ldgn_x_1"], g["ldgn_x_2"], g["ldgn_x_3"]], axis=1), atol=TOL, rtol=0)
