@@ -233,770 +233,13 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
     return check_launch(what);
 }
 
-// ------------------------------------------------------------------------------------------------
-// plan: one wavefront per env (= observation row), lane = node
-//
-// The forward is evaluated for a SET of controlling agents per env (mask L).  The reference's collector
-// presents one agent per observation row (L = {obs[:, -1]}, common.py:63); within one env round every
-// active agent sees the same obs_matrix (graph.py:186-188: rows differ only in the last column), so the
-// round-batched loop passes all of a round's agents at once and the encoder / conv1 work is shared:
-//   U1 = union over g in L of closed one-hop(g)   - conv1 targets that can reach some agent's logits
-//   U2 = union over t in U1 of closed one-hop(t)  - their sources
-// Rows are packed per env in id order, so the packed position of node j is popcount(mask below j).
-// ------------------------------------------------------------------------------------------------
-// everything the attention kernel needs to know about one target row, in one 32-byte load
-struct TargetDesc {
-    uint64_t sources;   // source nodes of the target (closed neighbourhood for GATv2, open for TransformerConv)
-    uint64_t smask;     // node set the source rows are packed by
-    int32_t soff;       // first source row of the env
-    int32_t env;
-    int32_t node;
-    int32_t cat_row;    // conv1: agent row whose head input takes x_1 / x_2 from this target, or -1
-};
+}  // namespace mel
 
-struct PlanBuffers {
-    uint64_t* adj;      // [bs*N] sources of target i (radius rule, self excluded)
-    uint64_t* live;     // [bs]   L: controlling agents of the env
-    uint64_t* u1;       // [bs]
-    uint64_t* u2;       // [bs]
-    int32_t* cnt;       // [3*bs] |L|, |U1|, |U2|
-    int32_t* offL;      // [bs+1] exclusive scans (last entry = total)
-    int32_t* off1;      // [bs+1]
-    int32_t* off2;      // [bs+1]
-    int32_t* nid2;      // [sum|U2|] global node id (b*N + i) of packed row
-    int32_t* arow1;     // [sum|U1|] row of the U2 list holding the same node
-    float* dm1;         // [sum|U1|] decision-maker flag of the node (l_dgn.py:128)
-    TargetDesc* desc1;  // [sum|U1|] conv1 target rows
-    TargetDesc* desc2;  // [R]       conv2 target rows (one per agent row)
-    int32_t* row_env;   // [R] env of agent row r
-    int32_t* row_agent; // [R] agent (node id) of agent row r
-    int32_t* arow_g;    // [R] row of the U1 list holding the agent
-    float* dm_g;        // [R]
-};
+#include "plan.hpp"
+#include "attention.hpp"
+#include "heads.hpp"
 
-// [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
-// positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
-// the first 33 hits in index order (self included) survive, then self is dropped.
-__device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
-    const float r2 = (float)(0.2 * 0.2);
-    uint64_t m = 0;
-    for (int j = 0; j < n; ++j) {
-        const float xj = lane_f32(x, j), yj = lane_f32(y, j);     // j is the loop counter: v_readlane
-        const float dx = x - xj, dy = y - yj;
-        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-        if (d2 < r2) m |= 1ull << j;
-    }
-    while (__popcll(m) > 33) m &= ~(1ull << (63 - __clzll((long long)m)));
-    return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
-}
-
-// standalone adjacency for the learn path (one wave per observation row)
-__global__ __launch_bounds__(256) void radius_graph_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
-                                                           int node_cols, uint64_t* __restrict__ adj) {
-    const int lane = lane_id();
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= bs) return;
-    float x = 0.f, y = 0.f;
-    if (lane < n) {
-        const float* p = obs + (size_t)b * obs_stride + lane * node_cols;
-        x = p[0], y = p[1];
-    }
-    const uint64_t m = radius_sources(x, y, lane, n);
-    if (lane < n) adj[(size_t)b * n + lane] = m;
-}
-
-// agent_mask == null: one agent per row, taken from the index column (common.py:63)
-__global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict__ obs, int bs, int n,
-                                                         int obs_stride, int node_cols,
-                                                         const uint64_t* __restrict__ agent_mask, PlanBuffers p,
-                                                         int want_receptive) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= bs) return;
-    const int lane = lane_id();
-    const float* row = obs + (size_t)b * obs_stride;
-    float x = 0.f, y = 0.f;
-    if (lane < n) {
-        x = row[lane * node_cols];
-        y = row[lane * node_cols + 1];
-    }
-    const uint64_t src = radius_sources(x, y, lane, n);
-    if (lane < n) p.adj[(size_t)b * n + lane] = src;
-    const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-    uint64_t live;
-    if (want_receptive < 0) {              // adjacency only: the row has no index column
-        return;
-    } else if (agent_mask) {
-        live = agent_mask[b] & full;
-    } else {                               // obs[:, -1].clamp(0, N-1).long()
-        float gf = row[n * node_cols];
-        gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
-        live = 1ull << (int)gf;
-    }
-    if (!want_receptive) {
-        if (lane == 0) p.live[b] = live;
-        return;
-    }
-    const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
-    const uint64_t u1 = wave_or_u64(((live >> lane) & 1ull) ? closed : 0ull);
-    const uint64_t u2 = wave_or_u64(((u1 >> lane) & 1ull) ? closed : 0ull);
-    if (lane == 0) {
-        p.live[b] = live;
-        p.u1[b] = u1;
-        p.u2[b] = u2;
-        p.cnt[b] = __popcll(live);
-        p.cnt[bs + b] = __popcll(u1);
-        p.cnt[2 * bs + b] = __popcll(u2);
-    }
-}
-
-// exclusive scans of |L|, |U1|, |U2| over the batch (single workgroup, any bs)
-__global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) {
-    __shared__ int32_t part[3][1024];
-    const int tid = threadIdx.x;
-    const int per = (bs + 1023) / 1024;
-    const int lo = min(tid * per, bs), hi = min(lo + per, bs);
-    int32_t s[3] = {0, 0, 0};
-    for (int b = lo; b < hi; ++b)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k] += p.cnt[k * bs + b];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) part[k][tid] = s[k];
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int32_t a[3] = {0, 0, 0};
-        if (tid >= d)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a[k] = part[k][tid - d];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) part[k][tid] += a[k];
-        __syncthreads();
-    }
-    int32_t o[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) o[k] = part[k][tid] - s[k];
-    for (int b = lo; b < hi; ++b) {
-        p.offL[b] = o[0], p.off1[b] = o[1], p.off2[b] = o[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] += p.cnt[k * bs + b];
-    }
-    if (tid == 1023) p.offL[bs] = part[0][1023], p.off1[bs] = part[1][1023], p.off2[bs] = part[2][1023];
-}
-
-__global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
-                                                         int obs_stride, int node_cols, PlanBuffers p,
-                                                         int32_t* __restrict__ row_offsets_out, int self_loops,
-                                                         int inline_scan) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= bs) return;
-    const int lane = lane_id();
-    const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
-    int oL, o1, o2;
-    if (inline_scan) {
-        // exclusive prefix of the three per-env counts, recomputed by every wave from the cnt array (a few KB out
-        // of L2): cheaper than a separate single-workgroup scan launch between the two plan kernels
-        int sL = 0, s1 = 0, s2 = 0;
-        for (int i = lane; i < b; i += 64) sL += p.cnt[i], s1 += p.cnt[bs + i], s2 += p.cnt[2 * bs + i];
-        oL = wave_sum_i32_dpp(sL), o1 = wave_sum_i32_dpp(s1), o2 = wave_sum_i32_dpp(s2);
-        if (lane == 0) {
-            p.offL[b] = oL, p.off1[b] = o1, p.off2[b] = o2;
-            if (b == bs - 1)
-                p.offL[bs] = oL + p.cnt[b], p.off1[bs] = o1 + p.cnt[bs + b], p.off2[bs] = o2 + p.cnt[2 * bs + b];
-        }
-    } else {
-        oL = p.offL[b], o1 = p.off1[b], o2 = p.off2[b];
-    }
-    const float* row = obs + (size_t)b * obs_stride;
-    const float dm = (lane < n) ? row[lane * node_cols + node_cols - 1] : 0.f;
-    if ((u2 >> lane) & 1ull) p.nid2[o2 + rank_below(u2, lane)] = b * n + lane;
-    if ((u1 >> lane) & 1ull) {
-        const int r1 = o1 + rank_below(u1, lane);
-        p.arow1[r1] = o2 + rank_below(u2, lane);
-        p.dm1[r1] = dm;
-    }
-    const uint64_t mine = (lane < n) ? (p.adj[(size_t)b * n + lane] | (self_loops ? (1ull << lane) : 0ull)) : 0ull;
-    const bool is_agent = (live >> lane) & 1ull;
-    const int rL = oL + rank_below(live, lane);
-    if ((u1 >> lane) & 1ull) {
-        TargetDesc d;
-        d.sources = mine, d.smask = u2, d.soff = o2, d.env = b, d.node = lane, d.cat_row = is_agent ? rL : -1;
-        p.desc1[o1 + rank_below(u1, lane)] = d;
-    }
-    if (is_agent) {
-        p.row_env[rL] = b;
-        p.row_agent[rL] = lane;
-        p.arow_g[rL] = o1 + rank_below(u1, lane);
-        p.dm_g[rL] = dm;
-        TargetDesc d;
-        d.sources = mine, d.smask = u1, d.soff = o1, d.env = b, d.node = lane, d.cat_row = rL;
-        p.desc2[rL] = d;
-    }
-    if (row_offsets_out && lane == 0) {
-        row_offsets_out[b] = oL;
-        if (b == bs - 1) row_offsets_out[bs] = oL + p.cnt[b];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// GATv2 edge softmax + aggregation.  One wavefront per target node; the 64 lanes
-// span the heads*C output channels (VPL contiguous channels per lane, so a head is C/VPL adjacent
-// lanes and the per-head score reduction is a few xor-shuffles).  Sources are streamed once with an
-// online softmax: out = sum_j exp(e_j - m) x_l[j] / (sum_j exp(e_j - m) + 1e-16).
-// ------------------------------------------------------------------------------------------------
-enum { ATT_ROWS = 0, ATT_POOL = 1, ATT_SINGLE = 2 };
-
-struct AttArgs {
-    const float* xl;        // source rows
-    int ld_l;
-    const float* xr;        // target rows
-    int ld_r;
-    const float* att;       // [heads*C]
-    const float* bias;      // [heads*C]
-    const uint64_t* adj;    // [bs*N]
-    const uint64_t* live;   // [bs] controlling agents (ATT_ROWS: whose x_1 / x_2 go to the head input)
-    const uint64_t* tmask;  // [bs] targets, or null = all nodes
-    const uint64_t* smask;  // [bs] set the source rows are packed by, or null = all nodes
-    const int32_t* toff;    // [bs] first target row, or null = b*N
-    const int32_t* soff;    // [bs] first source row, or null = b*N
-    const int32_t* loff;    // [bs+1] first agent row of the env (ATT_ROWS) / row count at [bs] (ATT_SINGLE)
-    int bs, n, lanes_per_head;
-    int kind;               // MEL_CONV_*
-    float score_scale;      // TransformerConv: 1 / sqrt(C)
-    // ATT_ROWS
-    float* out;             // [rows, ldo] relu(out + bias)
-    int ldo;
-    float* xcat;            // [R, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
-    int ld_cat, hidden;
-    const float* h0;        // encoder rows (packed by smask), [*, hidden]
-    // ATT_POOL
-    const float* obs;       // dm flag source
-    int obs_stride, node_cols, aggregator;
-    float* pooled;          // [bs, heads*C]
-    // ATT_ROWS / ATT_SINGLE: one wavefront per target row
-    const TargetDesc* desc;     // [rows] per-target descriptor
-    const int32_t* rows_dev;    // device-side row count
-    long rows_hint;             // expected rows (grid sizing only)
-    int rows_cap, cat_off;
-    int bf16;                   // bf16 feature path: xl / xr / out / xcat / h0 hold bf16 rows (att / bias stay fp32)
-};
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int VPL>
-struct Vec {
-    float v[VPL];
-};
-
-template <int VPL>
-__device__ __forceinline__ Vec<VPL> load_vec(const float* p) {
-    Vec<VPL> r;
-    if constexpr (VPL >= 4) {
-#pragma unroll
-        for (int i = 0; i < VPL / 4; ++i) {
-            const float4 t = reinterpret_cast<const float4*>(p)[i];
-            r.v[4 * i] = t.x, r.v[4 * i + 1] = t.y, r.v[4 * i + 2] = t.z, r.v[4 * i + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) r.v[i] = p[i];
-    }
-    return r;
-}
-
-template <int VPL>
-__device__ __forceinline__ void store_vec(float* p, const Vec<VPL>& r) {
-    if constexpr (VPL >= 4) {
-#pragma unroll
-        for (int i = 0; i < VPL / 4; ++i)
-            reinterpret_cast<float4*>(p)[i] = make_float4(r.v[4 * i], r.v[4 * i + 1], r.v[4 * i + 2], r.v[4 * i + 3]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) p[i] = r.v[i];
-    }
-}
-
-// feature rows: fp32, or bf16 on the bf16 feature path (math stays fp32 either way).  idx in elements.
-template <int VPL, bool BF>
-__device__ __forceinline__ Vec<VPL> load_row(const float* base, size_t idx) {
-    if constexpr (!BF) {
-        return load_vec<VPL>(base + idx);
-    } else {
-        const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + idx;
-        Vec<VPL> r;
-        if constexpr (VPL >= 8) {
-#pragma unroll
-            for (int c = 0; c < VPL / 8; ++c) {
-                const u32x4 w = reinterpret_cast<const u32x4*>(p)[c];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) r.v[8 * c + 2 * i] = bf16_lo(w[i]), r.v[8 * c + 2 * i + 1] = bf16_hi(w[i]);
-            }
-        } else if constexpr (VPL == 4) {
-            const u32x2 w = *reinterpret_cast<const u32x2*>(p);
-            r.v[0] = bf16_lo(w[0]), r.v[1] = bf16_hi(w[0]), r.v[2] = bf16_lo(w[1]), r.v[3] = bf16_hi(w[1]);
-        } else {
-            static_assert(VPL == 2, "VPL");
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
-            r.v[0] = bf16_lo(w), r.v[1] = bf16_hi(w);
-        }
-        return r;
-    }
-}
-
-template <int VPL, bool BF>
-__device__ __forceinline__ void store_row(float* base, size_t idx, const Vec<VPL>& r) {
-    if constexpr (!BF) {
-        store_vec<VPL>(base + idx, r);
-    } else {
-        uint16_t* p = reinterpret_cast<uint16_t*>(base) + idx;
-        if constexpr (VPL >= 8) {
-#pragma unroll
-            for (int c = 0; c < VPL / 8; ++c) {
-                const u32x4 w = {pack_bf16x2(r.v[8 * c], r.v[8 * c + 1]), pack_bf16x2(r.v[8 * c + 2], r.v[8 * c + 3]),
-                                 pack_bf16x2(r.v[8 * c + 4], r.v[8 * c + 5]), pack_bf16x2(r.v[8 * c + 6], r.v[8 * c + 7])};
-                reinterpret_cast<u32x4*>(p)[c] = w;
-            }
-        } else if constexpr (VPL == 4) {
-            const u32x2 w = {pack_bf16x2(r.v[0], r.v[1]), pack_bf16x2(r.v[2], r.v[3])};
-            *reinterpret_cast<u32x2*>(p) = w;
-        } else {
-            *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(r.v[0], r.v[1]);
-        }
-    }
-}
-
-// sum over the lanes of one head (lanes_per_head adjacent lanes).  The common case (16 lanes: C = 128,
-// 8 channels per lane) is four DPP moves inside a 16-lane row; anything else falls back to shuffles.
-__device__ __forceinline__ float head_sum(float s, int lanes_per_head) {
-    if (lanes_per_head == 16) {
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));  // row_half_mirror
-        s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, true));  // row_mirror
-        return s;
-    }
-    for (int o = lanes_per_head >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    return s;
-}
-
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
-
-// attention output of one target for this lane's VPL channels: relu(out + bias).  The source rows are
-// streamed once with an online softmax, FOUR sources per step: their row loads, score dot products and
-// per-head reductions are independent chains (the single-source form is one long dependent chain per source
-// and the launch is latency bound), then one rescale per step:
-//   m' = max(m, s_0..s_3); l = l e^(m-m') + sum_k e^(s_k-m'); acc = acc e^(m-m') + sum_k e^(s_k-m') row_k
-// KIND = MEL_CONV_GATV2:       e = att . leaky_relu(x_r[i] + x_l[j]),          out = sum alpha x_l[j]
-// KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
-template <int VPL, int KIND, bool BF>
-__device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_row, uint64_t sources,
-                                                  uint64_t smask, int soff, const Vec<VPL>& att,
-                                                  const Vec<VPL>& bias, int lane) {
-    constexpr int HC = 64 * VPL;
-#ifndef MEL_ATT_G
-#define MEL_ATT_G 4      // measured 2 / 3 / 4 / 8 sources per step: 24.9 / 25.9 / 25.7 / 29.9 us (conv1, round loop)
-#endif
-    constexpr int G = MEL_ATT_G;
-    const Vec<VPL> xr = load_row<VPL, BF>(a.xr, xr_row * a.ld_r + lane * VPL);
-    float m = -INFINITY, l = 0.f;
-    Vec<VPL> acc;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    while (sources) {                            // TransformerConv adds no self-loop: a target may be isolated
-        size_t row[G];                           // element index of this lane's slice of the source row
-        bool on[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            on[k] = sources != 0;
-            const int j = on[k] ? lowest_bit(sources) : 0;
-            sources &= sources - 1;              // 0 stays 0
-            row[k] = (size_t)(soff + (on[k] ? rank_below(smask, j) : 0)) * a.ld_l + lane * VPL;    // off slots re-read a valid row
-        }
-        Vec<VPL> xl[G], xv[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            xl[k] = load_row<VPL, BF>(a.xl, row[k]);
-            if constexpr (KIND == MEL_CONV_TRANSFORMER) xv[k] = load_row<VPL, BF>(a.xl, row[k] + HC);
-        }
-        float sc_[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            float t = 0.f;
-            if constexpr (KIND == MEL_CONV_GATV2 && VPL % 2 == 0) {
-                // leaky_relu(negative_slope=0.2) as max(z, 0.2 z): same value for every finite z and one op
-                // fewer than compare + select; channel pairs so that add / scale / fma issue as v_pk_*_f32
-                f32x2 t2 = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < VPL; i += 2) {
-                    const f32x2 z = f32x2{xr.v[i], xr.v[i + 1]} + f32x2{xl[k].v[i], xl[k].v[i + 1]};
-                    const f32x2 zs = z * 0.2f;
-                    const f32x2 zm = {fmaxf(z.x, zs.x), fmaxf(z.y, zs.y)};
-                    t2 = __builtin_elementwise_fma(f32x2{att.v[i], att.v[i + 1]}, zm, t2);
-                }
-                t = t2.x + t2.y;
-            } else if constexpr (KIND == MEL_CONV_GATV2) {
-#pragma unroll
-                for (int i = 0; i < VPL; ++i) {
-                    const float z = xr.v[i] + xl[k].v[i];
-                    t = fmaf(att.v[i], fmaxf(z, 0.2f * z), t);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < VPL; ++i) t = fmaf(xr.v[i], xl[k].v[i], t);
-            }
-            sc_[k] = t;
-        }
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            sc_[k] = head_sum(sc_[k], a.lanes_per_head);
-            if constexpr (KIND == MEL_CONV_TRANSFORMER) sc_[k] *= a.score_scale;
-            if (!on[k]) sc_[k] = -INFINITY;
-        }
-        float mn = m;
-#pragma unroll
-        for (int k = 0; k < G; ++k) mn = fmaxf(mn, sc_[k]);
-        // e^x as v_exp_f32(x log2 e): ~1e-6 relative on softmax weights that are later normalised (the libm
-        // expansion was a quarter of this kernel's VALU work, and the kernel is VALU / latency bound)
-        const float rs = fast_exp(m - mn);       // slot 0 is always on, so mn is finite
-        float pe[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) pe[k] = fast_exp(sc_[k] - mn);   // exp(-inf) = 0 for the off slots
-        float ps = 0.f;
-#pragma unroll
-        for (int k = 0; k < G; ++k) ps += pe[k];
-        l = l * rs + ps;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            float t = acc.v[i] * rs;
-#pragma unroll
-            for (int k = 0; k < G; ++k) t = fmaf(pe[k], (KIND == MEL_CONV_TRANSFORMER ? xv[k].v[i] : xl[k].v[i]), t);
-            acc.v[i] = t;
-        }
-        m = mn;
-    }
-    const float inv = __builtin_amdgcn_rcpf(l + 1e-16f);
-    Vec<VPL> out;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) out.v[i] = fmaxf(acc.v[i] * inv + bias.v[i], 0.f);
-    return out;
-}
-
-template <int VPL>
-__device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
-    Vec<VPL> r;
-    if (p) return load_vec<VPL>(p + lane * VPL);
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) r.v[i] = 0.f;
-    return r;
-}
-
-// ATT_ROWS / ATT_SINGLE: ONE WAVEFRONT PER TARGET ROW over the whole batch (envs differ a lot in how many
-// targets they have - a workgroup per env leaves the launch waiting for the few crowded envs).
-//   ATT_ROWS   conv1 of L-DGN: row r of the U1 list -> h1[r]; the agents' x_1 / x_2 go to the head input
-//   ATT_SINGLE conv2 of L-DGN: one target per agent row (only the controlling agent's row can reach its
-//              logits, l_dgn.py:135), sources = its closed neighbourhood inside U1 -> x_3
-// (256, 2): with the bare bound the register allocator aims at 6 waves per SIMD and SPILLS the source-row
-// pointers (88 B of scratch in front of every row load); two blocks per CU lets it keep ~100 VGPRs.
-template <int VPL, int MODE, int KIND, bool BF>
-__global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
-    const int lane = lane_id();
-    const int rows = min(*a.rows_dev, a.rows_cap);
-    const Vec<VPL> att = load_vec_or_zero<VPL>(a.att, lane);
-    const Vec<VPL> bias = load_vec_or_zero<VPL>(a.bias, lane);
-    // grid-stride over the target rows: the grid is sized from the expected row count, not the worst case
-    // (a surplus workgroup costs a global-load latency and a CU slot before it can exit)
-    // XCD-aware order: consecutive target rows belong to one env and share their source rows, so each XCD
-    // (block id % 8 under round-robin dispatch; the grid is a multiple of 8) walks a CONTIGUOUS range of rows
-    // and the shared rows hit in that XCD's L2 instead of being fetched by all eight (measured before the
-    // remap: 54 % L2 misses in this kernel).
-    const int per_xcd = gridDim.x >> 3;
-    const int vblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int rows_pad = ((rows + 4 * (int)gridDim.x - 1) / (4 * (int)gridDim.x)) * (4 * (int)gridDim.x);
-    const int span = rows_pad >> 3;              // rows each XCD owns (multiple of 4 * per_xcd)
-    for (int i = (vblock % per_xcd) * 4 + (threadIdx.x >> 6); i < span; i += per_xcd * 4) {
-        const int r = (blockIdx.x & 7) * span + i;
-        if (r >= rows) continue;
-        const TargetDesc d = a.desc[r];          // one 32-byte record: no chain of dependent index loads
-        const Vec<VPL> o = attend_target<VPL, KIND, BF>(a, (size_t)r, d.sources, d.smask, d.soff, att, bias, lane);
-        if constexpr (MODE == ATT_SINGLE) {
-            store_row<VPL, BF>(a.xcat, (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
-        } else {
-            store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, o);
-            if (d.cat_row >= 0) {
-                const size_t cat = (size_t)d.cat_row * a.ld_cat;
-                // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
-                store_row<VPL, BF>(a.xcat, cat + a.hidden + lane * VPL, o);
-                // x_1: its encoder row (l_dgn.py:122)
-                const size_t h0 = (size_t)(d.soff + rank_below(d.smask, d.node)) * a.hidden;
-                if constexpr (BF) {
-                    uint16_t* dst = reinterpret_cast<uint16_t*>(a.xcat) + cat;
-                    const uint16_t* src = reinterpret_cast<const uint16_t*>(a.h0) + h0;
-                    for (int c = lane; c < a.hidden; c += 64) dst[c] = src[c];
-                } else {
-                    for (int c = lane; c < a.hidden; c += 64) a.xcat[cat + c] = a.h0[h0 + c];
-                }
-            }
-        }
-    }
-}
-
-// ATT_POOL (HL-DGN): one workgroup per env (every env has exactly N targets, so this is balanced):
-// conv1 attention for all nodes, decision-maker mask, max / mean / add pool over the graph.
-template <int VPL, bool BF>
-__global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
-    constexpr int HC = 64 * VPL;
-    __shared__ float part[4][HC];
-    const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    const Vec<VPL> att = load_vec<VPL>(a.att + lane * VPL);
-    const Vec<VPL> bias = load_vec<VPL>(a.bias + lane * VPL);
-    const uint64_t full = (a.n == 64) ? ~0ull : ((1ull << a.n) - 1ull);
-    Vec<VPL> pool;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
-    for (int t = wave; t < a.n; t += 4) {
-        const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
-        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF>(a, (size_t)(b * a.n + t), sources, full, b * a.n,
-                                                                  att, bias, lane);
-        // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
-        const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const float v = o.v[i] * dm;
-            pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? fmaxf(pool.v[i], v) : pool.v[i] + v;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) part[wave][lane * VPL + i] = pool.v[i];
-    __syncthreads();
-    for (int c = threadIdx.x; c < HC; c += 256) {
-        float v;
-        if (a.aggregator == MEL_AGG_MAX) {
-            v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
-        } else {
-            v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
-            if (a.aggregator == MEL_AGG_MEAN) v /= (float)a.n;
-        }
-        if constexpr (BF) reinterpret_cast<uint16_t*>(a.pooled)[(size_t)b * HC + c] = (uint16_t)pack_bf16x2(v, 0.f);
-        else a.pooled[(size_t)b * HC + c] = v;
-    }
-}
-
-template <int MODE>
-static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const char* what) {
-    if constexpr (MODE == ATT_POOL) {
-        switch (hc / 64) {
-#define MEL_POOL_LAUNCH(V)                                                                              \
-    if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true>), dim3(a.bs), dim3(256), 0, s, a);  \
-    else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false>), dim3(a.bs), dim3(256), 0, s, a);
-            case 2: MEL_POOL_LAUNCH(2) break;
-            case 4: MEL_POOL_LAUNCH(4) break;
-            case 8: MEL_POOL_LAUNCH(8) break;
-            case 16: MEL_POOL_LAUNCH(16) break;
-#undef MEL_POOL_LAUNCH
-            default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
-        }
-    } else {
-        long want = ((a.rows_hint > 0 ? a.rows_hint : a.rows_cap) * 5 / 4 + 3) / 4;     // 25 % head-room, loop covers the rest
-        if (want > (a.rows_cap + 3) / 4) want = (a.rows_cap + 3) / 4;
-        if (want < 256) want = 256;
-        const int grid = (int)((want + 7) & ~7L);       // multiple of 8: block id % 8 = XCD
-#define MEL_ATT_LAUNCH(V)                                                                                             \
-    if (a.kind == MEL_CONV_TRANSFORMER && a.bf16)                                                                     \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, true>), dim3(grid), dim3(256), 0, s, a);  \
-    else if (a.kind == MEL_CONV_TRANSFORMER)                                                                          \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, false>), dim3(grid), dim3(256), 0, s, a); \
-    else if (a.bf16)                                                                                                  \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, true>), dim3(grid), dim3(256), 0, s, a);        \
-    else                                                                                                              \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, false>), dim3(grid), dim3(256), 0, s, a);
-        switch (hc / 64) {
-            case 2: MEL_ATT_LAUNCH(2) break;
-            case 4: MEL_ATT_LAUNCH(4) break;
-            case 8: MEL_ATT_LAUNCH(8) break;
-            case 16: MEL_ATT_LAUNCH(16) break;
-            default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
-        }
-#undef MEL_ATT_LAUNCH
-    }
-    return check_launch(what);
-}
-
-// counter-based uniform stream for the on-device exploration noise
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {     // lowbias32 integer hash
-    x ^= x >> 16;
-    x *= 0x7feb352dU;
-    x ^= x >> 15;
-    x *= 0x846ca68bU;
-    x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
-
-
-// ------------------------------------------------------------------------------------------------
-// dueling tail: last Linear of Q and V + q - mean(q) + v  (l_dgn.py:142-147); one wave per row
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dueling_tail_kernel(const float* __restrict__ hq, int ldq, int kq,
-                                                           const float* __restrict__ hv, int ldv, int kv,
-                                                           mel_linear q_last, mel_linear v_last, int bs,
-                                                           const int32_t* __restrict__ rows_dev, int dueling,
-                                                           float* __restrict__ logits, mel_select sel) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= bs || (rows_dev && b >= *rows_dev)) return;
-    const int lane = lane_id();
-    const int na = q_last.out_dim;
-    float q[8];
-    float qsum = 0.f;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        q[a] = 0.f;
-        if (a < na) {
-            float s = 0.f;
-            for (int k = lane; k < kq; k += 64) s = fmaf(hq[(size_t)b * ldq + k], q_last.weight[(size_t)a * kq + k], s);
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            q[a] = s + q_last.bias[a];
-            qsum += q[a];
-        }
-    }
-    float v = 0.f, mean = 0.f;
-    if (dueling) {
-        for (int k = lane; k < kv; k += 64) v = fmaf(hv[(size_t)b * ldv + k], v_last.weight[k], v);
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        v += v_last.bias[0];
-        mean = qsum / (float)na;
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-        if (a < na && lane == a) logits[(size_t)b * na + a] = q[a] - mean + v;
-    if (sel.act && lane == 0) {                 // fused DQN action selection
-        int best = 0;
-        float bv = -INFINITY;
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-            if (a < na && q[a] - mean + v > bv) bv = q[a] - mean + v, best = a;
-        if (sel.eps > 0.f) {
-            const uint32_t step = sel.step_dev ? *sel.step_dev : 0u;
-            const uint32_t base = mix32(sel.seed ^ mix32(step * 0x9e3779b9U + (uint32_t)b));
-            if (u01(base) < sel.eps) {
-                best = 0, bv = -1.f;
-                for (int a = 0; a < na; ++a) {
-                    const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
-                    if (u > bv) bv = u, best = a;
-                }
-            }
-        }
-        sel.act[b] = best;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// [3P] DQNPolicy.forward / exploration_noise
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ x, long count, float* out) {
-    __shared__ float smin[16], smax[16];
-    float lo = INFINITY, hi = -INFINITY;
-    for (long i = threadIdx.x; i < count; i += 1024) {
-        lo = fminf(lo, x[i]);
-        hi = fmaxf(hi, x[i]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = lo, smax[threadIdx.x >> 6] = hi;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) lo = fminf(lo, smin[w]), hi = fmaxf(hi, smax[w]);
-        out[0] = lo;
-        out[1] = hi;
-    }
-}
-
-__global__ __launch_bounds__(256) void select_action_kernel(const float* __restrict__ logits,
-                                                            const uint8_t* __restrict__ mask, long bs, int na,
-                                                            float eps, const float* __restrict__ rand_u,
-                                                            const float* __restrict__ rand_q,
-                                                            const float* __restrict__ minmax,
-                                                            int32_t* __restrict__ act) {
-    const long b = (long)blockIdx.x * 256 + threadIdx.x;
-    if (b >= bs) return;
-    const float shift = mask ? (minmax[0] - minmax[1] - 1.0f) : 0.f;
-    int best = 0;
-    float bv = -INFINITY;
-    for (int a = 0; a < na; ++a) {
-        float q = logits[b * na + a];
-        if (mask) q = q + (1.0f - (float)mask[b * na + a]) * shift;
-        if (q > bv) bv = q, best = a;          // first maximum, as argmax
-    }
-    if (rand_u && rand_q && rand_u[b] < eps) {
-        best = 0, bv = -INFINITY;
-        for (int a = 0; a < na; ++a) {
-            float q = rand_q[b * na + a];
-            if (mask) q += (float)mask[b * na + a];
-            if (q > bv) bv = q, best = a;
-        }
-    }
-    act[b] = best;
-}
-
-// ------------------------------------------------------------------------------------------------
-// row-wise action selection with a counter-based RNG (round-batched loop: row count lives on the device)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ logits,
-                                                          const int32_t* __restrict__ logit_row, long rows_cap,
-                                                          const int32_t* __restrict__ rows_dev, int na, float eps,
-                                                          uint32_t seed, uint32_t step,
-                                                          const uint32_t* __restrict__ step_dev,
-                                                          int32_t* __restrict__ act) {
-    const long r = (long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows_cap || (rows_dev && r >= *rows_dev)) return;
-    if (step_dev) step += *step_dev;            // device-side counter: advances under hipGraph replay
-    const float* q = logits + (size_t)(logit_row ? logit_row[r] : r) * na;
-    int best = 0;
-    float bv = -INFINITY;
-    for (int a = 0; a < na; ++a)
-        if (q[a] > bv) bv = q[a], best = a;
-    if (eps > 0.f) {                                   // exploration_noise, on-device stream
-        const uint32_t base = mix32(seed ^ mix32(step * 0x9e3779b9U + (uint32_t)r));
-        if (u01(base) < eps) {
-            best = 0, bv = -1.f;
-            for (int a = 0; a < na; ++a) {
-                const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
-                if (u > bv) bv = u, best = a;
-            }
-        }
-    }
-    act[r] = best;
-}
-
-__global__ __launch_bounds__(256) void select_envs_kernel(const float* __restrict__ logits,
-                                                          const uint64_t* __restrict__ live, long bs, int n, int na,
-                                                          float eps, uint32_t seed, const uint32_t* __restrict__ step_dev,
-                                                          int32_t* __restrict__ act) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= bs * n) return;
-    const long b = t / n;
-    const int i = (int)(t - b * n);
-    if (!((live[b] >> i) & 1ull)) return;
-    const float* q = logits + b * na;
-    int best = 0;
-    float bv = -INFINITY;
-    for (int a = 0; a < na; ++a)
-        if (q[a] > bv) bv = q[a], best = a;
-    if (eps > 0.f) {
-        const uint32_t step = step_dev ? *step_dev : 0u;
-        const uint32_t base = mix32(seed ^ mix32(step * 0x9e3779b9U + (uint32_t)(b * 64 + i)));
-        if (u01(base) < eps) {
-            best = 0, bv = -1.f;
-            for (int a = 0; a < na; ++a) {
-                const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
-                if (u > bv) bv = u, best = a;
-            }
-        }
-    }
-    act[t] = best;
-}
+namespace mel {
 
 // ------------------------------------------------------------------------------------------------
 // workspace layout

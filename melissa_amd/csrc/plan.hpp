@@ -1,0 +1,212 @@
+// Forward plan kernels: fp32 radius adjacency, agent / receptive-field sets, packed row lists and per-target
+// descriptors (networks/common.py:6-64; the row lists serve l_dgn.py:117-135).  Included by fwd.hip.
+#pragma once
+#include "common.hpp"
+
+namespace mel {
+
+// ------------------------------------------------------------------------------------------------
+// plan: one wavefront per env (= observation row), lane = node
+//
+// The forward is evaluated for a SET of controlling agents per env (mask L).  The reference's collector
+// presents one agent per observation row (L = {obs[:, -1]}, common.py:63); within one env round every
+// active agent sees the same obs_matrix (graph.py:186-188: rows differ only in the last column), so the
+// round-batched loop passes all of a round's agents at once and the encoder / conv1 work is shared:
+//   U1 = union over g in L of closed one-hop(g)   - conv1 targets that can reach some agent's logits
+//   U2 = union over t in U1 of closed one-hop(t)  - their sources
+// Rows are packed per env in id order, so the packed position of node j is popcount(mask below j).
+// ------------------------------------------------------------------------------------------------
+// everything the attention kernel needs to know about one target row, in one 32-byte load
+struct TargetDesc {
+    uint64_t sources;   // source nodes of the target (closed neighbourhood for GATv2, open for TransformerConv)
+    uint64_t smask;     // node set the source rows are packed by
+    int32_t soff;       // first source row of the env
+    int32_t env;
+    int32_t node;
+    int32_t cat_row;    // conv1: agent row whose head input takes x_1 / x_2 from this target, or -1
+};
+
+struct PlanBuffers {
+    uint64_t* adj;      // [bs*N] sources of target i (radius rule, self excluded)
+    uint64_t* live;     // [bs]   L: controlling agents of the env
+    uint64_t* u1;       // [bs]
+    uint64_t* u2;       // [bs]
+    int32_t* cnt;       // [3*bs] |L|, |U1|, |U2|
+    int32_t* offL;      // [bs+1] exclusive scans (last entry = total)
+    int32_t* off1;      // [bs+1]
+    int32_t* off2;      // [bs+1]
+    int32_t* nid2;      // [sum|U2|] global node id (b*N + i) of packed row
+    int32_t* arow1;     // [sum|U1|] row of the U2 list holding the same node
+    float* dm1;         // [sum|U1|] decision-maker flag of the node (l_dgn.py:128)
+    TargetDesc* desc1;  // [sum|U1|] conv1 target rows
+    TargetDesc* desc2;  // [R]       conv2 target rows (one per agent row)
+    int32_t* row_env;   // [R] env of agent row r
+    int32_t* row_agent; // [R] agent (node id) of agent row r
+    int32_t* arow_g;    // [R] row of the U1 list holding the agent
+    float* dm_g;        // [R]
+};
+
+// [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
+// positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
+// the first 33 hits in index order (self included) survive, then self is dropped.
+__device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
+    const float r2 = (float)(0.2 * 0.2);
+    uint64_t m = 0;
+    for (int j = 0; j < n; ++j) {
+        const float xj = lane_f32(x, j), yj = lane_f32(y, j);     // j is the loop counter: v_readlane
+        const float dx = x - xj, dy = y - yj;
+        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        if (d2 < r2) m |= 1ull << j;
+    }
+    while (__popcll(m) > 33) m &= ~(1ull << (63 - __clzll((long long)m)));
+    return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
+}
+
+// standalone adjacency for the learn path (one wave per observation row)
+__global__ __launch_bounds__(256) void radius_graph_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
+                                                           int node_cols, uint64_t* __restrict__ adj) {
+    const int lane = lane_id();
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    float x = 0.f, y = 0.f;
+    if (lane < n) {
+        const float* p = obs + (size_t)b * obs_stride + lane * node_cols;
+        x = p[0], y = p[1];
+    }
+    const uint64_t m = radius_sources(x, y, lane, n);
+    if (lane < n) adj[(size_t)b * n + lane] = m;
+}
+
+// agent_mask == null: one agent per row, taken from the index column (common.py:63)
+__global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict__ obs, int bs, int n,
+                                                         int obs_stride, int node_cols,
+                                                         const uint64_t* __restrict__ agent_mask, PlanBuffers p,
+                                                         int want_receptive) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    const int lane = lane_id();
+    const float* row = obs + (size_t)b * obs_stride;
+    float x = 0.f, y = 0.f;
+    if (lane < n) {
+        x = row[lane * node_cols];
+        y = row[lane * node_cols + 1];
+    }
+    const uint64_t src = radius_sources(x, y, lane, n);
+    if (lane < n) p.adj[(size_t)b * n + lane] = src;
+    const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+    uint64_t live;
+    if (want_receptive < 0) {              // adjacency only: the row has no index column
+        return;
+    } else if (agent_mask) {
+        live = agent_mask[b] & full;
+    } else {                               // obs[:, -1].clamp(0, N-1).long()
+        float gf = row[n * node_cols];
+        gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
+        live = 1ull << (int)gf;
+    }
+    if (!want_receptive) {
+        if (lane == 0) p.live[b] = live;
+        return;
+    }
+    const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
+    const uint64_t u1 = wave_or_u64(((live >> lane) & 1ull) ? closed : 0ull);
+    const uint64_t u2 = wave_or_u64(((u1 >> lane) & 1ull) ? closed : 0ull);
+    if (lane == 0) {
+        p.live[b] = live;
+        p.u1[b] = u1;
+        p.u2[b] = u2;
+        p.cnt[b] = __popcll(live);
+        p.cnt[bs + b] = __popcll(u1);
+        p.cnt[2 * bs + b] = __popcll(u2);
+    }
+}
+
+// exclusive scans of |L|, |U1|, |U2| over the batch (single workgroup, any bs)
+__global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) {
+    __shared__ int32_t part[3][1024];
+    const int tid = threadIdx.x;
+    const int per = (bs + 1023) / 1024;
+    const int lo = min(tid * per, bs), hi = min(lo + per, bs);
+    int32_t s[3] = {0, 0, 0};
+    for (int b = lo; b < hi; ++b)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s[k] += p.cnt[k * bs + b];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[k][tid] = s[k];
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int32_t a[3] = {0, 0, 0};
+        if (tid >= d)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[k] = part[k][tid - d];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) part[k][tid] += a[k];
+        __syncthreads();
+    }
+    int32_t o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = part[k][tid] - s[k];
+    for (int b = lo; b < hi; ++b) {
+        p.offL[b] = o[0], p.off1[b] = o[1], p.off2[b] = o[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] += p.cnt[k * bs + b];
+    }
+    if (tid == 1023) p.offL[bs] = part[0][1023], p.off1[bs] = part[1][1023], p.off2[bs] = part[2][1023];
+}
+
+__global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
+                                                         int obs_stride, int node_cols, PlanBuffers p,
+                                                         int32_t* __restrict__ row_offsets_out, int self_loops,
+                                                         int inline_scan) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    const int lane = lane_id();
+    const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
+    int oL, o1, o2;
+    if (inline_scan) {
+        // exclusive prefix of the three per-env counts, recomputed by every wave from the cnt array (a few KB out
+        // of L2): cheaper than a separate single-workgroup scan launch between the two plan kernels
+        int sL = 0, s1 = 0, s2 = 0;
+        for (int i = lane; i < b; i += 64) sL += p.cnt[i], s1 += p.cnt[bs + i], s2 += p.cnt[2 * bs + i];
+        oL = wave_sum_i32_dpp(sL), o1 = wave_sum_i32_dpp(s1), o2 = wave_sum_i32_dpp(s2);
+        if (lane == 0) {
+            p.offL[b] = oL, p.off1[b] = o1, p.off2[b] = o2;
+            if (b == bs - 1)
+                p.offL[bs] = oL + p.cnt[b], p.off1[bs] = o1 + p.cnt[bs + b], p.off2[bs] = o2 + p.cnt[2 * bs + b];
+        }
+    } else {
+        oL = p.offL[b], o1 = p.off1[b], o2 = p.off2[b];
+    }
+    const float* row = obs + (size_t)b * obs_stride;
+    const float dm = (lane < n) ? row[lane * node_cols + node_cols - 1] : 0.f;
+    if ((u2 >> lane) & 1ull) p.nid2[o2 + rank_below(u2, lane)] = b * n + lane;
+    if ((u1 >> lane) & 1ull) {
+        const int r1 = o1 + rank_below(u1, lane);
+        p.arow1[r1] = o2 + rank_below(u2, lane);
+        p.dm1[r1] = dm;
+    }
+    const uint64_t mine = (lane < n) ? (p.adj[(size_t)b * n + lane] | (self_loops ? (1ull << lane) : 0ull)) : 0ull;
+    const bool is_agent = (live >> lane) & 1ull;
+    const int rL = oL + rank_below(live, lane);
+    if ((u1 >> lane) & 1ull) {
+        TargetDesc d;
+        d.sources = mine, d.smask = u2, d.soff = o2, d.env = b, d.node = lane, d.cat_row = is_agent ? rL : -1;
+        p.desc1[o1 + rank_below(u1, lane)] = d;
+    }
+    if (is_agent) {
+        p.row_env[rL] = b;
+        p.row_agent[rL] = lane;
+        p.arow_g[rL] = o1 + rank_below(u1, lane);
+        p.dm_g[rL] = dm;
+        TargetDesc d;
+        d.sources = mine, d.smask = u1, d.soff = o1, d.env = b, d.node = lane, d.cat_row = rL;
+        p.desc2[rL] = d;
+    }
+    if (row_offsets_out && lane == 0) {
+        row_offsets_out[b] = oL;
+        if (b == bs - 1) row_offsets_out[bs] = oL + p.cnt[b];
+    }
+}
+
+}  // namespace mel
