@@ -91,14 +91,17 @@ class HipGraphVectorEnv:
 
     def __init__(self, env_num: int, number_of_agents: int, graph_pool=None, graph: Graph | None = None,
                  dynamic_graph: bool = False, local_ratio=None, device="cuda", max_moves: int = 64,
-                 seed=None, fixed_interest_density=None, construct_like_reference: bool = True,
+                 seed=None, fixed_interest_density=None, construct_like_reference: "bool | int" = True,
                  is_testing: bool = False, num_test_episodes: int = 10, scripted_agents_ratio: float = 0.0,
                  heuristic: str | None = None):
         """``graph`` fixes one graph for every episode (GraphEnv(graph=...)); ``graph_pool`` is a list of
         ``Graph`` standing for the ``graph_topologies/training_N/*`` files.  ``seed`` seeds env k's
         generator with ``seed + k`` (tianshou ``BaseVectorEnv.seed``).  ``construct_like_reference``
-        replays the two episode samplings the reference performs while constructing a GraphEnv
-        (core.py:190, graph.py:118) so RNG streams line up with a reference run.  ``is_testing``: the
+        replays the episode samplings the reference performs while CONSTRUCTING an env, so that RNG streams
+        line up with a reference run: ``True`` (= 3) for ``PettingZooEnv(GraphEnv(...))`` as ``get_env`` builds it
+        (common.py:100-129: World.__init__ -> reset core.py:190, GraphEnv.__init__ -> reset graph.py:118, [3P]
+        tianshou PettingZooEnv.__init__ -> env.reset()), ``2`` for a bare ``GraphEnv`` (what the golden traces
+        drive), ``False`` for none.  ``is_testing``: the
         reference's evaluation schedule (GraphEnv(is_testing=True, num_test_episodes=...), core.py:182-187,348-370);
         ``graph_pool`` then stands for the sorted ``graph_topologies/testing_N/*`` files."""
         if is_testing and graph is not None:
@@ -143,9 +146,8 @@ class HipGraphVectorEnv:
         self.out = ObsBuffers(self.env_num, self.n, self.device)
         self._graph_loaded = np.zeros(self.env_num, dtype=bool)
         self._ids_all = torch.arange(self.env_num, dtype=torch.int32, device=self.device)
-        if construct_like_reference:
-            self._reset_rows(np.arange(self.env_num), observe=False)      # World.__init__ -> reset (core.py:190)
-            self._reset_rows(np.arange(self.env_num), observe=False)      # GraphEnv.__init__ -> reset (graph.py:118)
+        for _ in range(3 if construct_like_reference is True else int(construct_like_reference)):
+            self._reset_rows(np.arange(self.env_num), observe=False)
 
     # ------------------------------------------------------------------ plumbing
     def __len__(self):

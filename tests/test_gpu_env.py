@@ -48,7 +48,8 @@ def build_venv(tr, env_num=1, slot=0):
     graphs = [Graph(tr["pool_pos"][k].copy(), tr["pool_adj"][k].copy()) for k in range(tr["pool_pos"].shape[0])]
     lr = float(tr["local_ratio"])
     kw = dict(env_num=env_num, number_of_agents=n, dynamic_graph=bool(tr["dynamic"]),
-              local_ratio=None if lr < 0 else lr, seed=int(tr["env_seed"]) - slot, max_moves=64)
+              local_ratio=None if lr < 0 else lr, seed=int(tr["env_seed"]) - slot, max_moves=64,
+              construct_like_reference=2)         # the traces drive a bare GraphEnv (no PettingZooEnv.__init__ reset)
     kw.update(scripted_kwargs(tr))
     if "is_testing" in tr.files and bool(tr["is_testing"]):          # core.py:348-370 evaluation schedule
         kw.update(is_testing=True, num_test_episodes=int(tr["num_test_episodes"]))

@@ -248,3 +248,19 @@ def test_sample_collective_siblings_and_dgn_learner_step():
     losses = [learner.step()["loss"] for _ in range(3)]
     assert all(np.isfinite(losses))
     assert any(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
+
+
+def test_construct_time_samplings_line_up_with_the_wrapped_oracle():
+    """PettingZooEnv(GraphEnv(...)) samples THREE episodes while being constructed (core.py:190, graph.py:118, [3P]
+    tianshou PettingZooEnv.__init__ -> env.reset()); HipGraphVectorEnv(construct_like_reference=True) replays that
+    many, so its first reset() yields the sampler's 4th episode - what __graft_entry__.smoke() relies on."""
+    n = 20
+    pool = synthetic_graph_pool(n, 3, 10)
+    opool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in pool]
+    mk = lambda: np.random.Generator(np.random.PCG64(np.random.SeedSequence(7)))
+    sampler = EpisodeSampler(n, mk(), 3, False)
+    episodes = [sampler.sample() for _ in range(5)]
+    wrapped = eo.OraclePettingZooEnv(eo.OracleGraphEnv(n, graph_pool=opool, dynamic_graph=True, np_random=mk()))
+    assert wrapped.env.origin_agent == episodes[2].origin and wrapped.env.interested == episodes[2].interested
+    wrapped.reset()
+    assert wrapped.env.origin_agent == episodes[3].origin and wrapped.env.interested == episodes[3].interested
