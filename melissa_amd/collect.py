@@ -27,8 +27,7 @@ def sample_episode_table(venv: HipGraphVectorEnv, episodes_per_env: int, seed: i
     generator seeded ``seed + k``) -> (packed pool dict, episode_table int32 [B, K])."""
     episodes, table = [], np.zeros((venv.env_num, episodes_per_env), dtype=np.int32)
     for b in range(venv.env_num):
-        sampler = EpisodeSampler(venv.n, np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))),
-                                 len(venv.graphs), venv.fixed_graph)
+        sampler = venv.make_sampler(seed + b)          # same evaluation schedule / scripted ratio / density as the env
         for k in range(episodes_per_env):
             table[b, k] = len(episodes)
             episodes.append(sampler.sample())

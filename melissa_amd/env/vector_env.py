@@ -125,11 +125,9 @@ class HipGraphVectorEnv:
         self.graphs = [graph] if graph is not None else list(graph_pool)
         self.action_space = [Discrete(2) for _ in range(self.env_num)]
         seeds = [None] * self.env_num if seed is None else [seed + k for k in range(self.env_num)]
-        self.samplers = [EpisodeSampler(self.n, np.random.Generator(np.random.PCG64(np.random.SeedSequence(s))),
-                                        len(self.graphs), self.fixed_graph, fixed_interest_density,
-                                        is_testing=is_testing, num_test_episodes=num_test_episodes,
-                                        scripted_agents_ratio=scripted_agents_ratio)
-                         for s in seeds]
+        self._sampler_kw = dict(fixed_interest_density=fixed_interest_density, is_testing=is_testing,
+                                num_test_episodes=num_test_episodes, scripted_agents_ratio=scripted_agents_ratio)
+        self.samplers = [self.make_sampler(s) for s in seeds]
         # device state
         nbytes = int(self.lib.mel_env_state_bytes(self.env_num, self.n))
         self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
@@ -148,6 +146,12 @@ class HipGraphVectorEnv:
         self._ids_all = torch.arange(self.env_num, dtype=torch.int32, device=self.device)
         for _ in range(3 if construct_like_reference is True else int(construct_like_reference)):
             self._reset_rows(np.arange(self.env_num), observe=False)
+
+    def make_sampler(self, seed) -> EpisodeSampler:
+        """An episode sampler with this env's settings (graph pool size, evaluation schedule, scripted ratio, ...)
+        and its own generator seeded ``seed`` - what the device-resident loops pre-draw their episode pools with."""
+        return EpisodeSampler(self.n, np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))),
+                              len(self.graphs), self.fixed_graph, **self._sampler_kw)
 
     # ------------------------------------------------------------------ plumbing
     def __len__(self):

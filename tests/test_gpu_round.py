@@ -243,9 +243,13 @@ def test_replay_sampling_and_dqn_learner():
     assert any(k.startswith("model_old.") for k in policy.state_dict())
 
 
-def test_hldgn_round_loop_matches_oracle():
+@pytest.mark.parametrize("scripted", [None, (0.3, "simple_broadcast"), (0.4, "broadcast_if_any_interested")],
+                         ids=["all-policy", "scripted-broadcast", "scripted-interested"])
+def test_hldgn_round_loop_matches_oracle(scripted):
     """HL-DGN in the round loop: one logits row per env (hl_dgn.py:108 ignores the controlling index), dense
-    per-agent actions; env state after every round equals the oracle replaying the same actions."""
+    per-agent actions; env state after every round equals the oracle replaying the same actions.  With scripted
+    agents the round's active set excludes them, their rows are zeroed by the dm mask before pooling (hl_dgn.py:105)
+    and they relay by their heuristic inside the world step."""
     from melissa_amd import _lib as L
     from melissa_amd.collect import RoundLoop, sample_episode_table
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
@@ -255,8 +259,9 @@ def test_hldgn_round_loop_matches_oracle():
     from oracle import net_oracle as no
     n, B, seed, K = 20, 5, 41, 30
     graphs = synthetic_graph_pool(n, 3, first_seed=50)
+    skw = dict(scripted_agents_ratio=scripted[0], heuristic=scripted[1]) if scripted else {}
     venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
-                             construct_like_reference=False)
+                             construct_like_reference=False, **skw)
     sd = no.init_weights("hl_dgn", seed=9, random_conv_bias=True)
     net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda", backend="hip")
     net.load_state_dict(sd)
@@ -267,14 +272,20 @@ def test_hldgn_round_loop_matches_oracle():
     for b in range(B):
         env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in graphs],
                                 dynamic_graph=True,
-                                np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))))
+                                np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))), **skw)
         pz = eo.OraclePettingZooEnv.__new__(eo.OraclePettingZooEnv)
         pz.env, pz.n, pz.rewards, pz.done_count = env, n, [0] * n, 0
         env.last()
         refs.append(pz)
+    saw_scripted = False
     for it in range(K):
         live = loop.live.cpu().numpy().view(np.uint64).copy()
         mat = venv.obs_matrix().cpu().numpy().copy()
+        if scripted:
+            sets = venv.node_sets().cpu().numpy().view(np.uint64)
+            for b, pz in enumerate(refs):
+                assert int(sets[b, L.SET_SCRIPTED]) == pz.env.scripted and int(live[b]) & pz.env.scripted == 0
+                saw_scripted |= pz.env.scripted != 0
         loop.step()
         torch.cuda.synchronize()
         logits = loop.logits.cpu().numpy()
@@ -291,6 +302,7 @@ def test_hldgn_round_loop_matches_oracle():
             assert int(s[b, L.SET_HAS_MESSAGE]) == pz.env.has_message and int(s[b, L.SET_AGENTS]) == pz.env.agents
             np.testing.assert_array_equal(venv.positions()[b].cpu().numpy(), pz.env.pos)
     assert loop.counters()["errors"] == 0
+    assert saw_scripted == bool(scripted)
 
 
 @pytest.mark.parametrize("model", ["hl_dgn", "dgn_r"])
