@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0            # same guide, HBM3E ~8 TB/s
 N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
 HC = HIDDEN * HEADS
 
@@ -260,6 +261,38 @@ def main():
                     "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]),
                                         "agent_rows": float(mean_tot[2])}}
 
+    # HBM-side rooflines of the non-contraction kernels ("the gather / edge-softmax / pool stage ...
+    # reported separately as achieved GB/s ... env step: report GB/s"): COMPULSORY bytes per launch - every row the
+    # launch needs read once, every row it produces written once - over the launch's average duration, against HBM peak.
+    # They are latency / VALU bound, the fractions say how far from a streaming kernel they are.
+    hbm_rooflines = None
+    if stages and args.mode == "round" and args.model == "l_dgn":
+        esz = 2 if args.dtype == "bf16" else 4
+        u1, u2, r = (float(x) for x in mean_tot)
+        row = HC * esz
+        att1 = (u2 + u1) * row + u1 * row + r * (HIDDEN + HC) * esz        # x_l rows + x_r rows read, h1 + x_1|x_2 written
+        att2 = (u1 + r) * row + r * row                                      # x_l2 rows + x_r2 rows read, x_3 written
+        env_b = 2.0 * args.envs * (8968 if args.nodes == 50 else float(lib.mel_env_state_bytes(args.envs, args.nodes)) / args.envs)
+        pmc_extra = {}
+        if traffic is not None or os.path.exists(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")):
+            try:
+                pmc_extra = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json"))).get("per_launch", {})
+            except (OSError, ValueError):
+                pmc_extra = {}
+        same = (args.nodes == N_NODES and args.envs == ENVS_PER_GPU and args.dtype == "f32")
+        hbm_rooflines = []
+        for name, stage, nbytes, key in (("gat_attend_rows_kernel<8, 0, ...> (conv1 attention)", "conv1_att", att1, "conv1 attention"),
+                                         ("gat_attend_rows_kernel<8, 2, ...> (conv2 attention)", "conv2_att", att2, "conv2 attention"),
+                                         ("env_round_kernel", "env_step", env_b, "env round")):
+            us = stages.get(stage, 0.0)
+            if us <= 0:
+                continue
+            gbs = nbytes / (us * 1e-6) / 1e9
+            hbm_rooflines.append({"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                                  "avg_launch_us": round(us, 2),
+                                  "traffic": pmc_extra.get(key, {}).get("hbm_bytes_corrected") if same else None})
+
     # forward-only rows/s and env-only world-rounds/s, from the same stage timers: agent rows
     # of one step / the forward stages' time, envs of one step / the env launch's time
     parts = None
@@ -296,6 +329,7 @@ def main():
         "roofline": roofline,
         "stage_us": {k: round(v, 2) for k, v in (stages or {}).items() if v > 0},
         "parts": parts,
+        "roofline_hbm": hbm_rooflines,
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.nodes)
