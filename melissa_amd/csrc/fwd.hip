@@ -6,6 +6,7 @@
 #include "gemm_f32.hpp"
 #include "gemm_bf16.hpp"
 #include "gemm_split.hpp"
+#include "gemm_ring.hpp"
 
 namespace mel {
 
@@ -62,8 +63,37 @@ static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipS
         hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
 }
 
+// specialised-wavefront kernel (gemm_ring.hpp): two 8-wave workgroups per CU
+template <int TAG>
+static void gemm_launch_ring_t(const GemmArgs* gs, int count, hipStream_t s) {
+    GemmBatch batch{};
+    batch.count = count;
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        tiles += ((long)((gs[i].M + 63) / 64) * (gs[i].N / 64) + 7) & ~7L;
+    }
+    long grid = 256L * 2;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL((gemm_f32_ring_kernel<TAG>), dim3((int)grid), dim3(512), 0, s, batch);
+}
+
 // ragged 64 x 64 launches of the round step, named per call site
 static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int tag) {
+    // Long-K problems (the heads' first layer, K = 1152: 36 K steps per tile) go to the specialised-wavefront kernel:
+    // measured 27.4 vs 30.7 us for the head launches; at K <= 512 the one-role kernel is as fast or faster
+    // (conv2 84 vs 85 us, conv1 46 vs 53 us), see DESIGN.md.
+    bool long_k = true;
+    for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024;
+    if (long_k) {
+        switch (tag) {
+            case 1: gemm_launch_ring_t<1>(gs, count, s); break;
+            case 2: gemm_launch_ring_t<2>(gs, count, s); break;
+            case 3: gemm_launch_ring_t<3>(gs, count, s); break;
+            default: gemm_launch_ring_t<0>(gs, count, s); break;
+        }
+        return;
+    }
     switch (tag) {
         case 1: gemm_launch_persistent<2, 2, 1, 1, 1>(gs, count, GEMM_MODE_PLAIN, s); break;
         case 2: gemm_launch_persistent<2, 2, 1, 1, 2>(gs, count, GEMM_MODE_PLAIN, s); break;
@@ -638,6 +668,15 @@ using namespace mel;
 extern "C" {
 
 const char* mel_last_error(void) { return g_err; }
+#ifdef MEL_RING_PROF
+// EXPERIMENT: read (and reset) the ring kernel's in-kernel cycle counters
+void mel_debug_ring_prof(unsigned long long* out8) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ring_prof), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_prof), z, sizeof(z));
+}
+#endif
 size_t mel_abi_sizeof(int32_t which) {
     switch (which) {
         case 0: return sizeof(mel_linear);

@@ -109,6 +109,49 @@ __device__ __forceinline__ f32x4 fetch_a(const GemmArgs& g, const AChunk& c, int
     }
 }
 
+// Epilogue of one 32x32 accumulator block (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) +
+// 8*(reg >> 2) + 4*(lane >> 5)):   Y[m, n] = act(rscale[m] * acc + bias[n]),  m = m_lane + (e & 3) + 8*(e >> 2).
+// Written so that the 16 row-scale loads go out together, everything is computed, and then the 16 stores go out
+// back to back.  The obvious per-element loop compiles to: reload Y / ldy / relu from the kernel-argument segment
+// (s_load + lgkmcnt wait), load rscale[m], s_waitcnt vmcnt(0) - which also waits for the PREVIOUS element's store -
+// and only then the next store: sixteen serialised memory round trips per block (measured: a third of the kernel).
+// The operands the epilogue reads from memory (bias of this lane's column, row scales of its 16 rows).  (Fetching them
+// a couple of K steps before the tile ends was measured and is NOT worth it: the live range costs the one-role kernel
+// a wavefront of occupancy - conv2 103 vs 84 us - and changes nothing where registers are free.)
+struct EpilogueOperands {
+    float bias;
+    float sc[16];
+};
+__device__ __forceinline__ EpilogueOperands fetch_epilogue_operands(const GemmArgs& g, int m_lane, int n, int M) {
+    EpilogueOperands o;
+    const float* __restrict__ rs = g.rscale;
+    o.bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n] : (g.bias ? g.bias[n] : 0.f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o.sc[e] = rs ? rs[min(m_lane + (e & 3) + 8 * (e >> 2), M - 1)] : 1.f;
+    return o;
+}
+
+__device__ __forceinline__ void store_block_f32(const GemmArgs& g, const f32x16& acc, int m_lane, int n, int M,
+                                                const EpilogueOperands& o) {
+    float* __restrict__ Y = g.Y;
+    const int ldy = g.ldy, relu = g.relu;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        v[e] = acc[e] * o.sc[e] + o.bias;
+        if (relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    float* col = Y + n;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m_lane + (e & 3) + 8 * (e >> 2);
+        if (m < M) col[(size_t)m * ldy] = v[e];
+    }
+}
+__device__ __forceinline__ void store_block_f32(const GemmArgs& g, const f32x16& acc, int m_lane, int n, int M) {
+    store_block_f32(g, acc, m_lane, n, M, fetch_epilogue_operands(g, m_lane, n, M));
+}
+
 template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32_kernel(GemmBatch batch) {
     int pi = 0;
@@ -249,27 +292,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    // epilogue
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 32 * TN + j * 32 + r;
-        const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n]
-                                                         : (g.bias ? g.bias[n] : 0.f);
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < M) {
-                    float v = acc[i][j][e];
-                    if (g.rscale) v *= g.rscale[m];
-                    v += bias;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    g.Y[(size_t)m * g.ldy + n] = v;
-                }
-            }
-        }
-    }
+        for (int i = 0; i < TM; ++i)
+            store_block_f32(g, acc[i][j], m0 + wm * 32 * TM + i * 32 + 4 * h, n0 + wn * 32 * TN + j * 32 + r, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -472,25 +500,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
         {   // epilogue of the finished tile (the next tile's first K step already sits in LDS)
             const GemmArgs& g = batch.p[cur.pi];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = cur.n0 + wn * 32 * TN + j * 32 + r;
-                const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n]
-                                                                 : (g.bias ? g.bias[n] : 0.f);
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = cur.m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (m < cur.M) {
-                            float v = acc[i][j][e];
-                            if (g.rscale) v *= g.rscale[m];
-                            v += bias;
-                            if (g.relu) v = fmaxf(v, 0.f);
-                            g.Y[(size_t)m * g.ldy + n] = v;
-                        }
-                    }
-                }
-            }
+                for (int i = 0; i < TM; ++i)
+                    store_block_f32(g, acc[i][j], cur.m0 + wm * 32 * TM + i * 32 + 4 * h, cur.n0 + wn * 32 * TN + j * 32 + r,
+                                    cur.M);
         }
         if (!has_next) break;
         cur = nxt;
@@ -627,25 +641,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_glds_kernel(GemmBatc
     }
 
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * 32 * TN + j * 32 + r;
-        const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n]
-                                                         : (g.bias ? g.bias[n] : 0.f);
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < M) {
-                    float v = acc[i][j][e];
-                    if (g.rscale) v *= g.rscale[m];
-                    v += bias;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    g.Y[(size_t)m * g.ldy + n] = v;
-                }
-            }
-        }
-    }
+        for (int i = 0; i < TM; ++i)
+            store_block_f32(g, acc[i][j], m0 + wm * 32 * TM + i * 32 + 4 * h, n0 + wn * 32 * TN + j * 32 + r, M);
 }
 
 // Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.  `m_hint` is the row

@@ -1,0 +1,236 @@
+// fp32-MFMA row GEMM with SPECIALISED wavefronts (PLAIN problems, 64 x 64 tiles, persistent):
+//
+//   waves 0-3  consumers  2 x 2 wavefronts of 32 x 32: ds_read_b128 fragments + v_mfma_f32_32x32x2_f32, epilogue
+//   waves 4-7  loaders    global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), running
+//                         THREE K steps ahead of the arithmetic through a four-stage LDS ring
+//
+// Why: in the one-role kernels (gemm_f32.hpp) the workgroups that share a CU move through load -> LDS -> MFMA phases
+// in step, so the data-movement skeleton and the MFMA chain of a launch add up instead of overlapping (DESIGN.md,
+// "GEMM status": conv2 38 us + 51.5 us ~ the measured 87).  Here the two never wait for each other inside a K step:
+// a consumer wave's step is 8 fragment reads + 16 MFMAs and nothing else, a loader wave's step is "issue the DMAs of
+// step g+3, make sure step g+1 has landed", and one s_barrier per step hands a stage over in each direction.
+//
+// LDS stage = 64 A rows + 64 W rows x 128 B, unpadded (a DMA instruction writes 1 KiB linearly); bank conflicts of the
+// fragment reads are removed by XOR-ing the 16-byte chunk index with (row >> 1) & 7 on the DMA's SOURCE side and on
+// the read side.  4 stages x 16 KiB = 64 KiB per workgroup -> two workgroups (16 wavefronts) per CU.
+#pragma once
+#include "gemm_f32.hpp"
+
+namespace mel {
+
+constexpr int RING_STAGES = 4;
+constexpr int RING_AHEAD = 3;                      // K steps the loaders run ahead (< RING_STAGES)
+constexpr int RING_STAGE_FLOATS = 128 * GEMM_BK;   // 64 + 64 rows x 32 floats
+constexpr int RING_PPW = 4;                        // 1 KiB DMA pieces per loader wave per stage (16 pieces / 4 waves)
+
+#ifdef MEL_RING_PROF
+// EXPERIMENT: cycles a consumer wave 0 spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
+// [4] workgroups counted; loaders: [5] issue, [6] wait_landed, [7] barrier
+__device__ unsigned long long g_ring_prof[8];
+#define RING_T() __builtin_readcyclecounter()
+#endif
+
+template <int TAG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) {
+    constexpr int BM = 64, BN = 64;
+    __shared__ __attribute__((aligned(16))) float lds[RING_STAGES * RING_STAGE_FLOATS];
+
+    // tile bookkeeping (wave-uniform), identical for every wave of the workgroup
+    int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
+        act[i] = 0, rows[i] = 0;
+        if (i < batch.count) {
+            const GemmArgs& q = batch.p[i];
+            rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
+            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN);
+        }
+        pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
+    }
+    const int total = pre[GEMM_MAX_GROUP];
+    const int stride = gridDim.x;
+    auto next_valid = [&](int t) {
+        for (; t < total; t += stride) {
+            int pi = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (t >= pre[k]) pi = k;
+            if (t - pre[pi] < act[pi]) return t;
+        }
+        return total;
+    };
+    struct Tile {
+        int pi, m0, n0, M, KT;
+    };
+    auto tile_of = [&](int t) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (t >= pre[k]) pi = k;
+        const GemmArgs& g = batch.p[pi];
+        const int nbn = g.N / BN;
+        int wg = t - pre[pi];
+        {   // workgroups sharing an A row panel sit on one XCD (see gemm_f32.hpp)
+            const int active = act[pi];
+            const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
+            wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+        }
+        return Tile{pi, (wg / nbn) * BM, (wg % nbn) * BN, rows[pi], g.K / GEMM_BK};
+    };
+
+    const int first = next_valid(blockIdx.x);
+    if (first >= total) return;
+    // total K steps of this workgroup's stream: every wave executes exactly that many step barriers
+    int steps_total = 0;
+    for (int t = first; t < total; t = next_valid(t + stride)) steps_total += tile_of(t).KT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ loaders
+        const int lw = wid - 4;
+        const float* src[RING_PPW];            // this lane's 16-byte chunk of each piece, K step 0 of the loader's tile
+        int lt = first, lkt = 0, lKT = 0;
+        auto load_tile = [&](int t) {
+            const Tile c = tile_of(t);
+            const GemmArgs& g = batch.p[c.pi];
+            lKT = c.KT;
+#pragma unroll
+            for (int i = 0; i < RING_PPW; ++i) {
+                const int row = (lw * RING_PPW + i) * 8 + (lane >> 3);            // tile-local: A rows then W rows
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);                  // source chunk of this LDS slot
+                if (row < BM) {
+                    const int gr = min(c.m0 + row, c.M - 1);                      // clamped, never predicated
+                    const int ar = g.arow ? g.arow[gr] : gr;
+                    src[i] = g.A + (size_t)ar * g.lda + chunk * 4;
+                } else {
+                    const int n = c.n0 + (row - BM);
+                    const float* base = (g.W_hi && n >= g.split_n) ? g.W_hi + (size_t)(n - g.split_n) * g.K
+                                                                    : g.W + (size_t)n * g.K;
+                    src[i] = base + chunk * 4;
+                }
+            }
+        };
+        load_tile(first);
+        int issued = 0;
+        auto issue = [&]() {                   // DMAs of the next step of the stream into its ring stage
+            if (issued >= steps_total) return;
+            float* stage = lds + (issued % RING_STAGES) * RING_STAGE_FLOATS;
+#ifndef MEL_EXP_NODMA
+#pragma unroll
+            for (int i = 0; i < RING_PPW; ++i)
+                dma_16B_to_lds(src[i] + lkt * GEMM_BK, stage + (lw * RING_PPW + i) * 8 * GEMM_BK);
+#endif
+            ++issued;
+            if (++lkt == lKT) {
+                lt = next_valid(lt + stride);
+                lkt = 0;
+                if (lt < total) load_tile(lt);
+            }
+        };
+        auto wait_landed = [&](int g) {        // every DMA of steps <= g has landed (in-order completion)
+            const int after = issued - (g + 1);    // steps issued later than g: 0 .. RING_AHEAD - 1
+            if (after >= 2) wait_vmcnt_le<2 * RING_PPW>();
+            else if (after == 1) wait_vmcnt_le<RING_PPW>();
+            else wait_vmcnt_le<0>();
+        };
+#pragma unroll
+        for (int i = 0; i < RING_AHEAD; ++i) issue();
+        wait_landed(0);
+        __builtin_amdgcn_s_barrier();          // B(-1): step 0 is in its stage
+#ifdef MEL_RING_PROF
+        unsigned long long li = 0, lw_ = 0, lb = 0;
+#endif
+        for (int g = 0; g < steps_total; ++g) {
+#ifdef MEL_RING_PROF
+            const unsigned long long t0 = RING_T();
+#endif
+            issue();                           // step g + 3 -> the stage step g - 1 was read from (released by B(g-1))
+#ifdef MEL_RING_PROF
+            const unsigned long long t1 = RING_T();
+#endif
+            if (g + 1 < steps_total) wait_landed(g + 1);
+#ifdef MEL_RING_PROF
+            const unsigned long long t2 = RING_T();
+#endif
+            __builtin_amdgcn_s_barrier();      // B(g)
+#ifdef MEL_RING_PROF
+            const unsigned long long t3 = RING_T();
+            li += t1 - t0, lw_ += t2 - t1, lb += t3 - t2;
+#endif
+        }
+#ifdef MEL_RING_PROF
+        if (wid == 4 && lane == 0) {
+            atomicAdd(&g_ring_prof[5], li), atomicAdd(&g_ring_prof[6], lw_), atomicAdd(&g_ring_prof[7], lb);
+        }
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int a_row_l = wm * 32 + r, w_row_l = BM + wn * 32 + r;
+    const int a_row = a_row_l * GEMM_BK, a_x = (a_row_l >> 1) & 7;
+    const int w_row = w_row_l * GEMM_BK, w_x = (w_row_l >> 1) & 7;
+
+    int t = first;
+    Tile c = tile_of(t);
+    int kt = 0;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#ifdef MEL_RING_PROF
+    unsigned long long cm_ = 0, cb = 0, ce = 0;
+    const unsigned long long tk0 = RING_T();
+#endif
+    __builtin_amdgcn_s_barrier();              // B(-1)
+    for (int g = 0; g < steps_total; ++g) {
+#ifdef MEL_RING_PROF
+        const unsigned long long t0 = RING_T();
+#endif
+        const float* cur = lds + (g % RING_STAGES) * RING_STAGE_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#ifdef MEL_EXP_NOLDS
+            const f32x4 a = {1.f + q, 2.f, 3.f, 4.f + lane}, b = {0.5f, 0.25f + q, 0.125f, 1.f};
+#else
+            const f32x4 a = *reinterpret_cast<const f32x4*>(cur + a_row + (((2 * q + h) ^ a_x) << 2));
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cur + w_row + (((2 * q + h) ^ w_x) << 2));
+#endif
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+        }
+#ifdef MEL_RING_PROF
+        asm volatile("s_nop 0" ::"v"(acc[0]));          // the MFMA chain has retired
+        const unsigned long long t1 = RING_T();
+#endif
+        if (++kt == c.KT) {                    // tile complete: epilogue (the loaders are already three steps into the next)
+            store_block_f32(batch.p[c.pi], acc, c.m0 + wm * 32 + 4 * h, c.n0 + wn * 32 + r, c.M);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            t = next_valid(t + stride);
+            kt = 0;
+            if (t < total) c = tile_of(t);
+        }
+#ifdef MEL_RING_PROF
+        const unsigned long long t2 = RING_T();
+#endif
+        __builtin_amdgcn_s_barrier();          // B(g): every fragment read of step g is done (they fed MFMAs above)
+#ifdef MEL_RING_PROF
+        const unsigned long long t3 = RING_T();
+        cm_ += t1 - t0, ce += t2 - t1, cb += t3 - t2;
+#endif
+    }
+#ifdef MEL_RING_PROF
+    if (wid == 0 && lane == 0) {
+        atomicAdd(&g_ring_prof[0], cm_), atomicAdd(&g_ring_prof[1], cb), atomicAdd(&g_ring_prof[2], ce);
+        atomicAdd(&g_ring_prof[3], RING_T() - tk0), atomicAdd(&g_ring_prof[4], 1ull);
+    }
+#endif
+}
+
+}  // namespace mel

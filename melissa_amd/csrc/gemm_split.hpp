@@ -239,23 +239,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
         stage ^= 1;
         va = issue(Ra);
         if (++ckt < cm.KT) return true;
-        {   // the tile is complete: epilogue, identical to the fp32 kernel's
-            const GemmArgs& g = batch.p[cm.pi];
-            const int n = cm.n0 + wn * 32 + r;
-            const float bias = (g.bias_hi && n >= g.split_n) ? g.bias_hi[n - g.split_n] : (g.bias ? g.bias[n] : 0.f);
+        // the tile is complete: epilogue, the fp32 kernel's
+        store_block_f32(batch.p[cm.pi], acc, cm.m0 + wm * 32 + 4 * h, cm.n0 + wn * 32 + r, cm.M);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = cm.m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < cm.M) {
-                    float v = acc[e];
-                    if (g.rscale) v *= g.rscale[m];
-                    v += bias;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    g.Y[(size_t)m * g.ldy + n] = v;
-                }
-                acc[e] = 0.f;
-            }
-        }
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         if (!nm_valid) return false;
         cm = nm, nm_valid = false, ckt = 0;
         return true;

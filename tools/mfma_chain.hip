@@ -1,0 +1,56 @@
+// Calibration 2: v_mfma_f32_32x32x2_f32 issued as ONE dependent chain per wavefront (the 32x32 wave tile of the
+// 64x64 GEMM kernels: 16 MFMAs per K step into the same accumulator), against NACC independent chains; with and without
+// an s_barrier every 16 MFMAs; 1..4 wavefronts per SIMD.   tools/bin/mfma_chain
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC, int BARRIER>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a = 1.f + threadIdx.x * 1e-3f, b = 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 16 / NACC; ++m)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        if (BARRIER) __builtin_amdgcn_s_barrier();
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC, int BARRIER>
+void run(int blocks_per_cu) {
+    const int blocks = 256 * blocks_per_cu, iters = 2000;
+    float* out;
+    hipMalloc(&out, blocks * 256 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<NACC, BARRIER>), dim3(blocks), dim3(256), 0, 0, out, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep) best = ms < best ? ms : best;
+    }
+    const double flops = (double)blocks * 4 * iters * 16 * 4096.0;
+    printf("chains/wave %d  barrier/16 %d  waves/SIMD %d   %8.3f ms  %7.1f TFLOP/s\n", NACC, BARRIER, blocks_per_cu, best,
+           flops / best / 1e9);
+    hipFree(out);
+}
+
+int main() {
+    for (int w = 1; w <= 4; ++w) run<1, 0>(w);
+    for (int w = 1; w <= 4; ++w) run<1, 1>(w);
+    for (int w = 1; w <= 4; ++w) run<2, 1>(w);
+    for (int w = 1; w <= 2; ++w) run<4, 1>(w);
+    // sustained: many back-to-back launches of the 1-chain, 4 waves/SIMD shape (clock behaviour under steady load)
+    for (int rep = 0; rep < 3; ++rep) run<1, 1>(4);
+    return 0;
+}
