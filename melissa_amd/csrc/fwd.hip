@@ -85,6 +85,9 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
     // (conv2 84 vs 85 us, conv1 46 vs 53 us), see DESIGN.md.
     bool long_k = true;
     for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024;
+#ifdef MEL_RING_ALL
+    long_k = true;                              // tuning builds: every ragged launch through the ring kernel
+#endif
     if (long_k) {
         switch (tag) {
             case 1: gemm_launch_ring_t<1>(gs, count, s); break;

@@ -24,7 +24,7 @@ constexpr int RING_STAGE_FLOATS = 128 * GEMM_BK;   // 64 + 64 rows x 32 floats
 constexpr int RING_PPW = 4;                        // 1 KiB DMA pieces per loader wave per stage (16 pieces / 4 waves)
 
 #ifdef MEL_RING_PROF
-// EXPERIMENT: cycles a consumer wave 0 spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
+// Tuning builds (-DMEL_RING_PROF=<TAG> [-DMEL_RING_ALL]): cycles a consumer wave 0 of the launches tagged TAG spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
 // [4] workgroups counted; loaders: [5] issue, [6] wait_landed, [7] barrier
 __device__ unsigned long long g_ring_prof[8];
 #define RING_T() __builtin_readcyclecounter()
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
 #endif
         }
 #ifdef MEL_RING_PROF
-        if (wid == 4 && lane == 0) {
-            atomicAdd(&g_ring_prof[5], li), atomicAdd(&g_ring_prof[6], lw_), atomicAdd(&g_ring_prof[7], lb);
+        if (wid == 4 && lane == 0 && TAG == MEL_RING_PROF) {
+            atomicAdd(&g_ring_prof[7], lb);
         }
 #endif
         return;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #ifdef MEL_RING_PROF
-    unsigned long long cm_ = 0, cb = 0, ce = 0;
+    unsigned long long cm_ = 0, cb = 0, ce = 0, ep_load = 0, ep_store = 0;
     const unsigned long long tk0 = RING_T();
 #endif
     __builtin_amdgcn_s_barrier();              // B(-1)
@@ -210,6 +210,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
 #endif
         if (++kt == c.KT) {                    // tile complete: epilogue (the loaders are already three steps into the next)
             store_block_f32(batch.p[c.pi], acc, c.m0 + wm * 32 + 4 * h, c.n0 + wn * 32 + r, c.M);
+#ifdef MEL_RING_PROF
+            ep_store += RING_T() - t1;
+#endif
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             t = next_valid(t + stride);
@@ -226,9 +229,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
 #endif
     }
 #ifdef MEL_RING_PROF
-    if (wid == 0 && lane == 0) {
+    if (wid == 0 && lane == 0 && TAG == MEL_RING_PROF) {
         atomicAdd(&g_ring_prof[0], cm_), atomicAdd(&g_ring_prof[1], cb), atomicAdd(&g_ring_prof[2], ce);
         atomicAdd(&g_ring_prof[3], RING_T() - tk0), atomicAdd(&g_ring_prof[4], 1ull);
+        atomicAdd(&g_ring_prof[5], ep_load), atomicAdd(&g_ring_prof[6], ep_store);          // (overrides the loader slots)
     }
 #endif
 }
