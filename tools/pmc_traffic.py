@@ -10,25 +10,10 @@ import glob
 import json
 import sys
 
-NAMES = ["conv1 (lin_l+lin_r)", "conv2 (lin_l+lin_r)", "head0 (Q|V)", "head1 (Q+V)"]      # launch order inside a step
-
-
-def per_launch(directory, counter):
-    path = glob.glob(directory + "/**/*counter_collection.csv", recursive=True)[0]
-    # PLAIN launches of the round step: gemm_f32_persistent_kernel<2, 2, 1, 1, 0, TAG> with TAG 1 (conv1), 2 (conv2),
-    # 3 (head, two launches per step); the encoder is MODE 1
-    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "gemm_f32_persistent_kernel" in r["Kernel_Name"]
-            and ", 0, " in r["Kernel_Name"].split("(")[0][-9:]]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    rows = rows[len(rows) % 4:]
-    sums = [0.0] * 4
-    for i, r in enumerate(rows):
-        sums[i % 4] += float(r["Counter_Value"])
-    n = len(rows) // 4
-    return [s / n for s in sums], n
-
-
-OTHER = {"conv1 attention": "gat_attend_rows_kernel<8, 0,", "conv2 attention": "gat_attend_rows_kernel<8, 2,",
+# launches of the round step by kernel name (the call site is part of it: TAG 1 = conv1, 2 = conv2, 3 = heads)
+LAUNCHES = {"conv1 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 1>", "conv2 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
+         "head0 (Q|V)": "gemm_f32_ring_kernel<3>", "head1 (Q+V)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 3>",
+         "conv1 attention": "gat_attend_rows_kernel<8, 0,", "conv2 attention": "gat_attend_rows_kernel<8, 2,",
          "env round": "env_round_kernel", "encoder": "gemm_f32_persistent_kernel<2, 2, 1, 1, 1,"}
 
 
@@ -41,17 +26,12 @@ def mean_counter(directory, counter, needle):
 
 
 def main():
-    fetch, n1 = per_launch(sys.argv[1], "FETCH_SIZE")
-    write, n2 = per_launch(sys.argv[2], "WRITE_SIZE")
     out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 "
                       "--no-cpu-baseline --no-profile --no-graph",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
                          "MI355X_MICROARCH.md section HBM)",
-           "workload": "L-DGN 50-node, 1024 envs, round loop, fp32", "steps_averaged": [n1, n2], "per_launch": {}}
-    for k, name in enumerate(NAMES):
-        out["per_launch"][name] = {"FETCH_SIZE_KB": round(fetch[k], 1), "WRITE_SIZE_KB": round(write[k], 1),
-                                   "hbm_bytes_corrected": int((2 * fetch[k] + write[k]) * 1024)}
-    for name, needle in OTHER.items():
+           "workload": "L-DGN 50-node, 1024 envs, round loop, fp32", "per_launch": {}}
+    for name, needle in LAUNCHES.items():
         f, w = mean_counter(sys.argv[1], "FETCH_SIZE", needle), mean_counter(sys.argv[2], "WRITE_SIZE", needle)
         out["per_launch"][name] = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                                    "hbm_bytes_corrected": int((2 * f + w) * 1024)}
