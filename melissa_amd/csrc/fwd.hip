@@ -84,7 +84,7 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
     // measured 27.4 vs 30.7 us for the head launches; at K <= 512 the one-role kernel is as fast or faster
     // (conv2 84 vs 85 us, conv1 46 vs 53 us), see DESIGN.md.
     bool long_k = true;
-    for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024;
+    for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024 && gs[i].ldy % 4 == 0;
 #ifdef MEL_RING_ALL
     long_k = true;                              // tuning builds: every ragged launch through the ring kernel
 #endif

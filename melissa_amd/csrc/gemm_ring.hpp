@@ -1,8 +1,10 @@
 // fp32-MFMA row GEMM with SPECIALISED wavefronts (PLAIN problems, 64 x 64 tiles, persistent):
 //
-//   waves 0-3  consumers  2 x 2 wavefronts of 32 x 32: ds_read_b128 fragments + v_mfma_f32_32x32x2_f32, epilogue
+//   waves 0-3  consumers  2 x 2 wavefronts of 32 x 32: ds_read_b128 fragments + v_mfma_f32_32x32x2_f32; a finished
+//                         accumulator tile is dropped into an LDS hand-over buffer (16 ds_write_b32) and the wave goes on
 //   waves 4-7  loaders    global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), running
-//                         THREE K steps ahead of the arithmetic through a four-stage LDS ring
+//                         THREE K steps ahead of the arithmetic through a four-stage LDS ring; they also run the
+//                         epilogue (scale, bias, ReLU, 16-byte row stores) of the tile the consumers just finished
 //
 // Why: in the one-role kernels (gemm_f32.hpp) the workgroups that share a CU move through load -> LDS -> MFMA phases
 // in step, so the data-movement skeleton and the MFMA chain of a launch add up instead of overlapping (DESIGN.md,
@@ -22,6 +24,13 @@ constexpr int RING_STAGES = 4;
 constexpr int RING_AHEAD = 3;                      // K steps the loaders run ahead (< RING_STAGES)
 constexpr int RING_STAGE_FLOATS = 128 * GEMM_BK;   // 64 + 64 rows x 32 floats
 constexpr int RING_PPW = 4;                        // 1 KiB DMA pieces per loader wave per stage (16 pieces / 4 waves)
+constexpr int RING_OUT_STRIDE = 64;                // floats per row of the accumulator hand-over buffer (unpadded: 64 KiB
+                                                   // ring + 16 KiB = exactly half of the CU's LDS); 16-byte chunk c of row
+                                                   // r sits at chunk c ^ ((r & 3) << 1) so that the loaders' four-row reads
+                                                   // spread over all banks
+__device__ __forceinline__ int ring_out_index(int row, int col) {
+    return row * RING_OUT_STRIDE + ((((col >> 2) ^ ((row & 3) << 1))) << 2) + (col & 3);
+}
 
 #ifdef MEL_RING_PROF
 // Tuning builds (-DMEL_RING_PROF=<TAG> [-DMEL_RING_ALL]): cycles a consumer wave 0 of the launches tagged TAG spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
@@ -34,6 +43,8 @@ template <int TAG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) {
     constexpr int BM = 64, BN = 64;
     __shared__ __attribute__((aligned(16))) float lds[RING_STAGES * RING_STAGE_FLOATS];
+    // finished accumulator tile, handed from the consumers to the loaders
+    __shared__ __attribute__((aligned(16))) float outbuf[BM * RING_OUT_STRIDE];
 
     // tile bookkeeping (wave-uniform), identical for every wave of the workgroup
     int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
@@ -116,6 +127,32 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
         };
         load_tile(first);
         int issued = 0;
+        // the tile the CONSUMERS are working on (the loaders write its result out once it is complete)
+        int ct = first;
+        Tile cc = tile_of(first);
+        int ckt = 0;
+        auto write_out = [&]() {               // epilogue of tile cc from the hand-over buffer: 16 rows per loader wave
+            const GemmArgs& g = batch.p[cc.pi];
+            float* __restrict__ Y = g.Y;
+            const float* __restrict__ rs = g.rscale;
+            const int ldy = g.ldy, relu = g.relu;
+            const int col = (lane & 15) * 4, n = cc.n0 + col;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (g.bias_hi && n >= g.split_n) bias4 = *reinterpret_cast<const f32x4*>(g.bias_hi + (n - g.split_n));
+            else if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+            float sc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sc[i] = rs ? rs[min(cc.m0 + lw * 16 + i * 4 + (lane >> 4), cc.M - 1)] : 1.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lw * 16 + i * 4 + (lane >> 4);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(outbuf + ring_out_index(row, col));
+                f32x4 o = {a[0] * sc[i] + bias4[0], a[1] * sc[i] + bias4[1], a[2] * sc[i] + bias4[2], a[3] * sc[i] + bias4[3]};
+                if (relu) o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+                const int m = cc.m0 + row;
+                if (m < cc.M) *reinterpret_cast<f32x4*>(Y + (size_t)m * ldy + n) = o;
+            }
+        };
         auto issue = [&]() {                   // DMAs of the next step of the stream into its ring stage
             if (issued >= steps_total) return;
             float* stage = lds + (issued % RING_STAGES) * RING_STAGE_FLOATS;
@@ -161,6 +198,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             const unsigned long long t3 = RING_T();
             li += t1 - t0, lw_ += t2 - t1, lb += t3 - t2;
 #endif
+            if (++ckt == cc.KT) {              // step g completed a tile: its accumulators are in outbuf (written before B(g))
+                write_out();                   // done before this wave reaches B(g+1); the consumers' next hand-over is >= 2 steps away
+                ct = next_valid(ct + stride);
+                ckt = 0;
+                if (ct < total) cc = tile_of(ct);
+            }
         }
 #ifdef MEL_RING_PROF
         if (wid == 4 && lane == 0 && TAG == MEL_RING_PROF) {
@@ -209,12 +252,15 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
         const unsigned long long t1 = RING_T();
 #endif
         if (++kt == c.KT) {                    // tile complete: epilogue (the loaders are already three steps into the next)
-            store_block_f32(batch.p[c.pi], acc, c.m0 + wm * 32 + 4 * h, c.n0 + wn * 32 + r, c.M);
+            // hand the accumulator block to the loaders (C/D layout: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                outbuf[ring_out_index(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, wn * 32 + r)] = acc[e];
+                acc[e] = 0.f;
+            }
 #ifdef MEL_RING_PROF
             ep_store += RING_T() - t1;
 #endif
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             t = next_valid(t + stride);
             kt = 0;
             if (t < total) c = tile_of(t);
