@@ -20,10 +20,17 @@
 
 namespace mel {
 
-constexpr int RING_STAGES = 4;
-constexpr int RING_AHEAD = 3;                      // K steps the loaders run ahead (< RING_STAGES)
-constexpr int RING_STAGE_FLOATS = 128 * GEMM_BK;   // 64 + 64 rows x 32 floats
-constexpr int RING_PPW = 4;                        // 1 KiB DMA pieces per loader wave per stage (16 pieces / 4 waves)
+// TS = 1: 64 x 64 tiles, four-stage ring, loaders three K steps ahead, two workgroups per CU, loader-side epilogue.
+// TS = 2: 128 x 128 tiles (each consumer wave 64 x 64 = four accumulator blocks: half the operand traffic per FLOP),
+//         three-stage ring of 32 KiB stages, loaders two steps ahead, one workgroup per CU, consumer-side epilogue.
+template <int TS>
+struct RingCfg {
+    static constexpr int BM = 64 * TS, BN = 64 * TS;
+    static constexpr int STAGES = TS == 1 ? 4 : 3;
+    static constexpr int AHEAD = STAGES - 1;                       // K steps the loaders run ahead (< STAGES)
+    static constexpr int STAGE_FLOATS = (BM + BN) * GEMM_BK;
+    static constexpr int PPW = (BM + BN) / 8 / 4;                  // 1 KiB DMA pieces per loader wave per stage
+};
 constexpr int RING_OUT_STRIDE = 64;                // floats per row of the accumulator hand-over buffer (unpadded: 64 KiB
                                                    // ring + 16 KiB = exactly half of the CU's LDS); 16-byte chunk c of row
                                                    // r sits at chunk c ^ ((r & 3) << 1) so that the loaders' four-row reads
@@ -39,12 +46,14 @@ __device__ unsigned long long g_ring_prof[8];
 #define RING_T() __builtin_readcyclecounter()
 #endif
 
-template <int TAG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) {
-    constexpr int BM = 64, BN = 64;
+template <int TAG = 0, int TS = 1>
+__global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(GemmBatch batch) {
+    using Cfg = RingCfg<TS>;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN;
+    constexpr int RING_STAGES = Cfg::STAGES, RING_AHEAD = Cfg::AHEAD, RING_STAGE_FLOATS = Cfg::STAGE_FLOATS, RING_PPW = Cfg::PPW;
     __shared__ __attribute__((aligned(16))) float lds[RING_STAGES * RING_STAGE_FLOATS];
-    // finished accumulator tile, handed from the consumers to the loaders
-    __shared__ __attribute__((aligned(16))) float outbuf[BM * RING_OUT_STRIDE];
+    // finished accumulator tile, handed from the consumers to the loaders (TS = 1 only)
+    __shared__ __attribute__((aligned(16))) float outbuf[TS == 1 ? 64 * RING_OUT_STRIDE : 4];
 
     // tile bookkeeping (wave-uniform), identical for every wave of the workgroup
     int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
@@ -170,8 +179,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
         };
         auto wait_landed = [&](int g) {        // every DMA of steps <= g has landed (in-order completion)
             const int after = issued - (g + 1);    // steps issued later than g: 0 .. RING_AHEAD - 1
-            if (after >= 2) wait_vmcnt_le<2 * RING_PPW>();
-            else if (after == 1) wait_vmcnt_le<RING_PPW>();
+            if (RING_AHEAD >= 3 && after >= 2) wait_vmcnt_le<2 * RING_PPW>();
+            else if (after >= 1) wait_vmcnt_le<RING_PPW>();
             else wait_vmcnt_le<0>();
         };
 #pragma unroll
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             const unsigned long long t3 = RING_T();
             li += t1 - t0, lw_ += t2 - t1, lb += t3 - t2;
 #endif
-            if (++ckt == cc.KT) {              // step g completed a tile: its accumulators are in outbuf (written before B(g))
+            if (TS == 1 && ++ckt == cc.KT) {   // step g completed a tile: its accumulators are in outbuf (written before B(g))
                 write_out();                   // done before this wave reaches B(g+1); the consumers' next hand-over is >= 2 steps away
                 ct = next_valid(ct + stride);
                 ckt = 0;
@@ -216,16 +225,24 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
     // ---------------------------------------------------------------------- consumers
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int a_row_l = wm * 32 + r, w_row_l = BM + wn * 32 + r;
-    const int a_row = a_row_l * GEMM_BK, a_x = (a_row_l >> 1) & 7;
-    const int w_row = w_row_l * GEMM_BK, w_x = (w_row_l >> 1) & 7;
+    int a_row[TS], a_x[TS], w_row[TS], w_x[TS];          // fragment rows of this lane (floats into a stage) + their swizzle
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+        const int ar = wm * 32 * TS + i * 32 + r, wr = BM + wn * 32 * TS + i * 32 + r;
+        a_row[i] = ar * GEMM_BK, a_x[i] = (ar >> 1) & 7;
+        w_row[i] = wr * GEMM_BK, w_x[i] = (wr >> 1) & 7;
+    }
 
     int t = first;
     Tile c = tile_of(t);
     int kt = 0;
-    f32x16 acc;
+    f32x16 acc[TS][TS];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int j = 0; j < TS; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 #ifdef MEL_RING_PROF
     unsigned long long cm_ = 0, cb = 0, ce = 0, ep_load = 0, ep_store = 0;
     const unsigned long long tk0 = RING_T();
@@ -238,25 +255,42 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
         const float* cur = lds + (g % RING_STAGES) * RING_STAGE_FLOATS;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#ifdef MEL_EXP_NOLDS
-            const f32x4 a = {1.f + q, 2.f, 3.f, 4.f + lane}, b = {0.5f, 0.25f + q, 0.125f, 1.f};
-#else
-            const f32x4 a = *reinterpret_cast<const f32x4*>(cur + a_row + (((2 * q + h) ^ a_x) << 2));
-            const f32x4 b = *reinterpret_cast<const f32x4*>(cur + w_row + (((2 * q + h) ^ w_x) << 2));
-#endif
+            f32x4 a[TS], b[TS];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+            for (int i = 0; i < TS; ++i) {
+                a[i] = *reinterpret_cast<const f32x4*>(cur + a_row[i] + (((2 * q + h) ^ a_x[i]) << 2));
+                b[i] = *reinterpret_cast<const f32x4*>(cur + w_row[i] + (((2 * q + h) ^ w_x[i]) << 2));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+#pragma unroll
+                    for (int j = 0; j < TS; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
         }
 #ifdef MEL_RING_PROF
-        asm volatile("s_nop 0" ::"v"(acc[0]));          // the MFMA chain has retired
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));    // the MFMA chain has retired
         const unsigned long long t1 = RING_T();
 #endif
         if (++kt == c.KT) {                    // tile complete: epilogue (the loaders are already three steps into the next)
-            // hand the accumulator block to the loaders (C/D layout: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*h)
+            if constexpr (TS == 1) {
+                // hand the accumulator block to the loaders (C/D layout: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*h)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                outbuf[ring_out_index(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, wn * 32 + r)] = acc[e];
-                acc[e] = 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    outbuf[ring_out_index(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, wn * 32 + r)] = acc[0][0][e];
+                    acc[0][0][e] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TS; ++i)
+#pragma unroll
+                    for (int j = 0; j < TS; ++j) {
+                        store_block_f32(batch.p[c.pi], acc[i][j], c.m0 + wm * 32 * TS + i * 32 + 4 * h,
+                                        c.n0 + wn * 32 * TS + j * 32 + r, c.M);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    }
             }
 #ifdef MEL_RING_PROF
             ep_store += RING_T() - t1;

@@ -5,16 +5,27 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NACC, int BARRIER>
+// RANDOM = 1: operands with random mantissas and signs, changing every instruction (what real activations and weights
+// look like to the multiplier array), instead of one constant pair: data-dependent switching power / clocks
+template <int NACC, int BARRIER, int RANDOM = 0>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
     f32x16 acc[NACC];
     for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     float a = 1.f + threadIdx.x * 1e-3f, b = 0.5f;
+    float ra[16], rb[16];
+    unsigned x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int m = 0; m < 16; ++m) {
+        x = x * 1664525u + 1013904223u;
+        ra[m] = __builtin_bit_cast(float, (x & 0x807fffffu) | 0x3f000000u);       // +-[0.5, 1)
+        x = x * 1664525u + 1013904223u;
+        rb[m] = __builtin_bit_cast(float, (x & 0x807fffffu) | 0x3f000000u);
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < 16 / NACC; ++m)
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(RANDOM ? ra[m * NACC + i] : a, RANDOM ? rb[m * NACC + i] : b, acc[i], 0, 0, 0);
         if (BARRIER) __builtin_amdgcn_s_barrier();
     }
     float s = 0.f;
@@ -22,7 +33,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-template <int NACC, int BARRIER>
+template <int NACC, int BARRIER, int RANDOM = 0>
 void run(int blocks_per_cu) {
     const int blocks = 256 * blocks_per_cu, iters = 2000;
     float* out;
@@ -32,7 +43,7 @@ void run(int blocks_per_cu) {
     float best = 1e30f;
     for (int rep = 0; rep < 6; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<NACC, BARRIER>), dim3(blocks), dim3(256), 0, 0, out, iters);
+        hipLaunchKernelGGL((k<NACC, BARRIER, RANDOM>), dim3(blocks), dim3(256), 0, 0, out, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -40,8 +51,8 @@ void run(int blocks_per_cu) {
         if (rep) best = ms < best ? ms : best;
     }
     const double flops = (double)blocks * 4 * iters * 16 * 4096.0;
-    printf("chains/wave %d  barrier/16 %d  waves/SIMD %d   %8.3f ms  %7.1f TFLOP/s\n", NACC, BARRIER, blocks_per_cu, best,
-           flops / best / 1e9);
+    printf("chains/wave %d  barrier/16 %d  random operands %d  waves/SIMD %d   %8.3f ms  %7.1f TFLOP/s\n", NACC, BARRIER, RANDOM,
+           blocks_per_cu, best, flops / best / 1e9);
     hipFree(out);
 }
 
@@ -50,7 +61,9 @@ int main() {
     for (int w = 1; w <= 4; ++w) run<1, 1>(w);
     for (int w = 1; w <= 4; ++w) run<2, 1>(w);
     for (int w = 1; w <= 2; ++w) run<4, 1>(w);
-    // sustained: many back-to-back launches of the 1-chain, 4 waves/SIMD shape (clock behaviour under steady load)
-    for (int rep = 0; rep < 3; ++rep) run<1, 1>(4);
+    // the same shapes fed with random operands
+    for (int w = 1; w <= 4; ++w) run<1, 1, 1>(w);
+    for (int w = 1; w <= 2; ++w) run<4, 1, 1>(w);
+    run<1, 1, 0>(4);
     return 0;
 }
