@@ -142,6 +142,69 @@ def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
                       f"N={n_nodes}, dynamic graph"}
 
 
+def _env_worker(conn, n_nodes, seeds):
+    """One env-worker process of the SubprocVectorEnv-style CPU baseline: owns len(seeds) oracle envs."""
+    from oracle import env_oracle as eo
+    from melissa_amd.env import synthetic_graph_pool
+    pool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
+    envs = [eo.OraclePettingZooEnv(eo.OracleGraphEnv(
+        n_nodes, graph_pool=pool, dynamic_graph=True,
+        np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(s))))) for s in seeds]
+    obs = [e.reset()[0] for e in envs]
+    conn.send((np.stack([o["obs"] for o in obs]), np.stack([o["mask"] for o in obs])))
+    while True:
+        act = conn.recv()
+        if act is None:
+            return
+        live = 0
+        for k, e in enumerate(envs):
+            live += int(bool(obs[k]["mask"][0]))
+            o, _r, term, _tr, info = e.step(int(act[k]))
+            if term and info.get("explicit_reset"):
+                o, _ = e.reset()
+            obs[k] = o
+        conn.send((np.stack([o["obs"] for o in obs]), np.stack([o["mask"] for o in obs]), live))
+
+
+def cpu_baseline_subproc(n_nodes, budget_s=8.0, workers=None, envs_per_worker=5):
+    """SURVEY.md 8(d) variant (b): one env-worker PROCESS per core group (the reference's SubprocVectorEnv model,
+    l_dgn.py:137-146) stepping oracle envs in parallel, one learner process doing the batched oracle forward."""
+    import multiprocessing as mp
+    import torch
+    from oracle import net_oracle as no
+    workers = workers or max(1, min(16, (os.cpu_count() or 2) // 2))
+    ctx = mp.get_context("spawn")
+    conns, procs = [], []
+    for w in range(workers):
+        a, b = ctx.Pipe()
+        p = ctx.Process(target=_env_worker, args=(b, n_nodes, [5000 + w * envs_per_worker + k for k in range(envs_per_worker)]),
+                        daemon=True)
+        p.start()
+        conns.append(a), procs.append(p)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = no.init_weights("l_dgn", seed=9)
+    first = [c.recv() for c in conns]
+    obs, mask = np.concatenate([f[0] for f in first]), np.concatenate([f[1] for f in first])
+    decisions, iters = 0, 0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        while time.perf_counter() - t0 < budget_s:
+            act = no.dqn_act(no.ldgn_forward(sd, obs, n_nodes), mask).numpy()
+            for w, c in enumerate(conns):
+                c.send(act[w * envs_per_worker:(w + 1) * envs_per_worker])
+            out = [c.recv() for c in conns]
+            obs, mask = np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])
+            decisions += sum(o[2] for o in out)
+            iters += 1
+    dt = time.perf_counter() - t0
+    for c in conns:
+        c.send(None)
+    for p in procs:
+        p.join(timeout=5)
+    return {"value": decisions / dt, "workers": workers, "envs": workers * envs_per_worker,
+            "sample": f"{iters} iterations, {workers} env-worker processes x {envs_per_worker} envs + one learner ({dt:.1f} s)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +226,15 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
+
+    # CPU baseline variant (b) starts child processes: do it BEFORE anything touches the GPU (no fork / exec from a
+    # process with an initialised HIP runtime)
+    subproc_baseline = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        try:
+            subproc_baseline = cpu_baseline_subproc(args.nodes)
+        except Exception as exc:              # the baseline is a report, never a reason to lose the bench line
+            subproc_baseline = {"error": repr(exc)}
 
     import torch
     from melissa_amd import _lib, parallel
@@ -333,6 +405,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.nodes)
+        line["cpu_baseline"]["subproc"] = subproc_baseline       # variant (b): env-worker processes + one learner
     print(json.dumps(line))
 
 
