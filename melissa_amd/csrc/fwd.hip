@@ -684,7 +684,7 @@ extern "C" {
 
 const char* mel_last_error(void) { return g_err; }
 #ifdef MEL_RING_PROF
-// EXPERIMENT: read (and reset) the ring kernel's in-kernel cycle counters
+// tuning builds only (-DMEL_RING_PROF=<tag>): read and reset the ring kernel's in-kernel cycle counters (tools/ring_prof.py)
 void mel_debug_ring_prof(unsigned long long* out8) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ring_prof), 8 * sizeof(unsigned long long));

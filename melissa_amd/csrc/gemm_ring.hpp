@@ -165,11 +165,9 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
         auto issue = [&]() {                   // DMAs of the next step of the stream into its ring stage
             if (issued >= steps_total) return;
             float* stage = lds + (issued % RING_STAGES) * RING_STAGE_FLOATS;
-#ifndef MEL_EXP_NODMA
 #pragma unroll
             for (int i = 0; i < RING_PPW; ++i)
                 dma_16B_to_lds(src[i] + lkt * GEMM_BK, stage + (lw * RING_PPW + i) * 8 * GEMM_BK);
-#endif
             ++issued;
             if (++lkt == lKT) {
                 lt = next_valid(lt + stride);

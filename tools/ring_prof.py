@@ -1,4 +1,5 @@
-"""EXPERIMENT: in-kernel cycle breakdown of gemm_f32_ring_kernel over a few round steps (build with -DMEL_RING_PROF)."""
+"""Tuning aid: in-kernel cycle breakdown of gemm_f32_ring_kernel over a few round steps.
+Build with MEL_HIPCC_FLAGS="-DMEL_RING_PROF=<tag> -DMEL_RING_ALL" (tag 1 = conv1, 2 = conv2, 3 = heads)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
