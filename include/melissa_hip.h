@@ -314,6 +314,16 @@ typedef struct mel_env_batch {
     double*   episode_rewards; /* [B]       GraphEnv.episode_rewards_sum                         */
     float*    obs_matrix;      /* [B, N, 8] GraphEnv.obs_matrix                                  */
     double*   info_stats;      /* [B, N, 10] infos[agent]['logger_stats']                        */
+    /* Optional episode log (caller-owned; log_capacity 0 = off): whenever an env's episode ends inside
+     * mel_env_step / mel_env_round with on-device reset, one row is appended - the `logger_stats` of the final
+     * observation (graph.py:166-178: what the reference's collectors gather into `episode_info`,
+     * multi_agent_collector.py:283) plus env id, episode id and num_moves.  Rows beyond the capacity are dropped
+     * (the cursor keeps counting). */
+    int32_t   log_capacity;
+    int32_t   log_reserved;
+    int32_t*  log_cursor;      /* [1]  episodes logged so far (device, atomically advanced)      */
+    double*   log_stats;       /* [capacity, 10]                                                 */
+    int32_t*  log_meta;        /* [capacity, 3] env, pool episode, num_moves                     */
 } mel_env_batch;
 
 /* An episode pool: what World.reset samples (core.py:372-394), pre-drawn on the host with the

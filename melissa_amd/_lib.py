@@ -28,6 +28,9 @@ EXPORTS = ("mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_bac
            "mel_prof_read", "mel_last_error", "mel_version")
 PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
 HEURISTICS = {None: 0, "simple_broadcast": 1, "broadcast_if_any_interested": 2, "silent": 3}
+LOGGER_KEYS = ("total_messages_transmitted", "coverage", "messages_sent", "messages_received", "n_neighbours",
+               "interested_agents", "coverage_interested_fraction", "coverage_interested_count",
+               "uninterested_with_message", "episode_rewards_sum")      # graph.py:166-178
 N_STAGES = 14
 STAGE_NAMES = ("plan", "encoder", "conv1_lin", "conv1_lin_r", "conv1_att", "conv2_lin", "conv2_lin_r", "conv2_att",
                "head_hidden", "head_tail", "select", "env_step", "env_reset", "env_observe")
@@ -72,7 +75,9 @@ class MelEnvBatch(C.Structure):
                 ("agent_msgs", C.c_void_p), ("received", C.c_void_p), ("two_hop_cover", C.c_void_p),
                 ("agent_action", C.c_void_p), ("current_actions", C.c_void_p), ("steps_taken", C.c_void_p),
                 ("sel_steps", C.c_void_p), ("rewards", C.c_void_p), ("pz_rewards", C.c_void_p),
-                ("episode_rewards", C.c_void_p), ("obs_matrix", C.c_void_p), ("info_stats", C.c_void_p)]
+                ("episode_rewards", C.c_void_p), ("obs_matrix", C.c_void_p), ("info_stats", C.c_void_p),
+                ("log_capacity", C.c_int32), ("log_reserved", C.c_int32), ("log_cursor", C.c_void_p),
+                ("log_stats", C.c_void_p), ("log_meta", C.c_void_p)]
 
 
 class MelEpisodePool(C.Structure):

@@ -221,3 +221,49 @@ class MultiStreamRoundLoop:
             out["episodes"] += c["episodes"]
             out["errors"] |= c["errors"]
         return out
+
+
+class Collector:
+    """The collect() surface of the reference's collectors (multi_agent_collector.py:89-353: ``collect(n_step=...)`` /
+    ``collect(n_episode=...)`` returning counts, speed and the episodes' ``logger_stats``) on top of the device-resident
+    :class:`RoundLoop`: rounds are issued in chunks without host reads, the device counters and the on-device episode
+    log (``mel_env_batch.log_*``) are read between chunks.  ``n_step`` counts live agent decisions (what the reference
+    counts as collected transitions), ``n_episode`` finished episodes.  Evaluation as in l_dgn.py:92-129: build the
+    vector env with ``is_testing=True`` and call ``collect(n_episode=...)``."""
+
+    def __init__(self, policy, venv: HipGraphVectorEnv, episodes_per_env: int = 16, seed: int = 0, eps: float = 0.0,
+                 replay=None, log_capacity: int = 65536, chunk: int = 8, use_graph: bool = True):
+        self.venv, self.policy, self.chunk = venv, policy, int(chunk)
+        venv.enable_episode_log(log_capacity)
+        self.loop = RoundLoop(venv, policy, episodes_per_env=episodes_per_env, seed=seed, eps=eps, replay=replay,
+                              use_graph=use_graph)
+        self._decisions = self.loop.counters()["decisions"]
+        self.collect_step, self.collect_episode, self.collect_time = 0, 0, 0.0
+
+    def collect(self, n_step: int | None = None, n_episode: int | None = None) -> dict:
+        import time
+        if (n_step is None) == (n_episode is None):
+            raise ValueError("give exactly one of n_step / n_episode")        # the reference asserts the same
+        self.venv.log_cursor.zero_()
+        t0 = time.perf_counter()
+        steps = episodes = 0
+        with torch.no_grad():
+            while (n_step is not None and steps < n_step) or (n_episode is not None and episodes < n_episode):
+                self.loop.run(self.chunk)
+                c = self.loop.counters()                                      # synchronises
+                steps = c["decisions"] - self._decisions
+                episodes = int(self.venv.log_cursor.item())
+                if c["errors"]:
+                    raise RuntimeError(f"env error flags {c['errors']:#x} (episode pool exhausted or desynchronised actions)")
+        dt = max(time.perf_counter() - t0, 1e-9)
+        stats, meta, total = self.venv.read_episode_log()
+        self._decisions += steps
+        self.collect_step += steps
+        self.collect_episode += total
+        self.collect_time += dt
+        out = {"n/ep": total, "n/st": steps, "collect_time": dt, "collect_speed": steps / dt,
+               "lens": meta[:, 2].copy(), "episode_info": {k: stats[:, i].copy() for i, k in enumerate(_lib.LOGGER_KEYS)}}
+        if len(stats):
+            out.update({k: float(stats[:, i].mean()) for i, k in enumerate(_lib.LOGGER_KEYS)})
+            out["len"] = float(meta[:, 2].mean())
+        return out

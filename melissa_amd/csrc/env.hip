@@ -248,6 +248,28 @@ __device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, 
     }
 }
 
+// one row of the episode log: the logger_stats of the final observation of the episode that just ended
+__device__ __forceinline__ void log_episode(const mel_env_batch& e, int b, const Env& s, int lane) {
+    if (e.log_capacity <= 0) return;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(e.log_cursor, 1);
+    slot = uniform_i32(slot);
+    if (slot >= e.log_capacity) return;
+    // the info the collectors see is infos[agent_selection] AS STORED (graph.py:358 refreshes it only when that agent
+    // becomes the selection after a live step; a dead step returns before that, graph.py:304-310), so the row is a
+    // copy of the selected agent's slot, not a recomputation from the current state
+    if (lane < MEL_ENV_LOGGER_STATS) {
+        const int a = s.sel >= 0 ? s.sel : 0;
+        const bool valid = s.sel >= 0 && ((s.info_valid >> a) & 1ull);
+        e.log_stats[(size_t)slot * MEL_ENV_LOGGER_STATS + lane] =
+            valid ? e.info_stats[((size_t)b * e.n_nodes + a) * MEL_ENV_LOGGER_STATS + lane] : 0.0;
+    }
+    if (lane == 0) {
+        int32_t* m = e.log_meta + (size_t)slot * 3;
+        m[0] = b, m[1] = s.episode, m[2] = s.num_moves;
+    }
+}
+
 // GraphEnv.step graph.py:303-359 (+ the sticky reward copy of [3P] PettingZooEnv.step)
 // returns true when this step completed the round and ran the world step
 __device__ __forceinline__ bool env_step(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
@@ -483,6 +505,7 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
             if (r & 1) s.done_count += 1;
             if ((r & 1) && ((r & 2) || s.done_count == n)) {                  // episode over
                 s.episodes_done += 1;
+                log_episode(a.env, b, s, lane);
                 const int ep = uniform_i32(a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)]);
                 env_reset(a.env, a.pool, b, s, ep, 0, lane);
                 env_observe(a.env, b, s, none, 0, lane);
@@ -532,6 +555,7 @@ __global__ __launch_bounds__(256) void env_kernel(StepArgs a) {
                 // multi_agent_collector.py:261-264: episode over -> reset this env
                 if ((r & 1) && ((r & 2) || s.done_count == a.env.n_nodes)) {
                     s.episodes_done += 1;
+                    log_episode(a.env, b, s, lane);
                     const int ep = a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)];
                     env_reset(a.env, a.pool, b, s, ep, 0, lane);
                     env_observe(a.env, b, s, a.out, row, lane);
@@ -549,6 +573,8 @@ static mel_status check_env(const mel_env_batch* env, int64_t n) {
     if (env->n_nodes < 1 || env->n_nodes > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, 64]", env->n_nodes);
     if (n < 0 || n > env->n_envs) return fail(MEL_ERR_INVALID_ARG, "n=%ld outside [0, n_envs=%d]", (long)n, env->n_envs);
     if (!env->pos || !env->scalars) return fail(MEL_ERR_INVALID_ARG, "env batch is not bound (mel_env_bind)");
+    if (env->log_capacity < 0 || (env->log_capacity > 0 && (!env->log_cursor || !env->log_stats || !env->log_meta)))
+        return fail(MEL_ERR_INVALID_ARG, "episode log of capacity %d has null buffers", env->log_capacity);
     return MEL_OK;
 }
 
@@ -610,9 +636,12 @@ mel_status mel_env_bind(mel_env_batch* env, int32_t n_envs, int32_t n_nodes, voi
     const EnvLayout L = carve_env(n_envs, n_nodes, state);
     const int32_t dyn = env->dynamic_graph, hlr = env->has_local_ratio, heu = env->heuristic, tst = env->is_testing;
     const double lr = env->local_ratio;
+    const mel_env_batch keep = *env;               // the caller-owned episode log survives a (re)bind
     if (heu < MEL_HEURISTIC_NONE || heu > MEL_HEURISTIC_SILENT) return fail(MEL_ERR_INVALID_ARG, "heuristic %d", heu);
     *env = L.e;
     env->dynamic_graph = dyn, env->has_local_ratio = hlr, env->local_ratio = lr, env->heuristic = heu, env->is_testing = tst;
+    env->log_capacity = keep.log_capacity, env->log_cursor = keep.log_cursor, env->log_stats = keep.log_stats,
+    env->log_meta = keep.log_meta;
     return MEL_OK;
 }
 

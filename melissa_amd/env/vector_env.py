@@ -147,6 +147,26 @@ class HipGraphVectorEnv:
         for _ in range(3 if construct_like_reference is True else int(construct_like_reference)):
             self._reset_rows(np.arange(self.env_num), observe=False)
 
+    def enable_episode_log(self, capacity: int):
+        """Device-side log of finished episodes (on-device resets only): one row of the reference's ``logger_stats``
+        (graph.py:166-178) per episode, what ``MultiAgentCollector`` gathers into ``episode_info``."""
+        self.log_cursor = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.log_stats = torch.zeros(capacity, _lib.ENV_LOGGER_STATS, dtype=torch.float64, device=self.device)
+        self.log_meta = torch.zeros(capacity, 3, dtype=torch.int32, device=self.device)
+        self.env.log_capacity = int(capacity)
+        self.env.log_cursor, self.env.log_stats = self.log_cursor.data_ptr(), self.log_stats.data_ptr()
+        self.env.log_meta = self.log_meta.data_ptr()
+
+    def read_episode_log(self, reset: bool = False):
+        """-> (stats float64 [k, 10] in _lib.LOGGER_KEYS order, meta int32 [k, 3] = env, pool episode, num_moves,
+        total episodes ended incl. rows dropped beyond the capacity).  Synchronises."""
+        total = int(self.log_cursor.item())
+        k = min(total, int(self.env.log_capacity))
+        out = self.log_stats[:k].cpu().numpy(), self.log_meta[:k].cpu().numpy(), total
+        if reset:
+            self.log_cursor.zero_()
+        return out
+
     def make_sampler(self, seed) -> EpisodeSampler:
         """An episode sampler with this env's settings (graph pool size, evaluation schedule, scripted ratio, ...)
         and its own generator seeded ``seed`` - what the device-resident loops pre-draw their episode pools with."""
