@@ -352,3 +352,11 @@ def test_collector_surface_counts_and_episode_stats():
     assert 0.0 < out["coverage"] <= 1.0 and out["total_messages_transmitted"] >= 1.0 and out["len"] >= 1.0
     assert (out["episode_info"]["coverage"] <= 1.0).all() and (out["lens"] >= 1).all()
     assert col.collect_step >= 2000 and col.collect_episode >= 50
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn"])
+def test_watch_single_env(model):
+    """BASELINE config 0: --watch, 20-node graphs, a single env (evaluation schedule, greedy policy)."""
+    from melissa_amd.watch import watch
+    out = watch(model=model, n_nodes=20, envs=1, episodes=6)
+    assert out["n/ep"] >= 6 and 0.0 < out["coverage"] <= 1.0 and out["total_messages_transmitted"] >= 1
