@@ -692,6 +692,15 @@ void mel_debug_ring_prof(unsigned long long* out8) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ring_prof), z, sizeof(z));
 }
 #endif
+#ifdef MEL_GEMM_PROF
+// tuning builds only: read and reset the one-role persistent kernel's cycle counters (tools/gemm_prof.py)
+void mel_debug_gemm_prof(unsigned long long* out8) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_prof), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
+}
+#endif
 size_t mel_abi_sizeof(int32_t which) {
     switch (which) {
         case 0: return sizeof(mel_linear);

@@ -311,6 +311,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
 // Tile ids are padded per problem to multiples of 8 so that id % 8 (= XCD under round-robin dispatch, the
 // grid is a multiple of 8) keeps meaning "same XCD" for the A-panel-sharing remap.
 // ------------------------------------------------------------------------------------------------
+#ifdef MEL_GEMM_PROF
+// Tuning builds (-DMEL_GEMM_PROF=<TAG>): cycles wave 0 of every workgroup of the launches tagged TAG spends in
+// [0] issuing the prefetch (+ next-tile setup), [1] LDS fragment reads + MFMA chain, [2] waiting for the prefetch and
+// filling the other LDS stage, [3] the step barrier, [4] the epilogue, [5] whole kernel, [6] workgroups counted
+__device__ unsigned long long g_gemm_prof[8];
+#define GEMM_T() __builtin_readcyclecounter()
+#endif
+
 template <int A_CHUNKS, int W_CHUNKS>
 struct TileCtx {
     AChunk ac[A_CHUNKS];
@@ -438,6 +446,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
         *reinterpret_cast<f32x4*>(lds + BM * GEMM_LDS_STRIDE + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = w_reg[i];
     __syncthreads();
     int stage = 0;
+#ifdef MEL_GEMM_PROF
+    unsigned long long pf = 0, pm = 0, pw = 0, pb = 0, pe = 0;
+    const unsigned long long pk0 = GEMM_T();
+#endif
 
     for (;;) {
         const int tn = next_valid(t + stride);
@@ -454,6 +466,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
             const float* cst = lds + stage * BUF;
             float* nst = lds + (stage ^ 1) * BUF;
             const bool last = kt + 1 == KT;
+#ifdef MEL_GEMM_PROF
+            const unsigned long long q0 = GEMM_T();
+#endif
             // one K step ahead of its first load, resolve the next tile's pointers (row-gather indices)
             if (has_next && (kt + 2 == KT || (KT == 1 && last))) setup(nxt, tn);
             const bool fill = !last || has_next;
@@ -469,6 +484,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
 #pragma unroll
                 for (int i = 0; i < W_CHUNKS; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(nxt.w_src[i]);
             }
+#ifdef MEL_GEMM_PROF
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long q1 = GEMM_T();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 a[TM], b[TN];
@@ -486,6 +506,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
             }
+#ifdef MEL_GEMM_PROF
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 0" ::"v"(acc[0][0][0]));      // the MFMA chain has retired
+            const unsigned long long q2 = GEMM_T();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (fill) {
 #pragma unroll
                 for (int i = 0; i < A_CHUNKS; ++i)
@@ -494,9 +520,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
                 for (int i = 0; i < W_CHUNKS; ++i)
                     *reinterpret_cast<f32x4*>(nst + BM * GEMM_LDS_STRIDE + st_off + i * (T / 8) * GEMM_LDS_STRIDE) = w_reg[i];
             }
+#ifdef MEL_GEMM_PROF
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long q3 = GEMM_T();
+#endif
             __syncthreads();
+#ifdef MEL_GEMM_PROF
+            const unsigned long long q4 = GEMM_T();
+            pf += q1 - q0, pm += q2 - q1, pw += q3 - q2, pb += q4 - q3;
+#endif
             stage ^= 1;
         }
+#ifdef MEL_GEMM_PROF
+        const unsigned long long e0 = GEMM_T();
+#endif
         {   // epilogue of the finished tile (the next tile's first K step already sits in LDS)
             const GemmArgs& g = batch.p[cur.pi];
 #pragma unroll
@@ -506,10 +543,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
                     store_block_f32(g, acc[i][j], cur.m0 + wm * 32 * TM + i * 32 + 4 * h, cur.n0 + wn * 32 * TN + j * 32 + r,
                                     cur.M);
         }
+#ifdef MEL_GEMM_PROF
+        pe += GEMM_T() - e0;
+#endif
         if (!has_next) break;
         cur = nxt;
         t = tn;
     }
+#ifdef MEL_GEMM_PROF
+    if (tid == 0 && TAG == MEL_GEMM_PROF && MODE == GEMM_MODE_PLAIN) {
+        atomicAdd(&g_gemm_prof[0], pf), atomicAdd(&g_gemm_prof[1], pm), atomicAdd(&g_gemm_prof[2], pw);
+        atomicAdd(&g_gemm_prof[3], pb), atomicAdd(&g_gemm_prof[4], pe), atomicAdd(&g_gemm_prof[5], GEMM_T() - pk0);
+        atomicAdd(&g_gemm_prof[6], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
