@@ -264,3 +264,17 @@ def test_construct_time_samplings_line_up_with_the_wrapped_oracle():
     assert wrapped.env.origin_agent == episodes[2].origin and wrapped.env.interested == episodes[2].interested
     wrapped.reset()
     assert wrapped.env.origin_agent == episodes[3].origin and wrapped.env.interested == episodes[3].interested
+
+
+def test_bench_cpu_baseline_variants_run():
+    """bench.py's CPU baseline legs (the oracle on the host cores): single process and env-worker processes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    one = bench.cpu_baseline(12, budget_s=1.0, envs=4)
+    assert one["kind"] == "port" and one["value"] > 0 and one["value_bs1"] > 0 and one["cores"] >= 1
+    sub = bench.cpu_baseline_subproc(12, budget_s=1.0, workers=2, envs_per_worker=2)
+    assert sub["value"] > 0 and sub["envs"] == 4
+    fl = bench.stage_flops((10.0, 20.0, 5.0))
+    assert fl["conv2_lin"] == 2.0 * 15 * 512 * 512 and fl["conv1_lin"] == 2.0 * 30 * 512 * 128
