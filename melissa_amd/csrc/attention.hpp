@@ -265,8 +265,19 @@ __device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
 //              logits, l_dgn.py:135), sources = its closed neighbourhood inside U1 -> x_3
 // (256, 2): with the bare bound the register allocator aims at 6 waves per SIMD and SPILLS the source-row
 // pointers (88 B of scratch in front of every row load); two blocks per CU lets it keep ~100 VGPRs.
+#ifdef MEL_ATT_PROF
+// Tuning builds (-DMEL_ATT_PROF=<MODE>): cycles per wave of the rows kernel with that MODE (0 = conv1, 2 = conv2) in
+// [0] prologue (row count, att / bias), [1] descriptor load, [2] attend_target (row loads + scores + softmax + sum),
+// [3] stores, [4] whole wave, [5] waves counted, [6] rows processed
+__device__ unsigned long long g_att_prof[8];
+#endif
+
 template <int VPL, int MODE, int KIND, bool BF>
 __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
+#ifdef MEL_ATT_PROF
+    const unsigned long long p0 = __builtin_readcyclecounter();
+    unsigned long long pd = 0, pa = 0, ps = 0, prows = 0;
+#endif
     const int lane = lane_id();
     const int rows = min(*a.rows_dev, a.rows_cap);
     const Vec<VPL> att = load_vec_or_zero<VPL>(a.att, lane);
@@ -277,6 +288,10 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
     // (block id % 8 under round-robin dispatch; the grid is a multiple of 8) walks a CONTIGUOUS range of rows
     // and the shared rows hit in that XCD's L2 instead of being fetched by all eight (measured before the
     // remap: 54 % L2 misses in this kernel).
+#ifdef MEL_ATT_PROF
+    asm volatile("s_nop 0" ::"v"(att.v[0]), "v"(bias.v[0]), "s"(rows));
+    const unsigned long long p1 = __builtin_readcyclecounter();
+#endif
     const int per_xcd = gridDim.x >> 3;
     const int vblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int rows_pad = ((rows + 4 * (int)gridDim.x - 1) / (4 * (int)gridDim.x)) * (4 * (int)gridDim.x);
@@ -284,8 +299,19 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
     for (int i = (vblock % per_xcd) * 4 + (threadIdx.x >> 6); i < span; i += per_xcd * 4) {
         const int r = (blockIdx.x & 7) * span + i;
         if (r >= rows) continue;
+#ifdef MEL_ATT_PROF
+        const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
         const TargetDesc d = a.desc[r];          // one 32-byte record: no chain of dependent index loads
+#ifdef MEL_ATT_PROF
+        asm volatile("s_nop 0" ::"s"(d.sources), "s"(d.soff));
+        const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
         const Vec<VPL> o = attend_target<VPL, KIND, BF>(a, (size_t)r, d.sources, d.smask, d.soff, att, bias, lane);
+#ifdef MEL_ATT_PROF
+        asm volatile("s_nop 0" ::"v"(o.v[0]));
+        const unsigned long long q2 = __builtin_readcyclecounter();
+#endif
         if constexpr (MODE == ATT_SINGLE) {
             store_row<VPL, BF>(a.xcat, (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
         } else {
@@ -305,7 +331,18 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
                 }
             }
         }
+#ifdef MEL_ATT_PROF
+        const unsigned long long q3 = __builtin_readcyclecounter();
+        pd += q1 - q0, pa += q2 - q1, ps += q3 - q2, prows += 1;
+#endif
     }
+#ifdef MEL_ATT_PROF
+    if (threadIdx.x == 0 && (blockIdx.x & 31) == 0 && MODE == MEL_ATT_PROF && !BF) {      // a sample: few atomics
+        atomicAdd(&g_att_prof[0], p1 - p0), atomicAdd(&g_att_prof[1], pd), atomicAdd(&g_att_prof[2], pa);
+        atomicAdd(&g_att_prof[3], ps), atomicAdd(&g_att_prof[4], __builtin_readcyclecounter() - p0);
+        atomicAdd(&g_att_prof[5], 1ull), atomicAdd(&g_att_prof[6], prows);
+    }
+#endif
 }
 
 // ATT_POOL (HL-DGN): one workgroup per env (every env has exactly N targets, so this is balanced):

@@ -701,6 +701,15 @@ void mel_debug_gemm_prof(unsigned long long* out8) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
 }
 #endif
+#ifdef MEL_ATT_PROF
+// tuning builds only: read and reset the attention rows kernel's cycle counters (tools/att_prof.py)
+void mel_debug_att_prof(unsigned long long* out8) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_att_prof), 8 * sizeof(unsigned long long));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_att_prof), z, sizeof(z));
+}
+#endif
 size_t mel_abi_sizeof(int32_t which) {
     switch (which) {
         case 0: return sizeof(mel_linear);
