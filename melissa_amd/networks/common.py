@@ -378,3 +378,60 @@ def unpack(obs: torch.Tensor, input_dim: int, n: int):
     node = obs[:, :-1].reshape(bs, n, input_dim + 3).float()
     g = obs[:, -1].clamp(0, n - 1).long()
     return node[:, :, :2], node[:, :, 2:2 + input_dim], node[:, :, -1:], g
+
+
+# ---------------------------------------------------------------------------------------------------
+# shared body of the three drop-in networks (they differ in the conv type, the pooling and two details of how the
+# reference's constructors treat ``dueling_param``)
+# ---------------------------------------------------------------------------------------------------
+class GraphQNetwork(HipForwardMixin, nn.Module):
+    _RETURNS_STATE = True          # forward returns (logits, state); L-DGN returns (logits, None) (l_dgn.py:151)
+
+    def _setup(self, input_dim, hidden_dim, output_dim, num_heads, agents_num, device, edge_attributes, backend):
+        self.device, self.backend = device, backend                     # backend: "auto" | "hip" | "torch"
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.num_heads, self.agents_num = num_heads, agents_num
+        self.edge_attributes = edge_attributes                          # computed-but-unused in the reference
+        self.encoder = MLP(input_dim=input_dim, hidden_sizes=[hidden_dim], output_dim=hidden_dim, device=device)
+
+    def _build_heads(self, latent_dim: int, dueling_param, honour_output_dim_key: bool = False):
+        """Dueling Q / V MLPs (the caller's kwargs dicts are MUTATED, as in the reference) or one ``out_linear``."""
+        self.use_dueling = dueling_param is not None
+        if not self.use_dueling:
+            self.out_linear = nn.Linear(latent_dim, self.output_dim)
+            return
+        q_kwargs, v_kwargs = dueling_param
+        q_out, v_out = self.output_dim, 1
+        if honour_output_dim_key:                                       # only LDGNNetwork pops it (l_dgn.py:71-84)
+            q_out, v_out = q_kwargs.pop("output_dim", q_out), v_kwargs.pop("output_dim", v_out)
+        q_kwargs.update({"input_dim": latent_dim, "output_dim": q_out, "device": self.device})
+        v_kwargs.update({"input_dim": latent_dim, "output_dim": v_out, "device": self.device})
+        self.Q, self.V = MLP(**q_kwargs), MLP(**v_kwargs)
+        self.output_dim = q_out
+
+    def _head(self, latent: torch.Tensor) -> torch.Tensor:
+        if self.use_dueling:
+            q, v = self.Q.model(latent), self.V.model(latent)
+            return q - q.mean(dim=1, keepdim=True) + v
+        return self.out_linear(latent)
+
+    def forward(self, obs, state=None, info={}):
+        logits = self._dispatch(self._prepare_obs(obs))
+        return logits, (state if self._RETURNS_STATE else None)
+
+    def _two_conv_torch_forward(self, obs: torch.Tensor) -> torch.Tensor:
+        """encoder -> conv1 -> dm mask -> conv2 with the controlling agent's rows gathered after each stage
+        (l_dgn.py:117-149, dgn_r.py:95-127) in differentiable ops; on ROCm devices the convolutions' attention runs in
+        the HIP kernels of csrc/grad.hip."""
+        obs = obs.to(self.device)
+        pos, feats, dm, g = unpack(obs, self.input_dim, self.agents_num)
+        bs, n = pos.shape[:2]
+        hip = use_hip_autograd(self, obs)
+        adj = learn_adjacency(obs, pos, n, self.input_dim, hip)
+        x = F.relu(self.encoder.model(feats.reshape(bs * n, -1)))
+        gi = torch.arange(bs, device=x.device) * n + g
+        x_1 = x[gi]
+        x = conv_relu(self.conv1, x, adj, n, hip)
+        x_2 = x[gi]
+        x = conv_relu(self.conv2, x * dm.reshape(bs * n, 1), adj, n, hip)
+        return self._head(torch.cat([x_1, x_2, x[gi]], dim=1))
