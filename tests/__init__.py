@@ -1,0 +1,1 @@
+"""Parity tests (``-m gpu`` through the C ABI) and CPU-side oracle / host-logic tests."""
