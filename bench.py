@@ -297,7 +297,8 @@ def main():
         cnt = (C.c_int64 * _lib.N_STAGES)()
         lib.mel_prof_read(prof, ms, cnt)
         lib.mel_prof_destroy(prof)
-        stages = {name: (ms[i] / cnt[i] * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}   # us
+        # us per STEP: a stage that brackets several launches per step (the heads' two hidden layers) is their sum
+        stages = {name: (ms[i] / args.steps * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}
         mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model == "l_dgn"
                     else (0.0, float(args.envs * args.nodes), float(args.envs)))
         if args.model == "hl_dgn":

@@ -72,7 +72,7 @@ static void gemm_launch_ring_t(const GemmArgs* gs, int count, hipStream_t s) {
     long tiles = 0;
     for (int i = 0; i < count; ++i) {
         batch.p[i] = gs[i];
-        tiles += ((long)((gs[i].M + B - 1) / B) * (gs[i].N / B) + 7) & ~7L;
+        tiles += ((long)((gs[i].M + B - 1) / B) * (gs[i].N / B) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
     }
     long grid = 256L * (TS == 1 ? 2 : 1);
     if (grid > tiles) grid = tiles;
@@ -212,6 +212,10 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
         gemm_launch_persistent<2, 2, 1, 2>(&g, 1, mode, stream);
         return check_launch(what);
     }
+    if (force_tile == 31 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0) {      // specialised-wavefront kernel, 64 x 64
+        gemm_launch_ring_t<0>(&g, 1, stream);
+        return check_launch(what);
+    }
     if (force_tile == 1 || (force_tile >= 2 && g.N % 128 == 0)) {
         switch (force_tile) {
             case 1: gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream); break;     //  64 x  64, 4 waves
@@ -239,6 +243,48 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
         gemm_launch_t<2, 2, 2, 2>(&g, 1, mode, stream);
     else
         gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream);
+    return check_launch(what);
+}
+
+// Skinny long-K problems (the dueling heads' first layer: 4 820 x 256 outputs over K = 1 152 are 304 tiles of 64 x 64 for
+// 512 workgroup slots, one 36-step tile each and half of the slots empty): cut K into S chunks so that the work items
+// fill the chip evenly.  Chunk s writes raw partial products to plane s of `parts`; splitk_finish_kernel sums the planes
+// in order and applies scale / bias / ReLU.  Model of the launch in K steps of one workgroup: (workgroups sharing a
+// CU) x (items per workgroup) x (steps per item + 2 for the hand-over), over the 512 slots of the ring kernel.
+int choose_ksplit(const GemmArgs& g, long m_hint, int max_split) {
+    if (g.bf16 || g.split || g.K < 768 || g.ldy % 4 || g.N % 64 || g.K % GEMM_BK) return 1;
+    const long tiles = ((m_hint + 63) / 64) * (g.N / 64);
+    const int KT = g.K / GEMM_BK;
+    int best = 1;
+    long best_cost = 0;
+    for (int S = 1; S <= max_split; ++S) {
+        if (KT % S) continue;
+        const long items = tiles * S, slots = items < 512 ? items : 512;
+        const long cost = ((slots + 255) / 256) * ((items + slots - 1) / slots) * (KT / S + 2);
+        if (S == 1 || cost < best_cost) best = S, best_cost = cost;
+    }
+    return best;
+}
+
+mel_status launch_gemm_splitk(const GemmArgs& g, int S, float* parts, long part_stride, hipStream_t stream,
+                              const char* what, long m_hint, int tag, bool finish = true) {
+    if (g.M <= 0) return MEL_OK;
+    if (mel_status st = check_gemm_shape(g, what)) return st;
+    if (S < 2 || (g.K / GEMM_BK) % S || g.bf16 || g.split || !parts || part_stride < (long)g.M * g.N)
+        return fail(MEL_ERR_INVALID_ARG, "%s: bad split-K request (S=%d)", what, S);
+    GemmArgs p = g;
+    p.Y = parts, p.ldy = g.N, p.ksplit = S, p.part_stride = part_stride;
+    switch (tag) {
+        case 3: gemm_launch_ring_t<3>(&p, 1, stream); break;
+        default: gemm_launch_ring_t<0>(&p, 1, stream); break;
+    }
+    if (mel_status st = check_launch(what)) return st;
+    if (!finish) return MEL_OK;               // the caller's next launch sums the planes itself
+    SplitKFinish f{parts, part_stride, S, g.N, g.M, g.M_dev, g.bias, g.bias_hi, g.split_n, g.rscale, g.relu, g.Y, g.ldy};
+    if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
+    long blocks = (m_hint * (g.N / 4) + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, stream, f);
     return check_launch(what);
 }
 
@@ -315,10 +361,12 @@ struct FwdLayout {
     float* xr2;
     float* xcat;    // head input [rows, latent]
     float* hq[2];   // head hidden ping-pong [rows, qw + vw]
+    float* hpart;   // split-K partial planes of the heads' first layer [HEAD_KSPLIT_MAX][rows, qw + vw] (fp32 path)
     float* minmax;
     uint16_t* wb;   // bf16 copies of the projection weights (bf16 feature path)
     size_t wb_elems;
     size_t bytes;
+    size_t rows_cap;
 };
 
 // the weight matrices the dense projections read, in launch order; fp32 path: the nn.Parameter storages
@@ -354,6 +402,8 @@ static size_t projection_elems(const mel_weights* w) {
     for_each_projection(w, pw, [&](const mel_linear& l, const float**) { total += (lin_elems(l) + 7) & ~(size_t)7; });
     return total;
 }
+
+constexpr int HEAD_KSPLIT_MAX = 4;
 
 static int head_hidden_width(const mel_mlp& m) {
     int w = 0;
@@ -402,11 +452,13 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
+    L.hpart = c.take<float>(w->precision == MEL_PREC_F32 && hw > 0 ? (size_t)HEAD_KSPLIT_MAX * R * hw : 8);
     L.minmax = c.take<float>(64);
     L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
                  : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
     L.wb = c.take<uint16_t>(L.wb_elems ? L.wb_elems : 8);
     L.bytes = c.off;
+    L.rows_cap = R;
     return L;
 }
 
@@ -527,6 +579,35 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
     const float* in_q = L.xcat;
     const float* in_v = L.xcat;
     int ld_q = w->q_head.layer[0].in_dim, ld_v = ld_q;
+    // The standard heads (hidden [128, 128] for Q and V, l_dgn.py:66-84 with the CLI defaults) on the fp32 path: split-K
+    // first layer, then everything after its partial products in ONE launch (head_finish_kernel).
+    if (!bf && !sp && nl == 3 && w->dueling && w->v_head.n_layers == 3) {
+        const mel_linear& q = w->q_head.layer[0];
+        const mel_linear& v = w->v_head.layer[0];
+        const mel_linear& q1 = w->q_head.layer[1];
+        const mel_linear& v1 = w->v_head.layer[1];
+        GemmArgs g;
+        g.A = in_q, g.lda = ld_q, g.W = pw.q[0], g.W_hi = pw.v[0], g.split_n = q.out_dim;
+        g.Y = L.hq[0], g.ldy = 2 * HF_W, g.M = (int)rows, g.M_dev = rows_dev, g.N = 2 * HF_W, g.K = q.in_dim;
+        const long hint = rows_hint < 0 || rows_hint > rows ? rows : rows_hint;
+        const int S = choose_ksplit(g, hint, HEAD_KSPLIT_MAX);
+        if (S > 1 && q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W && q1.out_dim == HF_W &&
+            v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= 8 && w->v_head.layer[2].out_dim == 1) {
+            const long ps = (long)L.rows_cap * 2 * HF_W;
+            {
+                StageScope t(MEL_STAGE_HEAD_HIDDEN, s);
+                if (mel_status st = launch_gemm_splitk(g, S, L.hpart, ps, s, "head hidden (Q|V), split-K", hint, 3, false)) return st;
+            }
+            StageScope t(MEL_STAGE_HEAD_TAIL, s);
+            HeadFinish f{L.hpart, ps, S, (int)rows, rows_dev, q.bias, v.bias, q1, v1, w->q_head.layer[2], w->v_head.layer[2],
+                         logits, select ? *select : mel_select{}};
+            long blocks = (hint + hint / 4 + 63) / 32;
+            const long need = (rows + 31) / 32;
+            blocks = blocks > need ? need : blocks < 1 ? 1 : blocks;
+            hipLaunchKernelGGL(head_finish_kernel, dim3((int)blocks), dim3(512), 0, s, f);
+            return check_launch("head finish");
+        }
+    }
     for (int i = 0; i + 1 < nl; ++i) {
         StageScope t(MEL_STAGE_HEAD_HIDDEN, s);
         const mel_linear& q = w->q_head.layer[i];
@@ -539,7 +620,11 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             g.W = pw.q[i], g.W_hi = pw.v[i], g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
             g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
             g.bf16 = bf, g.split = sp, g.y_f32 = (i + 2 == nl);       // the tail reads fp32
-            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint, 0, 3)) return st;
+            const int S = choose_ksplit(g, rows_hint < 0 || rows_hint > rows ? rows : rows_hint, HEAD_KSPLIT_MAX);
+            if (S > 1) {
+                if (mel_status st = launch_gemm_splitk(g, S, L.hpart, (long)L.rows_cap * ldo, s, "head hidden (Q|V), split-K",
+                                                       rows_hint, 3)) return st;
+            } else if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V)", rows_hint, 0, 3)) return st;
         } else {
             GemmArgs g[2];
             // element offset of the V half inside a row: in elements of the buffer's type (bf16 halves the bytes)
@@ -844,7 +929,7 @@ mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, cons
 
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream) {
-    if (!A || !W || !Y || M < 0 || M > (1ll << 30) || lda < K || ldy < N)
+    if (!A || !W || !Y || M < 0 || M > (1ll << 30) || (lda < K && lda != 0) || ldy < N)
         return fail(MEL_ERR_INVALID_ARG, "bad gemm arguments");
     clear_stale_error();
     GemmArgs g;

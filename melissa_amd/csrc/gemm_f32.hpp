@@ -64,6 +64,10 @@ struct GemmArgs {
     int y_f32 = 0;
     // split path (gemm_split.hpp): A / Y fp32 as usual, W / W_hi point at [N][3][K] bf16 planes (hi | mid | lo)
     int split = 0;
+    // split-K (specialised-wavefront kernel only): the K range is cut into `ksplit` equal chunks, chunk s writes its RAW
+    // partial products (no scale / bias / ReLU) to Y + s * part_stride; splitk_finish_kernel sums the planes in order
+    int ksplit = 0;
+    long part_stride = 0;
 };
 
 // Up to four independent problems in one launch (e.g. conv.lin_l + conv.lin_r, or the Q and V hidden layers):

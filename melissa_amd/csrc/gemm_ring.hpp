@@ -41,7 +41,7 @@ __device__ __forceinline__ int ring_out_index(int row, int col) {
 
 #ifdef MEL_RING_PROF
 // Tuning builds (-DMEL_RING_PROF=<TAG> [-DMEL_RING_ALL]): cycles a consumer wave 0 of the launches tagged TAG spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
-// [4] workgroups counted; loaders: [5] issue, [6] wait_landed, [7] barrier
+// [4] workgroups counted; loader wave 4: [5] issue (+ epilogue of a finished tile), [6] wait_landed, [7] barrier
 __device__ unsigned long long g_ring_prof[8];
 #define RING_T() __builtin_readcyclecounter()
 #endif
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
         if (i < batch.count) {
             const GemmArgs& q = batch.p[i];
             rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
-            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN);
+            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN) * (q.ksplit > 1 ? q.ksplit : 1);
         }
         pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
     }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
         return total;
     };
     struct Tile {
-        int pi, m0, n0, M, KT;
+        int pi, m0, n0, M, KT, ks, k0;           // ks / k0: split-K chunk of this work item and its first K column
     };
     auto tile_of = [&](int t) {
         int pi = 0;
@@ -96,7 +96,11 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
             const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
             wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
         }
-        return Tile{pi, (wg / nbn) * BM, (wg % nbn) * BN, rows[pi], g.K / GEMM_BK};
+        // split-K: the work items of one row panel are ordered chunk-major, so the nbn items that share an A chunk are
+        // neighbours
+        const int S = g.ksplit > 1 ? g.ksplit : 1;
+        const int ks = (wg / nbn) % S, KT = g.K / GEMM_BK / S;
+        return Tile{pi, (wg / (nbn * S)) * BM, (wg % nbn) * BN, rows[pi], KT, ks, ks * KT * GEMM_BK};
     };
 
     const int first = next_valid(blockIdx.x);
@@ -125,12 +129,12 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
                 if (row < BM) {
                     const int gr = min(c.m0 + row, c.M - 1);                      // clamped, never predicated
                     const int ar = g.arow ? g.arow[gr] : gr;
-                    src[i] = g.A + (size_t)ar * g.lda + chunk * 4;
+                    src[i] = g.A + (size_t)ar * g.lda + c.k0 + chunk * 4;
                 } else {
                     const int n = c.n0 + (row - BM);
                     const float* base = (g.W_hi && n >= g.split_n) ? g.W_hi + (size_t)(n - g.split_n) * g.K
                                                                     : g.W + (size_t)n * g.K;
-                    src[i] = base + chunk * 4;
+                    src[i] = base + c.k0 + chunk * 4;
                 }
             }
         };
@@ -146,6 +150,16 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
             const float* __restrict__ rs = g.rscale;
             const int ldy = g.ldy, relu = g.relu;
             const int col = (lane & 15) * 4, n = cc.n0 + col;
+            if (g.ksplit > 1) {                // split-K: raw partial products into this chunk's plane
+                float* __restrict__ P = Y + (size_t)cc.ks * g.part_stride;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = lw * 16 + i * 4 + (lane >> 4), m = cc.m0 + row;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(outbuf + ring_out_index(row, col));
+                    if (m < cc.M) *reinterpret_cast<f32x4*>(P + (size_t)m * ldy + n) = a;
+                }
+                return;
+            }
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (g.bias_hi && n >= g.split_n) bias4 = *reinterpret_cast<const f32x4*>(g.bias_hi + (n - g.split_n));
             else if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
         }
 #ifdef MEL_RING_PROF
         if (wid == 4 && lane == 0 && TAG == MEL_RING_PROF) {
-            atomicAdd(&g_ring_prof[7], lb);
+            atomicAdd(&g_ring_prof[5], li), atomicAdd(&g_ring_prof[6], lw_), atomicAdd(&g_ring_prof[7], lb);
         }
 #endif
         return;
@@ -310,9 +324,46 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
     if (wid == 0 && lane == 0 && TAG == MEL_RING_PROF) {
         atomicAdd(&g_ring_prof[0], cm_), atomicAdd(&g_ring_prof[1], cb), atomicAdd(&g_ring_prof[2], ce);
         atomicAdd(&g_ring_prof[3], RING_T() - tk0), atomicAdd(&g_ring_prof[4], 1ull);
-        atomicAdd(&g_ring_prof[5], ep_load), atomicAdd(&g_ring_prof[6], ep_store);          // (overrides the loader slots)
+        (void)ep_load, (void)ep_store;
     }
 #endif
+}
+
+// split-K finish: Y = act(scale * (P_0 + P_1 + ... in plane order) + bias) over the row range the launch covered; the
+// fixed summation order keeps the result independent of how the work items were scheduled.
+struct SplitKFinish {
+    const float* parts;
+    long part_stride;
+    int S, N, M;
+    const int32_t* M_dev;
+    const float* bias;
+    const float* bias_hi;
+    int split_n;
+    const float* rscale;
+    int relu;
+    float* Y;
+    int ldy;
+};
+__global__ __launch_bounds__(256) void splitk_finish_kernel(SplitKFinish f) {
+    const int rows = f.M_dev ? min(*f.M_dev, f.M) : f.M;
+    const int n4 = f.N >> 2;
+    const long total = (long)rows * n4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+        const float* p = f.parts + (size_t)m * f.N + n;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+        for (int s = 1; s < f.S; ++s) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p + (size_t)s * f.part_stride);
+            acc = f32x4{acc[0] + q[0], acc[1] + q[1], acc[2] + q[2], acc[3] + q[3]};
+        }
+        const float sc = f.rscale ? f.rscale[m] : 1.f;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (f.bias_hi && n >= f.split_n) b = *reinterpret_cast<const f32x4*>(f.bias_hi + (n - f.split_n));
+        else if (f.bias) b = *reinterpret_cast<const f32x4*>(f.bias + n);
+        f32x4 o = {acc[0] * sc + b[0], acc[1] * sc + b[1], acc[2] * sc + b[2], acc[3] * sc + b[3]};
+        if (f.relu) o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+        *reinterpret_cast<f32x4*>(f.Y + (size_t)m * f.ldy + n) = o;
+    }
 }
 
 }  // namespace mel

@@ -99,6 +99,32 @@ def test_matches_oracle_on_random_batches(model, n, bs):
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("hidden", [(64,), (128, 64), (128, 128, 64), (128, 128)])
+@pytest.mark.parametrize("bs", [40, 700])
+def test_ldgn_head_shapes(hidden, bs):
+    """Dueling heads other than the CLI default [128, 128] (tianshou MLP, any depth): the first layer still goes through the
+    split-K launch + plane sum, the rest through the generic hidden-layer launches instead of the fused finish kernel;
+    (128, 128) is the fused case at the same inputs."""
+    from melissa_amd.networks import LDGNNetwork
+    from oracle import net_oracle as no
+    n = 20
+    rng = np.random.RandomState(7 + bs)
+    obs = np.zeros((bs, 8 * n + 1), dtype=np.float32)
+    m = obs[:, :-1].reshape(bs, n, 8)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2:7] = rng.randint(0, 3, size=(bs, n, 5))
+    m[:, :, 7] = 1.0
+    obs[:, -1] = rng.randint(0, n, size=bs)
+    sd = no.init_weights("l_dgn", seed=5, dueling_hidden=hidden, random_conv_bias=True)
+    net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=({"hidden_sizes": list(hidden)}, {"hidden_sizes": list(hidden)}),
+                      device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        got = net(obs)[0].cpu().numpy()
+        want = no.ldgn_forward(sd, obs, n).numpy()
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
 def test_full_size_linearity_property():
     """BASELINE size (N=50, 1024 rows): property checks that need no oracle run - row independence
     (a row's logits do not depend on its batch mates / position) and determinism."""

@@ -18,6 +18,6 @@ fn(buf)
 v = list(buf)
 wgs = v[4]
 print("workgroups counted", wgs, "per step", wgs / N)
-names = ["consumer MFMA section", "consumer step barrier", "consumer epilogue", "consumer whole kernel", "-", "epilogue: operand loads", "epilogue: stores issued", "loader barrier"]
+names = ["consumer MFMA section", "consumer step barrier", "consumer epilogue", "consumer whole kernel", "-", "loader issue", "loader wait_landed", "loader barrier"]
 for i in (0, 1, 2, 3, 5, 6, 7):
     print(f"{names[i]:26s} {v[i] / wgs:12.0f} ticks per workgroup-launch  ({100.0 * v[i] / max(v[3], 1):5.1f} % of consumer kernel time)")
