@@ -929,7 +929,7 @@ mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, cons
 
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream) {
-    if (!A || !W || !Y || M < 0 || M > (1ll << 30) || (lda < K && lda != 0) || ldy < N)
+    if (!A || !W || !Y || M < 0 || M > (1ll << 30) || lda < K || ldy < N)
         return fail(MEL_ERR_INVALID_ARG, "bad gemm arguments");
     clear_stale_error();
     GemmArgs g;
