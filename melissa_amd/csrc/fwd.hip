@@ -64,19 +64,18 @@ static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipS
 }
 
 // specialised-wavefront kernel (gemm_ring.hpp): two 8-wave workgroups per CU
-template <int TAG, int TS = 1>
+template <int TAG>
 static void gemm_launch_ring_t(const GemmArgs* gs, int count, hipStream_t s) {
-    constexpr int B = 64 * TS;
     GemmBatch batch{};
     batch.count = count;
     long tiles = 0;
     for (int i = 0; i < count; ++i) {
         batch.p[i] = gs[i];
-        tiles += ((long)((gs[i].M + B - 1) / B) * (gs[i].N / B) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
+        tiles += ((long)((gs[i].M + 63) / 64) * (gs[i].N / 64) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
     }
-    long grid = 256L * (TS == 1 ? 2 : 1);
+    long grid = 256L * 2;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL((gemm_f32_ring_kernel<TAG, TS>), dim3((int)grid), dim3(512), 0, s, batch);
+    hipLaunchKernelGGL((gemm_f32_ring_kernel<TAG>), dim3((int)grid), dim3(512), 0, s, batch);
 }
 
 // ragged 64 x 64 launches of the round step, named per call site
@@ -88,17 +87,6 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
     for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024 && gs[i].ldy % 4 == 0;
 #ifdef MEL_RING_ALL
     long_k = true;                              // tuning builds: every ragged launch through the ring kernel
-#endif
-#ifdef MEL_RING_BIG
-    {   // tuning builds: 128 x 128 ring tiles for the conv launches
-        bool n128 = true;
-        for (int i = 0; i < count; ++i) n128 = n128 && gs[i].N % 128 == 0;
-        if (n128 && (tag == 1 || tag == 2)) {
-            if (tag == 1) gemm_launch_ring_t<1, 2>(gs, count, s);
-            else gemm_launch_ring_t<2, 2>(gs, count, s);
-            return;
-        }
-    }
 #endif
     if (long_k) {
         switch (tag) {
@@ -212,7 +200,7 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
         gemm_launch_persistent<2, 2, 1, 2>(&g, 1, mode, stream);
         return check_launch(what);
     }
-    if (force_tile == 31 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0) {      // specialised-wavefront kernel, 64 x 64
+    if (force_tile == 31 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 64) {      // specialised-wavefront kernel, 64 x 64
         gemm_launch_ring_t<0>(&g, 1, stream);
         return check_launch(what);
     }
@@ -258,7 +246,7 @@ int choose_ksplit(const GemmArgs& g, long m_hint, int max_split) {
     int best = 1;
     long best_cost = 0;
     for (int S = 1; S <= max_split; ++S) {
-        if (KT % S) continue;
+        if (KT % S || KT / S < 2) continue;        // (the hand-over buffer needs two steps between tiles)
         const long items = tiles * S, slots = items < 512 ? items : 512;
         const long cost = ((slots + 255) / 256) * ((items + slots - 1) / slots) * (KT / S + 2);
         if (S == 1 || cost < best_cost) best = S, best_cost = cost;

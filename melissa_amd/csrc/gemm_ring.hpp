@@ -1,16 +1,19 @@
 // fp32-MFMA row GEMM with SPECIALISED wavefronts (PLAIN problems, 64 x 64 tiles, persistent):
 //
-//   waves 0-3  consumers  2 x 2 wavefronts of 32 x 32: ds_read_b128 fragments + v_mfma_f32_32x32x2_f32; a finished
-//                         accumulator tile is dropped into an LDS hand-over buffer (16 ds_write_b32) and the wave goes on
+//   waves 0-3  consumers  2 x 2 wavefronts of 32 x 32: v_mfma_f32_32x32x2_f32 on the fragments read (ds_read_b128) one
+//                         step earlier, while the reads of the next step are in flight; a finished accumulator tile is
+//                         dropped into an LDS hand-over buffer (16 ds_write_b32) and the wave goes on
 //   waves 4-7  loaders    global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write), running
-//                         THREE K steps ahead of the arithmetic through a four-stage LDS ring; they also run the
+//                         FOUR K steps ahead of the arithmetic through a four-stage LDS ring; they also run the
 //                         epilogue (scale, bias, ReLU, 16-byte row stores) of the tile the consumers just finished
 //
 // Why: in the one-role kernels (gemm_f32.hpp) the workgroups that share a CU move through load -> LDS -> MFMA phases
 // in step, so the data-movement skeleton and the MFMA chain of a launch add up instead of overlapping (DESIGN.md,
 // "GEMM status": conv2 38 us + 51.5 us ~ the measured 87).  Here the two never wait for each other inside a K step:
 // a consumer wave's step is 8 fragment reads + 16 MFMAs and nothing else, a loader wave's step is "issue the DMAs of
-// step g+3, make sure step g+1 has landed", and one s_barrier per step hands a stage over in each direction.
+// step g+4, make sure step g+2 has landed", and one s_barrier per step hands a stage over in each direction.
+// Long-K skinny problems can be cut along K (GemmArgs::ksplit): a work item is then (tile, K chunk) and writes raw
+// partial products to its chunk's plane; splitk_finish_kernel (or the heads' fused finish) sums the planes in order.
 //
 // LDS stage = 64 A rows + 64 W rows x 128 B, unpadded (a DMA instruction writes 1 KiB linearly); bank conflicts of the
 // fragment reads are removed by XOR-ing the 16-byte chunk index with (row >> 1) & 7 on the DMA's SOURCE side and on
@@ -20,14 +23,15 @@
 
 namespace mel {
 
-// TS = 1: 64 x 64 tiles, four-stage ring, loaders three K steps ahead, two workgroups per CU, loader-side epilogue.
-// TS = 2: 128 x 128 tiles (each consumer wave 64 x 64 = four accumulator blocks: half the operand traffic per FLOP),
-//         three-stage ring of 32 KiB stages, loaders two steps ahead, one workgroup per CU, consumer-side epilogue.
-template <int TS>
+// 64 x 64 tiles, four-stage ring; the loaders run FOUR K steps ahead: a consumer wave holds the fragments of the step it
+// multiplies in registers (read from LDS one step earlier, while the previous step's MFMAs ran), so a stage is free again as
+// soon as the step BEFORE the one it feeds has been multiplied.  Barrier B(g) therefore means: every consumer has the
+// fragments of step g + 1 in registers and has issued the MFMAs of step g; the loaders guarantee before B(g) that step
+// g + 2 has landed.
 struct RingCfg {
-    static constexpr int BM = 64 * TS, BN = 64 * TS;
-    static constexpr int STAGES = TS == 1 ? 4 : 3;
-    static constexpr int AHEAD = STAGES - 1;                       // K steps the loaders run ahead (< STAGES)
+    static constexpr int BM = 64, BN = 64;
+    static constexpr int STAGES = 4;
+    static constexpr int AHEAD = STAGES;                           // K steps the loaders run ahead
     static constexpr int STAGE_FLOATS = (BM + BN) * GEMM_BK;
     static constexpr int PPW = (BM + BN) / 8 / 4;                  // 1 KiB DMA pieces per loader wave per stage
 };
@@ -38,6 +42,11 @@ constexpr int RING_OUT_STRIDE = 64;                // floats per row of the accu
 __device__ __forceinline__ int ring_out_index(int row, int col) {
     return row * RING_OUT_STRIDE + ((((col >> 2) ^ ((row & 3) << 1))) << 2) + (col & 3);
 }
+__device__ __forceinline__ void wait_lds_done() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 
 #ifdef MEL_RING_PROF
 // Tuning builds (-DMEL_RING_PROF=<TAG> [-DMEL_RING_ALL]): cycles a consumer wave 0 of the launches tagged TAG spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
@@ -46,14 +55,14 @@ __device__ unsigned long long g_ring_prof[8];
 #define RING_T() __builtin_readcyclecounter()
 #endif
 
-template <int TAG = 0, int TS = 1>
-__global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(GemmBatch batch) {
-    using Cfg = RingCfg<TS>;
+template <int TAG = 0>
+__global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) {
+    using Cfg = RingCfg;
     constexpr int BM = Cfg::BM, BN = Cfg::BN;
     constexpr int RING_STAGES = Cfg::STAGES, RING_AHEAD = Cfg::AHEAD, RING_STAGE_FLOATS = Cfg::STAGE_FLOATS, RING_PPW = Cfg::PPW;
     __shared__ __attribute__((aligned(16))) float lds[RING_STAGES * RING_STAGE_FLOATS];
-    // finished accumulator tile, handed from the consumers to the loaders (TS = 1 only)
-    __shared__ __attribute__((aligned(16))) float outbuf[TS == 1 ? 64 * RING_OUT_STRIDE : 4];
+    // finished accumulator tile, handed from the consumers to the loaders
+    __shared__ __attribute__((aligned(16))) float outbuf[64 * RING_OUT_STRIDE];
 
     // tile bookkeeping (wave-uniform), identical for every wave of the workgroup
     int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
@@ -190,15 +199,16 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
             }
         };
         auto wait_landed = [&](int g) {        // every DMA of steps <= g has landed (in-order completion)
-            const int after = issued - (g + 1);    // steps issued later than g: 0 .. RING_AHEAD - 1
-            if (RING_AHEAD >= 3 && after >= 2) wait_vmcnt_le<2 * RING_PPW>();
+            const int after = issued - (g + 1);    // steps issued later than g
+            if (after >= 2) wait_vmcnt_le<2 * RING_PPW>();
             else if (after >= 1) wait_vmcnt_le<RING_PPW>();
             else wait_vmcnt_le<0>();
         };
 #pragma unroll
         for (int i = 0; i < RING_AHEAD; ++i) issue();
-        wait_landed(0);
-        __builtin_amdgcn_s_barrier();          // B(-1): step 0 is in its stage
+        wait_landed(1);
+        __builtin_amdgcn_s_barrier();          // B(-2): steps 0 and 1 are in their stages
+        __builtin_amdgcn_s_barrier();          // B(-1): the consumers hold step 0's fragments
 #ifdef MEL_RING_PROF
         unsigned long long li = 0, lw_ = 0, lb = 0;
 #endif
@@ -206,11 +216,11 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
 #ifdef MEL_RING_PROF
             const unsigned long long t0 = RING_T();
 #endif
-            issue();                           // step g + 3 -> the stage step g - 1 was read from (released by B(g-1))
+            issue();                           // step g + 4 -> the stage of step g (in registers since B(g-1))
 #ifdef MEL_RING_PROF
             const unsigned long long t1 = RING_T();
 #endif
-            if (g + 1 < steps_total) wait_landed(g + 1);
+            if (g + 2 < steps_total) wait_landed(g + 2);
 #ifdef MEL_RING_PROF
             const unsigned long long t2 = RING_T();
 #endif
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
             const unsigned long long t3 = RING_T();
             li += t1 - t0, lw_ += t2 - t1, lb += t3 - t2;
 #endif
-            if (TS == 1 && ++ckt == cc.KT) {   // step g completed a tile: its accumulators are in outbuf (written before B(g))
+            if (++ckt == cc.KT) {              // step g completed a tile: its accumulators are in outbuf (written before B(g))
                 write_out();                   // done before this wave reaches B(g+1); the consumers' next hand-over is >= 2 steps away
                 ct = next_valid(ct + stride);
                 ckt = 0;
@@ -237,76 +247,53 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
     // ---------------------------------------------------------------------- consumers
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
-    int a_row[TS], a_x[TS], w_row[TS], w_x[TS];          // fragment rows of this lane (floats into a stage) + their swizzle
+    const int ar = wm * 32 + r, wr = BM + wn * 32 + r;
+    const int a_row = ar * GEMM_BK, a_x = (ar >> 1) & 7;          // fragment rows of this lane (floats into a stage) + swizzle
+    const int w_row = wr * GEMM_BK, w_x = (wr >> 1) & 7;
+    auto read_frags = [&](int g, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
+        const float* cur = lds + (g % RING_STAGES) * RING_STAGE_FLOATS;
 #pragma unroll
-    for (int i = 0; i < TS; ++i) {
-        const int ar = wm * 32 * TS + i * 32 + r, wr = BM + wn * 32 * TS + i * 32 + r;
-        a_row[i] = ar * GEMM_BK, a_x[i] = (ar >> 1) & 7;
-        w_row[i] = wr * GEMM_BK, w_x[i] = (wr >> 1) & 7;
-    }
+        for (int q = 0; q < 4; ++q) {
+            fa[q] = *reinterpret_cast<const f32x4*>(cur + a_row + (((2 * q + h) ^ a_x) << 2));
+            fb[q] = *reinterpret_cast<const f32x4*>(cur + w_row + (((2 * q + h) ^ w_x) << 2));
+        }
+    };
 
     int t = first;
     Tile c = tile_of(t);
     int kt = 0;
-    f32x16 acc[TS][TS];
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < TS; ++i)
-#pragma unroll
-        for (int j = 0; j < TS; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #ifdef MEL_RING_PROF
-    unsigned long long cm_ = 0, cb = 0, ce = 0, ep_load = 0, ep_store = 0;
+    unsigned long long cm_ = 0, cb = 0, ce = 0;
     const unsigned long long tk0 = RING_T();
 #endif
+    f32x4 fa[2][4], fb[2][4];                  // fragments of the step being multiplied / of the next one
+    __builtin_amdgcn_s_barrier();              // B(-2)
+    read_frags(0, fa[0], fb[0]);
+    wait_lds_done();
     __builtin_amdgcn_s_barrier();              // B(-1)
-    for (int g = 0; g < steps_total; ++g) {
+    auto step = [&](int g, f32x4 (&ca)[4], f32x4 (&cbf)[4], f32x4 (&na)[4], f32x4 (&nb)[4]) {
 #ifdef MEL_RING_PROF
         const unsigned long long t0 = RING_T();
 #endif
-        const float* cur = lds + (g % RING_STAGES) * RING_STAGE_FLOATS;
+        if (g + 1 < steps_total) read_frags(g + 1, na, nb);       // landed before B(g-1); overlaps the MFMAs below
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 a[TS], b[TS];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int i = 0; i < TS; ++i) {
-                a[i] = *reinterpret_cast<const f32x4*>(cur + a_row[i] + (((2 * q + h) ^ a_x[i]) << 2));
-                b[i] = *reinterpret_cast<const f32x4*>(cur + w_row[i] + (((2 * q + h) ^ w_x[i]) << 2));
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < TS; ++i)
-#pragma unroll
-                    for (int j = 0; j < TS; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
-        }
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[q][kk], cbf[q][kk], acc, 0, 0, 0);
 #ifdef MEL_RING_PROF
-        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));    // the MFMA chain has retired
+        asm volatile("s_nop 0" ::"v"(acc[0]));    // the MFMA chain has retired
         const unsigned long long t1 = RING_T();
 #endif
-        if (++kt == c.KT) {                    // tile complete: epilogue (the loaders are already three steps into the next)
-            if constexpr (TS == 1) {
-                // hand the accumulator block to the loaders (C/D layout: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*h)
+        if (++kt == c.KT) {                    // tile complete: hand the accumulator block to the loaders
+            // (C/D layout: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*h)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    outbuf[ring_out_index(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, wn * 32 + r)] = acc[0][0][e];
-                    acc[0][0][e] = 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < TS; ++i)
-#pragma unroll
-                    for (int j = 0; j < TS; ++j) {
-                        store_block_f32(batch.p[c.pi], acc[i][j], c.m0 + wm * 32 * TS + i * 32 + 4 * h,
-                                        c.n0 + wn * 32 * TS + j * 32 + r, c.M);
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-                    }
+            for (int e = 0; e < 16; ++e) {
+                outbuf[ring_out_index(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h, wn * 32 + r)] = acc[e];
+                acc[e] = 0.f;
             }
-#ifdef MEL_RING_PROF
-            ep_store += RING_T() - t1;
-#endif
             t = next_valid(t + stride);
             kt = 0;
             if (t < total) c = tile_of(t);
@@ -314,17 +301,23 @@ __global__ __launch_bounds__(512, TS == 1 ? 2 : 1) void gemm_f32_ring_kernel(Gem
 #ifdef MEL_RING_PROF
         const unsigned long long t2 = RING_T();
 #endif
-        __builtin_amdgcn_s_barrier();          // B(g): every fragment read of step g is done (they fed MFMAs above)
+        wait_lds_done();                       // the next step's fragments are in registers, the hand-over is written
+        __builtin_amdgcn_s_barrier();          // B(g)
 #ifdef MEL_RING_PROF
         const unsigned long long t3 = RING_T();
         cm_ += t1 - t0, ce += t2 - t1, cb += t3 - t2;
 #endif
+    };
+    int g = 0;
+    for (; g + 1 < steps_total; g += 2) {
+        step(g, fa[0], fb[0], fa[1], fb[1]);
+        step(g + 1, fa[1], fb[1], fa[0], fb[0]);
     }
+    if (g < steps_total) step(g, fa[0], fb[0], fa[1], fb[1]);
 #ifdef MEL_RING_PROF
     if (wid == 0 && lane == 0 && TAG == MEL_RING_PROF) {
         atomicAdd(&g_ring_prof[0], cm_), atomicAdd(&g_ring_prof[1], cb), atomicAdd(&g_ring_prof[2], ce);
         atomicAdd(&g_ring_prof[3], RING_T() - tk0), atomicAdd(&g_ring_prof[4], 1ull);
-        (void)ep_load, (void)ep_store;
     }
 #endif
 }
