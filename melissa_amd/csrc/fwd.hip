@@ -440,7 +440,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
-    L.hpart = c.take<float>(w->precision == MEL_PREC_F32 && hw > 0 ? (size_t)HEAD_KSPLIT_MAX * R * hw : 8);
+    L.hpart = c.take<float>(hw > 0 ? (size_t)(w->precision == MEL_PREC_F32 ? HEAD_KSPLIT_MAX : 1) * R * hw : 8);
     L.minmax = c.take<float>(64);
     L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
                  : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
@@ -567,24 +567,30 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
     const float* in_q = L.xcat;
     const float* in_v = L.xcat;
     int ld_q = w->q_head.layer[0].in_dim, ld_v = ld_q;
-    // The standard heads (hidden [128, 128] for Q and V, l_dgn.py:66-84 with the CLI defaults) on the fp32 path: split-K
-    // first layer, then everything after its partial products in ONE launch (head_finish_kernel).
-    if (!bf && !sp && nl == 3 && w->dueling && w->v_head.n_layers == 3) {
+    // The standard heads (hidden [128, 128] for Q and V, l_dgn.py:66-84 with the CLI defaults): the first layer's RAW
+    // products go to fp32 planes (fp32 path: split-K, one plane per K chunk; bf16 / split paths: one plane), then
+    // everything after them runs in ONE launch (head_finish_kernel: plane sum + bias + ReLU, hidden layer 1 in fp32 MFMA,
+    // last layer, dueling combine, selection).
+    if (nl == 3 && w->dueling && w->v_head.n_layers == 3) {
         const mel_linear& q = w->q_head.layer[0];
         const mel_linear& v = w->v_head.layer[0];
         const mel_linear& q1 = w->q_head.layer[1];
         const mel_linear& v1 = w->v_head.layer[1];
         GemmArgs g;
         g.A = in_q, g.lda = ld_q, g.W = pw.q[0], g.W_hi = pw.v[0], g.split_n = q.out_dim;
-        g.Y = L.hq[0], g.ldy = 2 * HF_W, g.M = (int)rows, g.M_dev = rows_dev, g.N = 2 * HF_W, g.K = q.in_dim;
+        g.Y = L.hpart, g.ldy = 2 * HF_W, g.M = (int)rows, g.M_dev = rows_dev, g.N = 2 * HF_W, g.K = q.in_dim;
+        g.bf16 = bf, g.split = sp, g.y_f32 = 1;
         const long hint = rows_hint < 0 || rows_hint > rows ? rows : rows_hint;
         const int S = choose_ksplit(g, hint, HEAD_KSPLIT_MAX);
-        if (S > 1 && q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W && q1.out_dim == HF_W &&
-            v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= 8 && w->v_head.layer[2].out_dim == 1) {
+        if ((S > 1 || bf || sp) && q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W &&
+            q1.out_dim == HF_W && v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= 8 &&
+            w->v_head.layer[2].out_dim == 1 && q1.weight && v1.weight) {
             const long ps = (long)L.rows_cap * 2 * HF_W;
             {
                 StageScope t(MEL_STAGE_HEAD_HIDDEN, s);
-                if (mel_status st = launch_gemm_splitk(g, S, L.hpart, ps, s, "head hidden (Q|V), split-K", hint, 3, false)) return st;
+                if (S > 1) {
+                    if (mel_status st = launch_gemm_splitk(g, S, L.hpart, ps, s, "head hidden (Q|V), split-K", hint, 3, false)) return st;
+                } else if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "head hidden (Q|V), raw", hint, 0, 3)) return st;
             }
             StageScope t(MEL_STAGE_HEAD_TAIL, s);
             HeadFinish f{L.hpart, ps, S, (int)rows, rows_dev, q.bias, v.bias, q1, v1, w->q_head.layer[2], w->v_head.layer[2],
