@@ -77,7 +77,8 @@ def test_hldgn_matches_golden(path, agg):
 
 
 @pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])
-@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (1, 5), (7, 1), (5, 9000)])   # 9000 > 8192: separate scan launch
+# 9000 > 8192: separate scan launch; 2048 / 4800 / 9000 rows: the heads' first layer is cut along K in 2 / 3 / 4
+@pytest.mark.parametrize("n,bs", [(20, 256), (50, 300), (64, 37), (1, 5), (7, 1), (5, 9000), (5, 2048), (5, 4800)])
 def test_matches_oracle_on_random_batches(model, n, bs):
     """Fresh seeded inputs at sizes the oracle finishes in seconds (incl. ragged / tiny / max-N cases)."""
     from oracle import net_oracle as no
