@@ -64,18 +64,19 @@ static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipS
 }
 
 // specialised-wavefront kernel (gemm_ring.hpp): two 8-wave workgroups per CU
-template <int TAG>
+template <int TAG, int BK = GEMM_BK, int WMC = 2>
 static void gemm_launch_ring_t(const GemmArgs* gs, int count, hipStream_t s) {
+    using Cfg = RingCfg<BK, WMC>;
     GemmBatch batch{};
     batch.count = count;
     long tiles = 0;
     for (int i = 0; i < count; ++i) {
         batch.p[i] = gs[i];
-        tiles += ((long)((gs[i].M + 63) / 64) * (gs[i].N / 64) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
+        tiles += ((long)((gs[i].M + Cfg::BM - 1) / Cfg::BM) * (gs[i].N / 64) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
     }
-    long grid = 256L * 2;
+    long grid = 256L * Cfg::WG_PER_CU;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL((gemm_f32_ring_kernel<TAG>), dim3((int)grid), dim3(512), 0, s, batch);
+    hipLaunchKernelGGL((gemm_f32_ring_kernel<TAG, BK, WMC>), dim3((int)grid), dim3(Cfg::THREADS), 0, s, batch);
 }
 
 // ragged 64 x 64 launches of the round step, named per call site
@@ -87,6 +88,20 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
     for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024 && gs[i].ldy % 4 == 0;
 #ifdef MEL_RING_ALL
     long_k = true;                              // tuning builds: every ragged launch through the ring kernel
+#endif
+#ifdef MEL_RING_WIDE
+    {
+        bool ok = true;
+        for (int i = 0; i < count; ++i) ok = ok && gs[i].ldy % 4 == 0 && gs[i].K >= 64 && gs[i].ksplit <= 1;
+        if (ok && tag >= 1 && tag <= 3 && ((MEL_RING_WIDE >> (tag - 1)) & 1)) {
+            switch (tag) {
+                case 1: gemm_launch_ring_t<1, 16, 4>(gs, count, s); break;
+                case 2: gemm_launch_ring_t<2, 16, 4>(gs, count, s); break;
+                default: gemm_launch_ring_t<3, 16, 4>(gs, count, s); break;
+            }
+            return;
+        }
+    }
 #endif
     if (long_k) {
         switch (tag) {
@@ -198,6 +213,14 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     }
     if (enc_wide) {
         gemm_launch_persistent<2, 2, 1, 2>(&g, 1, mode, stream);
+        return check_launch(what);
+    }
+    if (force_tile == 33 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 32) {      // ring kernel, 128 x 64, K step 16
+        gemm_launch_ring_t<0, 16, 4>(&g, 1, stream);
+        return check_launch(what);
+    }
+    if (force_tile == 32 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 32) {      // ring kernel, K step 16, 3 per CU
+        gemm_launch_ring_t<0, 16>(&g, 1, stream);
         return check_launch(what);
     }
     if (force_tile == 31 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 64) {      // specialised-wavefront kernel, 64 x 64

@@ -28,12 +28,25 @@ namespace mel {
 // soon as the step BEFORE the one it feeds has been multiplied.  Barrier B(g) therefore means: every consumer has the
 // fragments of step g + 1 in registers and has issued the MFMAs of step g; the loaders guarantee before B(g) that step
 // g + 2 has landed.
+// BK = 32: 16 KiB stages, 80 KiB of LDS per workgroup, two workgroups per CU.  BK = 16: 8 KiB stages (rows of 64 B,
+// sixteen rows per 1 KiB DMA piece), 48 KiB per workgroup, THREE workgroups per CU - a third unsynchronised consumer wave
+// per SIMD to fill the matrix pipe while the other two sit at their step barriers or hand a tile over - at the price of a
+// barrier every 8 instead of 16 MFMAs.
+// WMC = 4: 128 x 64 tiles, eight consumer waves (4 x 2 of 32 x 32) + four loaders = 768 threads; with BK = 16 a stage is
+// 12 KiB and the hand-over buffer 32 KiB: 80 KiB, two workgroups per CU = four consumer waves per SIMD and a quarter
+// less operand traffic per FLOP than the 64 x 64 tile.
+template <int BK, int WMC = 2>
 struct RingCfg {
-    static constexpr int BM = 64, BN = 64;
+    static constexpr int BM = 32 * WMC, BN = 64;
+    static constexpr int CONSUMERS = 2 * WMC, THREADS = 64 * (CONSUMERS + 4);
     static constexpr int STAGES = 4;
     static constexpr int AHEAD = STAGES;                           // K steps the loaders run ahead
-    static constexpr int STAGE_FLOATS = (BM + BN) * GEMM_BK;
-    static constexpr int PPW = (BM + BN) / 8 / 4;                  // 1 KiB DMA pieces per loader wave per stage
+    static constexpr int STAGE_FLOATS = (BM + BN) * BK;
+    static constexpr int CPR = BK / 4;                             // 16-byte chunks per row
+    static constexpr int RP = 256 / BK;                            // rows per 1 KiB DMA piece
+    static constexpr int SWZ_SHIFT = BK == 32 ? 1 : 2;             // chunk c of row r sits in slot c ^ ((r >> SHIFT) & (CPR - 1))
+    static constexpr int PPW = (BM + BN) / RP / 4;                 // DMA pieces per loader wave per stage
+    static constexpr int WG_PER_CU = (BK == 32 || WMC == 4) ? 2 : 3;
 };
 constexpr int RING_OUT_STRIDE = 64;                // floats per row of the accumulator hand-over buffer (unpadded: 64 KiB
                                                    // ring + 16 KiB = exactly half of the CU's LDS); 16-byte chunk c of row
@@ -55,14 +68,15 @@ __device__ unsigned long long g_ring_prof[8];
 #define RING_T() __builtin_readcyclecounter()
 #endif
 
-template <int TAG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) {
-    using Cfg = RingCfg;
-    constexpr int BM = Cfg::BM, BN = Cfg::BN;
+template <int TAG = 0, int BK = GEMM_BK, int WMC = 2>
+__global__ __launch_bounds__((RingCfg<BK, WMC>::THREADS), (RingCfg<BK, WMC>::WG_PER_CU)) void gemm_f32_ring_kernel(GemmBatch batch) {
+    using Cfg = RingCfg<BK, WMC>;
+    constexpr int NC = Cfg::CONSUMERS;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, CPR = Cfg::CPR, RP = Cfg::RP, SWZ = Cfg::SWZ_SHIFT;
     constexpr int RING_STAGES = Cfg::STAGES, RING_AHEAD = Cfg::AHEAD, RING_STAGE_FLOATS = Cfg::STAGE_FLOATS, RING_PPW = Cfg::PPW;
     __shared__ __attribute__((aligned(16))) float lds[RING_STAGES * RING_STAGE_FLOATS];
     // finished accumulator tile, handed from the consumers to the loaders
-    __shared__ __attribute__((aligned(16))) float outbuf[64 * RING_OUT_STRIDE];
+    __shared__ __attribute__((aligned(16))) float outbuf[BM * RING_OUT_STRIDE];
 
     // tile bookkeeping (wave-uniform), identical for every wave of the workgroup
     int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
@@ -108,8 +122,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
         // split-K: the work items of one row panel are ordered chunk-major, so the nbn items that share an A chunk are
         // neighbours
         const int S = g.ksplit > 1 ? g.ksplit : 1;
-        const int ks = (wg / nbn) % S, KT = g.K / GEMM_BK / S;
-        return Tile{pi, (wg / (nbn * S)) * BM, (wg % nbn) * BN, rows[pi], KT, ks, ks * KT * GEMM_BK};
+        const int ks = (wg / nbn) % S, KT = g.K / BK / S;
+        return Tile{pi, (wg / (nbn * S)) * BM, (wg % nbn) * BN, rows[pi], KT, ks, ks * KT * BK};
     };
 
     const int first = next_valid(blockIdx.x);
@@ -122,9 +136,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    if (wid >= 4) {
+    if (wid >= NC) {
         // ------------------------------------------------------------------ loaders
-        const int lw = wid - 4;
+        const int lw = wid - NC;
         const float* src[RING_PPW];            // this lane's 16-byte chunk of each piece, K step 0 of the loader's tile
         int lt = first, lkt = 0, lKT = 0;
         auto load_tile = [&](int t) {
@@ -133,8 +147,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             lKT = c.KT;
 #pragma unroll
             for (int i = 0; i < RING_PPW; ++i) {
-                const int row = (lw * RING_PPW + i) * 8 + (lane >> 3);            // tile-local: A rows then W rows
-                const int chunk = (lane & 7) ^ ((row >> 1) & 7);                  // source chunk of this LDS slot
+                const int row = (lw * RING_PPW + i) * RP + lane / CPR;            // tile-local: A rows then W rows
+                const int chunk = (lane % CPR) ^ ((row >> SWZ) & (CPR - 1));      // source chunk of this LDS slot
                 if (row < BM) {
                     const int gr = min(c.m0 + row, c.M - 1);                      // clamped, never predicated
                     const int ar = g.arow ? g.arow[gr] : gr;
@@ -153,7 +167,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
         int ct = first;
         Tile cc = tile_of(first);
         int ckt = 0;
-        auto write_out = [&]() {               // epilogue of tile cc from the hand-over buffer: 16 rows per loader wave
+        constexpr int WR = BM / 16;            // row groups of four per loader wave (BM / 4 rows each)
+        auto write_out = [&]() {               // epilogue of tile cc from the hand-over buffer: BM / 4 rows per loader wave
             const GemmArgs& g = batch.p[cc.pi];
             float* __restrict__ Y = g.Y;
             const float* __restrict__ rs = g.rscale;
@@ -162,8 +177,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             if (g.ksplit > 1) {                // split-K: raw partial products into this chunk's plane
                 float* __restrict__ P = Y + (size_t)cc.ks * g.part_stride;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = lw * 16 + i * 4 + (lane >> 4), m = cc.m0 + row;
+                for (int i = 0; i < WR; ++i) {
+                    const int row = lw * (BM / 4) + i * 4 + (lane >> 4), m = cc.m0 + row;
                     const f32x4 a = *reinterpret_cast<const f32x4*>(outbuf + ring_out_index(row, col));
                     if (m < cc.M) *reinterpret_cast<f32x4*>(P + (size_t)m * ldy + n) = a;
                 }
@@ -172,12 +187,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (g.bias_hi && n >= g.split_n) bias4 = *reinterpret_cast<const f32x4*>(g.bias_hi + (n - g.split_n));
             else if (g.bias) bias4 = *reinterpret_cast<const f32x4*>(g.bias + n);
-            float sc[4];
+            float sc[WR];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sc[i] = rs ? rs[min(cc.m0 + lw * 16 + i * 4 + (lane >> 4), cc.M - 1)] : 1.f;
+            for (int i = 0; i < WR; ++i) sc[i] = rs ? rs[min(cc.m0 + lw * (BM / 4) + i * 4 + (lane >> 4), cc.M - 1)] : 1.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = lw * 16 + i * 4 + (lane >> 4);
+            for (int i = 0; i < WR; ++i) {
+                const int row = lw * (BM / 4) + i * 4 + (lane >> 4);
                 const f32x4 a = *reinterpret_cast<const f32x4*>(outbuf + ring_out_index(row, col));
                 f32x4 o = {a[0] * sc[i] + bias4[0], a[1] * sc[i] + bias4[1], a[2] * sc[i] + bias4[2], a[3] * sc[i] + bias4[3]};
                 if (relu) o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             float* stage = lds + (issued % RING_STAGES) * RING_STAGE_FLOATS;
 #pragma unroll
             for (int i = 0; i < RING_PPW; ++i)
-                dma_16B_to_lds(src[i] + lkt * GEMM_BK, stage + (lw * RING_PPW + i) * 8 * GEMM_BK);
+                dma_16B_to_lds(src[i] + lkt * BK, stage + (lw * RING_PPW + i) * 256);
             ++issued;
             if (++lkt == lKT) {
                 lt = next_valid(lt + stride);
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
             }
         }
 #ifdef MEL_RING_PROF
-        if (wid == 4 && lane == 0 && TAG == MEL_RING_PROF) {
+        if (wid == NC && lane == 0 && TAG == MEL_RING_PROF) {
             atomicAdd(&g_ring_prof[5], li), atomicAdd(&g_ring_prof[6], lw_), atomicAdd(&g_ring_prof[7], lb);
         }
 #endif
@@ -248,12 +263,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
     const int wm = wid >> 1, wn = wid & 1;
     const int r = lane & 31, h = lane >> 5;
     const int ar = wm * 32 + r, wr = BM + wn * 32 + r;
-    const int a_row = ar * GEMM_BK, a_x = (ar >> 1) & 7;          // fragment rows of this lane (floats into a stage) + swizzle
-    const int w_row = wr * GEMM_BK, w_x = (wr >> 1) & 7;
-    auto read_frags = [&](int g, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
+    const int a_row = ar * BK, a_x = (ar >> SWZ) & (CPR - 1);     // fragment rows of this lane (floats into a stage) + swizzle
+    const int w_row = wr * BK, w_x = (wr >> SWZ) & (CPR - 1);
+    constexpr int NQ = BK / 8;                                    // fragment pairs (four MFMAs each) per K step
+    auto read_frags = [&](int g, f32x4 (&fa)[NQ], f32x4 (&fb)[NQ]) {
         const float* cur = lds + (g % RING_STAGES) * RING_STAGE_FLOATS;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             fa[q] = *reinterpret_cast<const f32x4*>(cur + a_row + (((2 * q + h) ^ a_x) << 2));
             fb[q] = *reinterpret_cast<const f32x4*>(cur + w_row + (((2 * q + h) ^ w_x) << 2));
         }
@@ -269,18 +285,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_ring_kernel(GemmBatch batch) 
     unsigned long long cm_ = 0, cb = 0, ce = 0;
     const unsigned long long tk0 = RING_T();
 #endif
-    f32x4 fa[2][4], fb[2][4];                  // fragments of the step being multiplied / of the next one
+    f32x4 fa[2][NQ], fb[2][NQ];                // fragments of the step being multiplied / of the next one
     __builtin_amdgcn_s_barrier();              // B(-2)
     read_frags(0, fa[0], fb[0]);
     wait_lds_done();
     __builtin_amdgcn_s_barrier();              // B(-1)
-    auto step = [&](int g, f32x4 (&ca)[4], f32x4 (&cbf)[4], f32x4 (&na)[4], f32x4 (&nb)[4]) {
+    auto step = [&](int g, f32x4 (&ca)[NQ], f32x4 (&cbf)[NQ], f32x4 (&na)[NQ], f32x4 (&nb)[NQ]) {
 #ifdef MEL_RING_PROF
         const unsigned long long t0 = RING_T();
 #endif
         if (g + 1 < steps_total) read_frags(g + 1, na, nb);       // landed before B(g-1); overlaps the MFMAs below
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[q][kk], cbf[q][kk], acc, 0, 0, 0);
 #ifdef MEL_RING_PROF

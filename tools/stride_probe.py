@@ -19,7 +19,7 @@ for M, N, Ks in ((4820, 256, (1152,)), (1024, 256, (1152,)), (15468, 512, (512,)
             b = torch.randn(N, device=dev)
             Y = torch.empty(M, N, device=dev)
             line = f"M={M} N={N} K={K} lda={K + pad}:"
-            for t in (11, 31):
+            for t in (11, 32, 33):
                 call = lambda: lib.mel_gemm_f32(A.data_ptr(), K + pad, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
                                                 _lib.current_stream_ptr())
                 _lib.check(call())
