@@ -115,9 +115,10 @@ def load(build_if_missing: bool = True):
     if build_if_missing and _build.is_stale():
         try:
             _build.build_library()
-        except Exception as e:  # keep a usable prebuilt .so if the toolchain is missing
+        except FileNotFoundError as e:  # no hipcc on this machine: keep a prebuilt .so if there is one
             if not os.path.exists(path):
                 raise RuntimeError(f"libmelissa_hip.so is missing and could not be built: {e}") from e
+        # (a compile ERROR propagates: running a stale library against changed sources would hide it)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not found: the HIP hot path is not built (run python -m melissa_amd.build)")
     lib = C.CDLL(path)

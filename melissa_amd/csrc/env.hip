@@ -448,6 +448,15 @@ struct RoundArgs {
     mel_round_replay replay;       // optional (capacity 0 = off)
 };
 
+#ifdef MEL_ENV_PROF
+// tuning builds: cycles a sample of the env wavefronts spends in [0] state load, [1] the round loop, [2] the env_step call
+// that runs the world step, [3] the other env_step calls, [4] env_observe, [5] episode end (log + reset), [6] state store;
+// [7] wavefronts sampled, [8] loop iterations                                               (tools/env_prof.py)
+__device__ unsigned long long g_env_prof[9];
+#define ENV_T() __builtin_readcyclecounter()
+#define ENV_MARK(x) asm volatile("s_nop 0" ::"s"(x))
+#endif
+
 __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= a.env.n_envs) return;
@@ -455,7 +464,16 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     const int n = a.env.n_nodes;
     if (a.round_counter && b == 0 && lane == 0 && !a.first) atomicAdd(a.round_counter, 1u);
     Env s;
+#ifdef MEL_ENV_PROF
+    unsigned long long pw = 0, ps = 0, po = 0, pr = 0, pit = 0;
+    const unsigned long long p0 = ENV_T();
+#endif
     env_load(a.env, b, lane, s);
+#ifdef MEL_ENV_PROF
+    ENV_MARK(s.sel);
+    asm volatile("s_nop 0" ::"v"(s.px), "v"(s.steps));
+    const unsigned long long p1 = ENV_T();
+#endif
     const mel_env_obs none{};
     if (!a.first) {
         const uint64_t live_in = uniform_u64(a.live[b]);
@@ -496,8 +514,21 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
                 }
                 action = lane_i32(my_action, sel);
             }
+#ifdef MEL_ENV_PROF
+            const unsigned long long q0 = ENV_T();
+#endif
             const bool world = env_step(a.env, a.pool, b, s, action, lane, rec_next);
+#ifdef MEL_ENV_PROF
+            ENV_MARK(s.sel);
+            asm volatile("s_nop 0" ::"v"(s.reward), "v"(s.one_hop));
+            const unsigned long long q1 = ENV_T();
+#endif
             const int r = env_observe(a.env, b, s, none, 0, lane);
+#ifdef MEL_ENV_PROF
+            ENV_MARK(r);
+            const unsigned long long q2 = ENV_T();
+            (world ? pw : ps) += q1 - q0, po += q2 - q1, pit += 1;
+#endif
             if (world && rec_next) {          // the world step just ran: rewards / terminations of this round
                 if (lane < n) a.replay.rew[rec * n + lane] = ((live_in >> lane) & 1ull) ? (float)s.reward : 0.f;
                 if (lane == 0) a.replay.done[rec] = s.terminated & live_in;
@@ -505,18 +536,38 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
             if (r & 1) s.done_count += 1;
             if ((r & 1) && ((r & 2) || s.done_count == n)) {                  // episode over
                 s.episodes_done += 1;
+#ifdef MEL_ENV_PROF
+                const unsigned long long r0 = ENV_T();
+#endif
                 log_episode(a.env, b, s, lane);
                 const int ep = uniform_i32(a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)]);
                 env_reset(a.env, a.pool, b, s, ep, 0, lane);
                 env_observe(a.env, b, s, none, 0, lane);
+#ifdef MEL_ENV_PROF
+                ENV_MARK(s.sel);
+                asm volatile("s_nop 0" ::"v"(s.px), "v"(s.one_hop));
+                pr += ENV_T() - r0;
+#endif
                 break;
             }
             if (r & 4) break;                                                  // world step done: new round
         }
     }
+#ifdef MEL_ENV_PROF
+    const unsigned long long p2 = ENV_T();
+#endif
     // agents that will act in the coming round: exactly the selector's active set (selector.py:22-34,43-44)
     if (lane == 0) a.live[b] = s.sel_active;
     env_store(a.env, b, lane, s);
+#ifdef MEL_ENV_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long p3 = ENV_T();
+    if (lane == 0 && (b & 7) == 0 && !a.first) {
+        atomicAdd(&g_env_prof[0], p1 - p0), atomicAdd(&g_env_prof[1], p2 - p1), atomicAdd(&g_env_prof[2], pw);
+        atomicAdd(&g_env_prof[3], ps), atomicAdd(&g_env_prof[4], po), atomicAdd(&g_env_prof[5], pr);
+        atomicAdd(&g_env_prof[6], p3 - p2), atomicAdd(&g_env_prof[7], 1ull), atomicAdd(&g_env_prof[8], pit);
+    }
+#endif
 }
 
 struct StepArgs {
@@ -702,6 +753,17 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_round");
+}
+
+// tuning builds only (-DMEL_ENV_PROF): read and reset the round kernel's cycle counters (tools/env_prof.py)
+void mel_debug_env_prof(unsigned long long* out9) {
+#ifdef MEL_ENV_PROF
+    (void)hipMemcpyFromSymbol(out9, HIP_SYMBOL(g_env_prof), 9 * sizeof(unsigned long long));
+    unsigned long long z[9] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_env_prof), z, sizeof(z));
+#else
+    for (int i = 0; i < 9; ++i) out9[i] = 0;
+#endif
 }
 
 mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n, const mel_env_obs* out,
