@@ -147,7 +147,7 @@ static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_
     long tiles = 0;
     for (int i = 0; i < count; ++i) {
         batch.p[i] = gs[i];
-        tiles += ((long)((gs[i].M + BM - 1) / BM) * (gs[i].N / BN) + 7) & ~7L;
+        tiles += ((long)((gs[i].M + BM - 1) / BM) * (gs[i].N / BN) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
     }
     long grid = 256L * PER_CU;
     if (grid > tiles) grid = tiles;
@@ -263,8 +263,21 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
 // in order and applies scale / bias / ReLU.  Model of the launch in K steps of one workgroup: (workgroups sharing a
 // CU) x (items per workgroup) x (steps per item + 2 for the hand-over), over the 512 slots of the ring kernel.
 int choose_ksplit(const GemmArgs& g, long m_hint, int max_split) {
-    if (g.bf16 || g.split || g.K < 768 || g.ldy % 4 || g.N % 64 || g.K % GEMM_BK) return 1;
+    if (g.split || g.K < 768 || g.ldy % 4 || g.N % 64 || g.K % GEMB_BK) return 1;
     const long tiles = ((m_hint + 63) / 64) * (g.N / 64);
+    if (g.bf16) {
+        // bf16 one-role kernel: 1 024 slots, latency bound at these sizes - items per slot x (steps per item + 2)
+        const int KT = g.K / GEMB_BK;
+        int best = 1;
+        long best_cost = 0;
+        for (int S = 1; S <= max_split; ++S) {
+            if (KT % S || KT / S < 2) continue;
+            const long items = tiles * S, slots = items < 1024 ? items : 1024;
+            const long cost = ((items + slots - 1) / slots) * (KT / S + 2);
+            if (S == 1 || cost < best_cost) best = S, best_cost = cost;
+        }
+        return best;
+    }
     const int KT = g.K / GEMM_BK;
     int best = 1;
     long best_cost = 0;
@@ -281,13 +294,18 @@ mel_status launch_gemm_splitk(const GemmArgs& g, int S, float* parts, long part_
                               const char* what, long m_hint, int tag, bool finish = true) {
     if (g.M <= 0) return MEL_OK;
     if (mel_status st = check_gemm_shape(g, what)) return st;
-    if (S < 2 || (g.K / GEMM_BK) % S || g.bf16 || g.split || !parts || part_stride < (long)g.M * g.N)
+    if (S < 2 || (g.K / (g.bf16 ? GEMB_BK : GEMM_BK)) % S || g.split || !parts || part_stride < (long)g.M * g.N)
         return fail(MEL_ERR_INVALID_ARG, "%s: bad split-K request (S=%d)", what, S);
     GemmArgs p = g;
     p.Y = parts, p.ldy = g.N, p.ksplit = S, p.part_stride = part_stride;
-    switch (tag) {
-        case 3: gemm_launch_ring_t<3>(&p, 1, stream); break;
-        default: gemm_launch_ring_t<0>(&p, 1, stream); break;
+    if (g.bf16) {
+        p.y_f32 = 1;
+        gemm_launch_bf16<2, 2, 1, 1>(&p, 1, GEMM_MODE_PLAIN, stream);
+    } else {
+        switch (tag) {
+            case 3: gemm_launch_ring_t<3>(&p, 1, stream); break;
+            default: gemm_launch_ring_t<0>(&p, 1, stream); break;
+        }
     }
     if (mel_status st = check_launch(what)) return st;
     if (!finish) return MEL_OK;               // the caller's next launch sums the planes itself
@@ -463,7 +481,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
-    L.hpart = c.take<float>(hw > 0 ? (size_t)(w->precision == MEL_PREC_F32 ? HEAD_KSPLIT_MAX : 1) * R * hw : 8);
+    L.hpart = c.take<float>(hw > 0 ? (size_t)(w->precision == MEL_PREC_F32_SPLIT ? 1 : HEAD_KSPLIT_MAX) * R * hw : 8);
     L.minmax = c.take<float>(64);
     L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
                  : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
@@ -637,7 +655,8 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             g.W = pw.q[i], g.W_hi = pw.v[i], g.bias = q.bias, g.bias_hi = v.bias, g.split_n = q.out_dim;
             g.Y = out, g.ldy = ldo, g.M = (int)rows, g.M_dev = rows_dev, g.N = ldo, g.K = q.in_dim, g.relu = 1;
             g.bf16 = bf, g.split = sp, g.y_f32 = (i + 2 == nl);       // the tail reads fp32
-            const int S = choose_ksplit(g, rows_hint < 0 || rows_hint > rows ? rows : rows_hint, HEAD_KSPLIT_MAX);
+            // (the plane sum writes fp32: on the bf16 path only where the consumer reads fp32)
+            const int S = (bf && !g.y_f32) ? 1 : choose_ksplit(g, rows_hint < 0 || rows_hint > rows ? rows : rows_hint, HEAD_KSPLIT_MAX);
             if (S > 1) {
                 if (mel_status st = launch_gemm_splitk(g, S, L.hpart, (long)L.rows_cap * ldo, s, "head hidden (Q|V), split-K",
                                                        rows_hint, 3)) return st;

@@ -72,7 +72,7 @@ template <int A_CHUNKS, int W_CHUNKS>
 struct BTileCtx {
     BChunk ac[A_CHUNKS];
     const u32x4* w_src[W_CHUNKS];
-    int m0, n0, M, pi, KT;
+    int m0, n0, M, pi, KT, ks;          // ks: split-K chunk of this work item (GemmArgs::ksplit)
 };
 
 template <int WM, int WN, int TM, int TN, int MODE>
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmBatch ba
         if (i < batch.count) {
             const GemmArgs& q = batch.p[i];
             rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
-            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN);
+            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN) * (q.ksplit > 1 ? q.ksplit : 1);
         }
         pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
     }
@@ -133,11 +133,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmBatch ba
             const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
             wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
         }
-        c.pi = pi, c.M = rows[pi], c.KT = g.K / GEMB_BK;
-        c.m0 = (wg / nbn) * BM, c.n0 = (wg % nbn) * BN;
-        const uint16_t* A16 = reinterpret_cast<const uint16_t*>(g.A);
-        const uint16_t* W16 = reinterpret_cast<const uint16_t*>(g.W);
-        const uint16_t* Wh16 = reinterpret_cast<const uint16_t*>(g.W_hi);
+        // split-K (skinny long-K problems, see gemm_ring.hpp): work items of a row panel are ordered chunk-major; chunk ks
+        // covers K columns [k0, k0 + KT * GEMB_BK) and writes raw fp32 products to plane ks
+        const int S = g.ksplit > 1 ? g.ksplit : 1;
+        c.pi = pi, c.M = rows[pi], c.KT = g.K / GEMB_BK / S, c.ks = (wg / nbn) % S;
+        c.m0 = (wg / (nbn * S)) * BM, c.n0 = (wg % nbn) * BN;
+        const int k0 = c.ks * c.KT * GEMB_BK;
+        const uint16_t* A16 = reinterpret_cast<const uint16_t*>(g.A) + k0;
+        const uint16_t* W16 = reinterpret_cast<const uint16_t*>(g.W) + k0;
+        const uint16_t* Wh16 = g.W_hi ? reinterpret_cast<const uint16_t*>(g.W_hi) + k0 : nullptr;
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const int row = min(c.m0 + crow + i * (T / 8), c.M - 1);      // clamped, never predicated
@@ -251,6 +255,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmBatch ba
         {   // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5))
             const GemmArgs& g = batch.p[cur.pi];
             uint16_t* Y16 = reinterpret_cast<uint16_t*>(g.Y);
+            if (g.ksplit > 1) {                // raw partial products into this chunk's fp32 plane
+                float* P = g.Y + (size_t)cur.ks * g.part_stride;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = cur.n0 + wn * 32 * TN + j * 32 + r;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int m = cur.m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (m < cur.M) P[(size_t)m * g.ldy + n] = acc[i][j][e];
+                        }
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = cur.n0 + wn * 32 * TN + j * 32 + r;
