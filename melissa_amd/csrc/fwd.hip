@@ -263,7 +263,7 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
 // in order and applies scale / bias / ReLU.  Model of the launch in K steps of one workgroup: (workgroups sharing a
 // CU) x (items per workgroup) x (steps per item + 2 for the hand-over), over the 512 slots of the ring kernel.
 int choose_ksplit(const GemmArgs& g, long m_hint, int max_split) {
-    if (g.split || g.K < 768 || g.ldy % 4 || g.N % 64 || g.K % GEMB_BK) return 1;
+    if (g.split || g.K < 512 || g.ldy % 4 || g.N % 64 || g.K % GEMB_BK) return 1;
     const long tiles = ((m_hint + 63) / 64) * (g.N / 64);
     if (g.bf16) {
         // bf16 one-role kernel: 1 024 slots, latency bound at these sizes - items per slot x (steps per item + 2)
@@ -623,7 +623,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
         g.bf16 = bf, g.split = sp, g.y_f32 = 1;
         const long hint = rows_hint < 0 || rows_hint > rows ? rows : rows_hint;
         const int S = choose_ksplit(g, hint, HEAD_KSPLIT_MAX);
-        if ((S > 1 || bf || sp) && q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W &&
+        if (q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W &&
             q1.out_dim == HF_W && v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= 8 &&
             w->v_head.layer[2].out_dim == 1 && q1.weight && v1.weight) {
             const long ps = (long)L.rows_cap * 2 * HF_W;
