@@ -347,10 +347,12 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
 
 // ATT_POOL (HL-DGN): one workgroup per env (every env has exactly N targets, so this is balanced):
 // conv1 attention for all nodes, decision-maker mask, max / mean / add pool over the graph.
-template <int VPL, bool BF>
-__global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
+// NW wavefronts per env: at 512 envs per GPU four waves per workgroup leave a CU with 8 resident waves (two workgroups),
+// too few to hide the source-row latency; sixteen waves (three targets each at N = 50) fill it.
+template <int VPL, bool BF, int NW>
+__global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     constexpr int HC = 64 * VPL;
-    __shared__ float part[4][HC];
+    __shared__ float part[NW][HC];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
     Vec<VPL> pool;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
-    for (int t = wave; t < a.n; t += 4) {
+    for (int t = wave; t < a.n; t += NW) {
         const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
         const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF>(a, (size_t)(b * a.n + t), sources, full, b * a.n,
                                                                   att, bias, lane);
@@ -375,12 +377,14 @@ __global__ __launch_bounds__(256, 2) void gat_attend_pool_kernel(AttArgs a) {
 #pragma unroll
     for (int i = 0; i < VPL; ++i) part[wave][lane * VPL + i] = pool.v[i];
     __syncthreads();
-    for (int c = threadIdx.x; c < HC; c += 256) {
-        float v;
+    for (int c = threadIdx.x; c < HC; c += 64 * NW) {
+        float v = part[0][c];
         if (a.aggregator == MEL_AGG_MAX) {
-            v = fmaxf(fmaxf(part[0][c], part[1][c]), fmaxf(part[2][c], part[3][c]));
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v = fmaxf(v, part[w][c]);
         } else {
-            v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += part[w][c];
             if (a.aggregator == MEL_AGG_MEAN) v /= (float)a.n;
         }
         if constexpr (BF) reinterpret_cast<uint16_t*>(a.pooled)[(size_t)b * HC + c] = (uint16_t)pack_bf16x2(v, 0.f);
@@ -392,9 +396,14 @@ template <int MODE>
 static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const char* what) {
     if constexpr (MODE == ATT_POOL) {
         switch (hc / 64) {
-#define MEL_POOL_LAUNCH(V)                                                                              \
-    if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true>), dim3(a.bs), dim3(256), 0, s, a);  \
-    else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false>), dim3(a.bs), dim3(256), 0, s, a);
+#define MEL_POOL_LAUNCH(V)                                                                                         \
+    if (a.bs >= 2048) {                                                                                           \
+        if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true, 4>), dim3(a.bs), dim3(256), 0, s, a);     \
+        else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false, 4>), dim3(a.bs), dim3(256), 0, s, a);           \
+    } else {                                                                                                      \
+        if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true, 16>), dim3(a.bs), dim3(1024), 0, s, a);   \
+        else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false, 16>), dim3(a.bs), dim3(1024), 0, s, a);         \
+    }
             case 2: MEL_POOL_LAUNCH(2) break;
             case 4: MEL_POOL_LAUNCH(4) break;
             case 8: MEL_POOL_LAUNCH(8) break;
