@@ -635,10 +635,14 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             }
             StageScope t(MEL_STAGE_HEAD_TAIL, s);
             HeadFinish f{L.hpart, ps, S, (int)rows, rows_dev, q.bias, v.bias, q1, v1, w->q_head.layer[2], w->v_head.layer[2],
-                         logits, select ? *select : mel_select{}};
-            long blocks = (hint + hint / 4 + 63) / 32;
+                         logits, select ? *select : mel_select{}, 0};
+            // grid: twice the expected row count (the hint is a rough mean; a workgroup that has to loop doubles the
+            // launch), surplus workgroups leave after one load
             const long need = (rows + 31) / 32;
+            const long likely = (hint + 31) / 32;
+            long blocks = rows_dev ? 2 * likely + 8 : need;
             blocks = blocks > need ? need : blocks < 1 ? 1 : blocks;
+            f.likely_blocks = (int)(likely < blocks ? likely : blocks);
             hipLaunchKernelGGL(head_finish_kernel, dim3((int)blocks), dim3(512), 0, s, f);
             return check_launch("head finish");
         }
@@ -715,9 +719,11 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const int sp = w->precision == MEL_PREC_F32_SPLIT;
     ProjWeights pw;
     if (mel_status st = resolve_projections(w, L, pw, s)) return st;
-    const long hintL = single ? bs : bs * (long)(n < 10 ? 1 : n / 10);
-    const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : bs * (long)(n < 5 ? n : 1 + n / 5);
-    const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : bs * (long)(n < 3 ? n : 1 + n / 3);
+    // round-batched loop, measured on the bench workload (per env, N = 20 / 50): |L| = 3.1 / 4.7, |U1| = 5.8 / 10.4,
+    // |U2| = 7.6 / 15.8 - linear fits below
+    const long hintL = single ? bs : (n < 10 ? bs : bs * (long)(36 + n) / 18);
+    const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : (n < 10 ? bs * (long)n : bs * 2L * (18 + n) / 13);
+    const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : (n < 10 ? bs * (long)n : bs * 3L * (8 + n) / 11);
 
     {
         StageScope t(MEL_STAGE_PLAN, s);

@@ -105,6 +105,7 @@ struct HeadFinish {
     mel_linear q_last, v_last;
     float* logits;
     mel_select sel;
+    int likely_blocks;                     // workgroups below this index expect rows: they fetch W1 before the row count is known
 };
 __global__ __launch_bounds__(512) void head_finish_kernel(HeadFinish f) {
     __shared__ __attribute__((aligned(16))) float h0[32 * HF_LD];
@@ -117,8 +118,17 @@ __global__ __launch_bounds__(512) void head_finish_kernel(HeadFinish f) {
     const mel_linear& l1 = hd ? f.v1 : f.q1;
     const float* wrow = l1.weight + (size_t)(cb * 32 + r) * HF_W;
     f32x4 wf[16];
+    // the grid is sized generously from the EXPECTED row count (the real one lives on the device): a surplus workgroup
+    // must not pull its 128 KB of W1 through the L2 before it finds out that it has nothing to do
+    const bool likely = (int)blockIdx.x < f.likely_blocks;
+    if (likely) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + (2 * q + h) * 4);
+        for (int q = 0; q < 16; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + (2 * q + h) * 4);
+    } else {
+        if ((int)blockIdx.x * 32 >= rows) return;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + (2 * q + h) * 4);
+    }
     const float b1 = l1.bias[cb * 32 + r];
     // last layer: 16 threads per row, thread j of a row holds columns k = j + 16 i of every output's weight row
     const int na = f.q_last.out_dim, j16 = tid & 15, trow = tid >> 4;
