@@ -624,7 +624,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
         const long hint = rows_hint < 0 || rows_hint > rows ? rows : rows_hint;
         const int S = choose_ksplit(g, hint, HEAD_KSPLIT_MAX);
         if (q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W &&
-            q1.out_dim == HF_W && v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= 8 &&
+            q1.out_dim == HF_W && v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= HF_MAX_ACTIONS &&
             w->v_head.layer[2].out_dim == 1 && q1.weight && v1.weight) {
             const long ps = (long)L.rows_cap * 2 * HF_W;
             {
@@ -638,12 +638,15 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
                          logits, select ? *select : mel_select{}, 0};
             // grid: twice the expected row count (the hint is a rough mean; a workgroup that has to loop doubles the
             // launch), surplus workgroups leave after one load
-            const long need = (rows + 31) / 32;
-            const long likely = (hint + 31) / 32;
+            // 16 rows per workgroup while that leaves at most one workgroup per CU, 32 beyond
+            const int per = hint > 16 * 256 ? 32 : 16;
+            const long need = (rows + per - 1) / per;
+            const long likely = (hint + per - 1) / per;
             long blocks = rows_dev ? 2 * likely + 8 : need;
             blocks = blocks > need ? need : blocks < 1 ? 1 : blocks;
             f.likely_blocks = (int)(likely < blocks ? likely : blocks);
-            hipLaunchKernelGGL(head_finish_kernel, dim3((int)blocks), dim3(512), 0, s, f);
+            if (per == 16) hipLaunchKernelGGL(head_finish_kernel<1>, dim3((int)blocks), dim3(512), 0, s, f);
+            else hipLaunchKernelGGL(head_finish_kernel<2>, dim3((int)blocks), dim3(512), 0, s, f);
             return check_launch("head finish");
         }
     }

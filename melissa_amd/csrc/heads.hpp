@@ -87,13 +87,17 @@ __global__ __launch_bounds__(256) void dueling_tail_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused finish of the standard dueling heads (hidden [128, 128] for Q and for V) after a split-K first layer:
+// fused finish of the standard dueling heads (hidden [128, 128] for Q and for V) after the first layer's raw products:
 //   h0 = relu(P_0 + P_1 + ... + bias0)  ->  h1 = relu(W1 h0 + b1) for Q and V (fp32 MFMA)  ->  last layer + combine + selection
-// One workgroup of 8 wavefronts per 32 rows; h0 / h1 live in LDS; the arithmetic of each stage is the one the unfused
-// launches perform (splitk_finish_kernel, the 64 x 64 GEMM's K order, dueling_row).
+// One workgroup of 8 wavefronts per 16 * MB rows (v_mfma_f32_16x16x4_f32, MB row blocks share a wave's W1 fragments);
+// h0 / h1 live in LDS.  MB = 1 for small batches (half the matrix-pipe time per workgroup, twice the workgroups, two per
+// CU covering each other's load / barrier phases: N = 20 config 16.3 -> 13.2 us); MB = 2 once there is more than one
+// 16-row workgroup per CU - every workgroup pulls the 128 KB of W1 through the L2 (N = 50: 16.5 us against 18.1).
 // ------------------------------------------------------------------------------------------------
 constexpr int HF_W = 128;                  // hidden width per head
 constexpr int HF_LD = 2 * HF_W + 4;        // LDS row stride (floats)
+constexpr int HF_MAX_ACTIONS = 4;          // last-layer weights of Q live in registers (the reference has 2 actions)
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 struct HeadFinish {
     const float* parts;                    // [S][rows_cap][2 * HF_W] raw first-layer products (Q | V)
     long part_stride;
@@ -107,45 +111,42 @@ struct HeadFinish {
     mel_select sel;
     int likely_blocks;                     // workgroups below this index expect rows: they fetch W1 before the row count is known
 };
-__global__ __launch_bounds__(512) void head_finish_kernel(HeadFinish f) {
-    __shared__ __attribute__((aligned(16))) float h0[32 * HF_LD];
-    __shared__ __attribute__((aligned(16))) float h1[32 * HF_LD];
+template <int MB>
+__global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
+    constexpr int HF_ROWS = 16 * MB;
+    __shared__ __attribute__((aligned(16))) float h0[HF_ROWS * HF_LD];
+    __shared__ __attribute__((aligned(16))) float h1[HF_ROWS * HF_LD];
+    __shared__ float wl[(HF_MAX_ACTIONS + 1) * HF_W + HF_MAX_ACTIONS + 1];        // last-layer weights + biases
     const int rows = f.M_dev ? min(*f.M_dev, f.M) : f.M;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
+    const int li = lane & 15, lg = lane >> 4;              // MFMA 16x16x4: row / column index and k group of this lane
     const int hd = wid >> 2, cb = wid & 3;                 // head (0 Q, 1 V) and 32-column block of this wave's h1 tile
-    // this lane's W1 fragments: row n = cb*32 + r of the head's [128, 128] matrix, chunks (2q + h) of four k each
+    // K order of the 32 MFMA steps: step 4t + u multiplies k = 16t + 4g + u of lane group g, so that a lane's operands of
+    // four consecutive steps are ONE 16-byte chunk (column 16t + 4g) of its h0 row (A) and of its W1 row (B)
     const mel_linear& l1 = hd ? f.v1 : f.q1;
-    const float* wrow = l1.weight + (size_t)(cb * 32 + r) * HF_W;
-    f32x4 wf[16];
+    const float* wrow0 = l1.weight + (size_t)(cb * 32 + li) * HF_W + 4 * lg;            // column block 0: n = cb*32 + li
+    const float* wrow1 = wrow0 + (size_t)16 * HF_W;                                      // column block 1: n + 16
+    f32x4 wf[2][8];
     // the grid is sized generously from the EXPECTED row count (the real one lives on the device): a surplus workgroup
     // must not pull its 128 KB of W1 through the L2 before it finds out that it has nothing to do
     const bool likely = (int)blockIdx.x < f.likely_blocks;
-    if (likely) {
+    if (!likely && (int)blockIdx.x * HF_ROWS >= rows) return;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + (2 * q + h) * 4);
-    } else {
-        if ((int)blockIdx.x * 32 >= rows) return;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wf[q] = *reinterpret_cast<const f32x4*>(wrow + (2 * q + h) * 4);
+    for (int t = 0; t < 8; ++t) {
+        wf[0][t] = *reinterpret_cast<const f32x4*>(wrow0 + 16 * t);
+        wf[1][t] = *reinterpret_cast<const f32x4*>(wrow1 + 16 * t);
     }
-    const float b1 = l1.bias[cb * 32 + r];
-    // last layer: 16 threads per row, thread j of a row holds columns k = j + 16 i of every output's weight row
+    const float b1_0 = l1.bias[cb * 32 + li], b1_1 = l1.bias[cb * 32 + 16 + li];
+    // last layer: 16 threads per row, thread j of a row takes columns k = j + 16 i of every output's weight row; the
+    // weight rows (Q's na rows, then V's) and biases wait in LDS (visible after the loop's first barrier)
     const int na = f.q_last.out_dim, j16 = tid & 15, trow = tid >> 4;
-    float wq[8][8], wv[8], bq[8];
+    for (int i = tid; i < (na + 1) * HF_W; i += 512)
+        wl[i] = i < na * HF_W ? f.q_last.weight[i] : f.v_last.weight[i - na * HF_W];
+    if (tid <= na) wl[(HF_MAX_ACTIONS + 1) * HF_W + tid] = tid < na ? f.q_last.bias[tid] : f.v_last.bias[0];
+    for (int m0 = blockIdx.x * HF_ROWS; m0 < rows; m0 += gridDim.x * HF_ROWS) {
+        // 1. h0 = relu(sum of the planes in order + bias0): 16 MB rows x 64 chunks of four columns, 2 MB per thread
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        bq[a] = a < na ? f.q_last.bias[a] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wq[a][i] = a < na ? f.q_last.weight[(size_t)a * HF_W + j16 + 16 * i] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) wv[i] = f.v_last.weight[j16 + 16 * i];
-    const float bv = f.v_last.bias[0];
-    for (int m0 = blockIdx.x * 32; m0 < rows; m0 += gridDim.x * 32) {
-        // 1. h0 = relu(sum of the planes in order + bias0): 32 rows x 64 chunks of four columns, four per thread
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2 * MB; ++i) {
             const int c = tid + i * 512, row = c >> 6, col = (c & 63) * 4;
             const int m = min(m0 + row, f.M - 1);
             const float* p = f.parts + (size_t)m * (2 * HF_W) + col;
@@ -162,23 +163,35 @@ __global__ __launch_bounds__(512) void head_finish_kernel(HeadFinish f) {
                 f32x4{fmaxf(acc[0] + b[0], 0.f), fmaxf(acc[1] + b[1], 0.f), fmaxf(acc[2] + b[2], 0.f), fmaxf(acc[3] + b[3], 0.f)};
         }
         __syncthreads();
-        // 2. hidden layer 1: this wave's 32 x 32 block over K = 128
-        f32x16 acc;
+        // 2. hidden layer 1: this wave's (16 MB) x 32 block (two 16 x 16 accumulators per row block) over K = 128
+        f32x4_acc acc0[MB], acc1[MB];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const float* arow = h0 + r * HF_LD + hd * HF_W;
+        for (int mb = 0; mb < MB; ++mb) acc0[mb] = f32x4_acc{0.f, 0.f, 0.f, 0.f}, acc1[mb] = f32x4_acc{0.f, 0.f, 0.f, 0.f};
+        const float* arow = h0 + li * HF_LD + hd * HF_W + 4 * lg;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(arow + (2 * q + h) * 4);
+        for (int t = 0; t < 8; ++t) {
+            f32x4 a[MB];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wf[q][kk], acc, 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb) a[mb] = *reinterpret_cast<const f32x4*>(arow + mb * 16 * HF_LD + 16 * t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    acc0[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], wf[0][t][u], acc0[mb], 0, 0, 0);
+                    acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][u], wf[1][t][u], acc1[mb], 0, 0, 0);
+                }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e)        // C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
-            h1[((e & 3) + 8 * (e >> 2) + 4 * h) * HF_LD + hd * HF_W + cb * 32 + r] = fmaxf(acc[e] + b1, 0.f);
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
+                float* dst = h1 + (mb * 16 + 4 * lg + e) * HF_LD + hd * HF_W + cb * 32 + li;
+                dst[0] = fmaxf(acc0[mb][e] + b1_0, 0.f);
+                dst[16] = fmaxf(acc1[mb][e] + b1_1, 0.f);
+            }
         __syncthreads();
         // 3. last layer + dueling combine + selection: 16 threads per row
-        {
+        if (trow < HF_ROWS) {
             const float* hq = h1 + trow * HF_LD;
             float q[8], v = 0.f;
 #pragma unroll
@@ -186,28 +199,28 @@ __global__ __launch_bounds__(512) void head_finish_kernel(HeadFinish f) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float xq = hq[j16 + 16 * i], xv = hq[HF_W + j16 + 16 * i];
-                v = fmaf(xv, wv[i], v);
+                v = fmaf(xv, wl[na * HF_W + j16 + 16 * i], v);
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
-                    if (a < na) q[a] = fmaf(xq, wq[a][i], q[a]);
+                for (int a = 0; a < HF_MAX_ACTIONS; ++a)
+                    if (a < na) q[a] = fmaf(xq, wl[a * HF_W + j16 + 16 * i], q[a]);
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) {
                 v += __shfl_xor(v, o, 64);
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
+                for (int a = 0; a < HF_MAX_ACTIONS; ++a)
                     if (a < na) q[a] += __shfl_xor(q[a], o, 64);
             }
             const int b = m0 + trow;
             if (b < rows) {
                 float qsum = 0.f;
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
-                    if (a < na) q[a] += bq[a], qsum += q[a];
-                v += bv;
+                for (int a = 0; a < HF_MAX_ACTIONS; ++a)
+                    if (a < na) q[a] += wl[(HF_MAX_ACTIONS + 1) * HF_W + a], qsum += q[a];
+                v += wl[(HF_MAX_ACTIONS + 1) * HF_W + na];
                 const float mean = qsum / (float)na;
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
+                for (int a = 0; a < HF_MAX_ACTIONS; ++a)
                     if (a < na && j16 == a) f.logits[(size_t)b * na + a] = q[a] - mean + v;
                 if (f.sel.act && j16 == 0) select_fused(q, mean, v, na, f.sel, b);
             }
