@@ -204,7 +204,9 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     }
     // encoder (ENC producer): a 64 x 128 tile spans the whole hidden width, so the first layer (VALU work inside the
     // A-tile producer) is evaluated once per row instead of once per 64-column tile
-    const bool enc_wide = g.bf16 && mode == GEMM_MODE_ENC && force_tile == 0 && g.N % 128 == 0;   // fp32: measured slower (21 vs 18 us)
+    // (fp32: the wide tile wins from about 20 000 rows - HL-DGN's 25 600: 24.8 -> 19.9 us - and loses below - L-DGN's
+    // 16 000: 17 -> 19 us)
+    const bool enc_wide = mode == GEMM_MODE_ENC && force_tile == 0 && g.N % 128 == 0 && (g.bf16 || m_hint >= 20000);
     if (g.bf16) {
         if (force_tile == 2 && g.N % 128 == 0) gemm_launch_bf16<2, 2, 2, 2>(&g, 1, mode, stream);
         else if (enc_wide) gemm_launch_bf16<2, 2, 1, 2>(&g, 1, mode, stream);
