@@ -12,7 +12,7 @@ import sys
 
 # launches of the round step by kernel name (the call site is part of it: TAG 1 = conv1, 2 = conv2, 3 = heads)
 LAUNCHES = {"conv1 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 1>", "conv2 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
-         "head0 (Q|V, split-K)": "gemm_f32_ring_kernel<3>", "head finish": "head_finish_kernel",
+         "head0 (Q|V, split-K)": "gemm_f32_ring_kernel<3,", "head finish": "head_finish_kernel",
          "conv1 attention": "gat_attend_rows_kernel<8, 0,", "conv2 attention": "gat_attend_rows_kernel<8, 2,",
          "env round": "env_round_kernel", "encoder": "gemm_f32_persistent_kernel<2, 2, 1, 1, 1,"}
 
