@@ -126,6 +126,29 @@ def test_ldgn_head_shapes(hidden, bs):
     np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("n_actions", [3, 5])
+def test_ldgn_action_counts(n_actions):
+    """More than the reference's two actions: up to four stay on the fused finish kernel, five take the generic tail."""
+    from melissa_amd.networks import LDGNNetwork
+    from oracle import net_oracle as no
+    n, bs = 20, 333
+    rng = np.random.RandomState(3 + n_actions)
+    obs = np.zeros((bs, 8 * n + 1), dtype=np.float32)
+    m = obs[:, :-1].reshape(bs, n, 8)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2:7] = rng.randint(0, 3, size=(bs, n, 5))
+    m[:, :, 7] = 1.0
+    obs[:, -1] = rng.randint(0, n, size=bs)
+    sd = no.init_weights("l_dgn", seed=11, n_actions=n_actions, random_conv_bias=True)
+    net = LDGNNetwork(5, 128, n_actions, 4, n, dueling_param=DUEL(), device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        got = net(obs)[0].cpu().numpy()
+        want = no.ldgn_forward(sd, obs, n).numpy()
+    assert got.shape == (bs, n_actions)
+    np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
 def test_full_size_linearity_property():
     """BASELINE size (N=50, 1024 rows): property checks that need no oracle run - row independence
     (a row's logits do not depend on its batch mates / position) and determinism."""
