@@ -47,11 +47,13 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
     import torch
     from melissa_amd.collect import DecisionLoop, MultiStreamRoundLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
-    from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
+    from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
     from melissa_amd.policy import DQNPolicy
     torch.manual_seed(seed)                                   # default --seed 9, common.py:20
     if model_name == "l_dgn":
         net = LDGNNetwork(5, HIDDEN, 2, HEADS, n_nodes, dueling_param=dueling(), device=device, backend="hip")
+    elif model_name == "dgn_r":
+        net = DGNRNetwork(5, HIDDEN, 2, HEADS, n_nodes, dueling_param=dueling(), device=device, backend="hip")
     else:
         net = HLDGNNetwork(5, HIDDEN, 2, HEADS, n_nodes, aggregator="max", dueling_param=dueling(),
                            device=device, backend="hip")
@@ -76,15 +78,17 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
     return net, venv, loop
 
 
-def stage_flops(totals):
+def stage_flops(totals, model="l_dgn"):
     """ALGORITHMIC FLOPs (2*MAC) per launch of each GEMM stage, from the row counts the launch actually
     processed: U1 = conv1 targets, U2 = conv1 sources, R = agent rows (pruned / shared work
-    is priced at the pruned / shared count)."""
+    is priced at the pruned / shared count).  DGN-R: key | value projections on the source rows (2 HC wide), query on
+    the target rows."""
     u1, u2, r = totals[0], totals[1], totals[2]
+    src = 2 if model == "dgn_r" else 1
     return {
         "encoder": u2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
-        "conv1_lin": 2.0 * (u2 + u1) * HC * HIDDEN,        # lin_l on U2 rows + lin_r on U1 rows, one grouped launch
-        "conv2_lin": 2.0 * (u1 + r) * HC * HC,             # lin_l on U1 rows + lin_r on the agent rows
+        "conv1_lin": 2.0 * (src * u2 + u1) * HC * HIDDEN,  # lin_l on U2 rows + lin_r on U1 rows, one grouped launch
+        "conv2_lin": 2.0 * (src * u1 + r) * HC * HC,       # lin_l on U1 rows + lin_r on the agent rows
         "head_hidden": 2.0 * r * ((HIDDEN + 2 * HC) * 256 + 2 * 128 * 128),
     }
 
@@ -212,7 +216,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU")
     ap.add_argument("--nodes", type=int, default=N_NODES)
-    ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn"])
+    ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn", "dgn_r"])
     ap.add_argument("--mode", default="round", choices=["round", "aec"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--streams", type=int, default=1,
@@ -288,7 +292,7 @@ def main():
         lib.mel_prof_attach(prof)
         for k in range(args.steps):
             ploop.step()
-            if args.model == "l_dgn":
+            if args.model != "hl_dgn":
                 _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, rows_cap, ws.data_ptr(),
                                                totals[k].data_ptr(), _lib.current_stream_ptr(device)))
         lib.mel_prof_attach(None)
@@ -299,13 +303,13 @@ def main():
         lib.mel_prof_destroy(prof)
         # us per STEP: a stage that brackets several launches per step (the heads' two hidden layers) is their sum
         stages = {name: (ms[i] / args.steps * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}
-        mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model == "l_dgn"
+        mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model != "hl_dgn"
                     else (0.0, float(args.envs * args.nodes), float(args.envs)))
         if args.model == "hl_dgn":
             fl = {"encoder": args.envs * args.nodes * 34048.0, "conv1_lin": 2.0 * args.envs * args.nodes * 2 * HC * HIDDEN,
                   "head_hidden": 2.0 * args.envs * (HC * 256 + 2 * 128 * 128)}
         else:
-            fl = stage_flops(mean_tot)
+            fl = stage_flops(mean_tot, args.model)
         dom = max(fl, key=lambda k: stages.get(k, 0.0))
         # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
         # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied there); only valid for the
@@ -323,7 +327,7 @@ def main():
         peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
         # name as it appears in rocprofv3 summaries (fp32 round loop: the persistent kernel tagged per call site)
         tag = {"conv1_lin": 1, "conv2_lin": 2, "head_hidden": 3}.get(dom, 0)
-        if args.dtype == "f32" and args.mode == "round" and args.model != "hl_dgn" and dom != "encoder":
+        if args.dtype == "f32" and args.mode == "round" and args.model == "l_dgn" and dom != "encoder":
             kname = f"mel::gemm_f32_persistent_kernel<2, 2, 1, 1, 0, {tag}> ({dom})"
         else:
             kname = f"gemm_{args.dtype} ({dom})"
