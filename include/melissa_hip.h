@@ -170,7 +170,10 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 
 /* The dense projection used by every layer above, exposed for tests and tuning:
  *   Y[m, n] = act(sum_k A[m, k] * W[n, k] + bias[n]),  A [M, lda], W [N, K] (nn.Linear layout), Y [M, ldy],
- * all device fp32; K % 32 == 0, N % 64 == 0.  tile: 0 = automatic, 1 = 64x64, 2 = 128x128 workgroup tile. */
+ * all device fp32; K % 32 == 0, N % 64 == 0.  tile: 0 = automatic, 1 = 64x64, 2 = 128x128 workgroup tile;
+ * tuning values (csrc/fwd.hip launch_gemm): 3-6 other one-role tiles, 11 / 12 persistent 64x64 / 128x128,
+ * 21 / 22 LDS-DMA one-role, 31 / 32 / 33 specialised-wavefront kernel at K step 32 / K step 16 (three workgroups
+ * per CU) / 128x64 tiles with eight consumer waves. */
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
 
