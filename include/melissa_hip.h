@@ -146,6 +146,11 @@ typedef struct mel_select {
     float           eps;
     uint32_t        seed;
     const uint32_t* step_dev;  /* optional device counter added to the stream position             */
+    /* per-env logits (HL-DGN, mel_hldgn_forward_envs_select): every agent i in live[b] takes its action from row b,
+     * act is the dense [bs, n_nodes] layout of mel_select_action_envs and the stream is keyed on b*64 + i          */
+    const uint64_t* live;      /* NULL: one action per logits row                                   */
+    int32_t         n_nodes;
+    int32_t         reserved;
 } mel_select;
 
 size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap);
@@ -214,6 +219,11 @@ mel_status mel_pool_backward(const float* grad_pooled, const float* dm, const in
 /* HL-DGN for the round-batched loop: logits depend only on the env (hl_dgn.py:108 pools over the graph and
  * ignores the controlling index), so one row per env serves all of a round's agents.  obs: device fp32
  * [bs, obs_stride], row b = obs_matrix of env b, obs_stride >= n_nodes*(in_dim+3), index column not read. */
+/* mel_hldgn_forward_envs with the per-(env, agent) selection of mel_select_action_envs fused into the launch that
+ * produces the logits (select->live / n_nodes / act as documented at mel_select). */
+mel_status mel_hldgn_forward_envs_select(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs,
+                                         int32_t n_nodes, int32_t obs_stride, float* logits, const mel_select* select,
+                                         void* workspace, size_t ws_bytes, void* stream);
 mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs,
                                   int32_t n_nodes, int32_t obs_stride, float* logits, void* workspace,
                                   size_t ws_bytes, void* stream);

@@ -21,7 +21,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
 
 # every symbol include/melissa_hip.h declares
 EXPORTS = ("mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
-           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
@@ -57,7 +57,8 @@ class MelWeights(C.Structure):
 
 
 class MelSelect(C.Structure):
-    _fields_ = [("act", C.c_void_p), ("eps", C.c_float), ("seed", C.c_uint32), ("step_dev", C.c_void_p)]
+    _fields_ = [("act", C.c_void_p), ("eps", C.c_float), ("seed", C.c_uint32), ("step_dev", C.c_void_p),
+                ("live", C.c_void_p), ("n_nodes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MelRoundReplay(C.Structure):
@@ -156,6 +157,8 @@ def load(build_if_missing: bool = True):
     lib.mel_pool_backward.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
     lib.mel_hldgn_forward_envs.restype = i32
     lib.mel_hldgn_forward_envs.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_hldgn_forward_envs_select.restype = i32
+    lib.mel_hldgn_forward_envs_select.argtypes = [W, i32, vp, i64, i32, i32, vp, C.POINTER(MelSelect), vp, sz, vp]
     lib.mel_select_action_envs.restype = i32
     lib.mel_select_action_envs.argtypes = [vp, vp, i64, i32, i32, C.c_float, C.c_uint32, vp, vp, vp]
     lib.mel_forward_tap.restype = i32

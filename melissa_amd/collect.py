@@ -116,6 +116,8 @@ class RoundLoop:
         self._select = _lib.MelSelect()
         self._select.act, self._select.eps = self.act.data_ptr(), float(eps)
         self._select.seed, self._select.step_dev = seed & 0xFFFFFFFF, self.rounds.data_ptr()
+        if self.per_env_logits:                    # every agent of live[b] draws from env b's logits row
+            self._select.live, self._select.n_nodes = self.live.data_ptr(), venv.n
         self._obs_matrix = venv.obs_matrix()
         # own forward scratch: several loops may share one network on different streams
         self.workspace = torch.empty(policy.model.agents_workspace_bytes(venv.env_num, self.rows_cap),
@@ -130,11 +132,9 @@ class RoundLoop:
         net = self.policy.model
         dev = self.venv.device
         if self.per_env_logits:
-            net.hip_forward_envs(self._obs_matrix, out=self.logits, workspace=self.workspace)
-            _lib.check(lib.mel_select_action_envs(self.logits.data_ptr(), self.live.data_ptr(), self.venv.env_num,
-                                                  self.venv.n, self.n_actions, float(self.eps),
-                                                  self.seed & 0xFFFFFFFF, self.rounds.data_ptr(), self.act.data_ptr(),
-                                                  _lib.current_stream_ptr(dev)), "mel_select_action_envs")
+            # forward + per-(env, agent) argmax / eps-greedy in the launch that writes the logits (same stream of draws as
+            # mel_select_action_envs)
+            net.hip_forward_envs(self._obs_matrix, out=self.logits, workspace=self.workspace, select=self._select)
             self.venv.round_device(self.pool, self.act, None, self.live, self.table, round_counter=self.rounds,
                                    replay=self.replay)
             return

@@ -908,7 +908,7 @@ mel_status mel_dgnr_forward_agents(const mel_weights* w, const float* obs, int64
 
 static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
                                      int32_t obs_width, bool index_col, float* logits, void* workspace,
-                                     size_t ws_bytes, void* stream) {
+                                     size_t ws_bytes, void* stream, const mel_select* select = nullptr) {
     if (mel_status st = validate(w, MEL_MODEL_HLDGN, bs, n, obs_width, index_col)) return st;
     if (aggregator < MEL_AGG_MAX || aggregator > MEL_AGG_ADD) return fail(MEL_ERR_INVALID_ARG, "aggregator %d", aggregator);
     if (!obs || !logits || !workspace) return fail(MEL_ERR_INVALID_ARG, "null obs/logits/workspace");
@@ -961,7 +961,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
-    return run_heads(w, pw, L, bs, nullptr, bs, logits, s);
+    return run_heads(w, pw, L, bs, nullptr, bs, logits, s, select);
 }
 
 mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
@@ -972,6 +972,16 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
                                   int32_t obs_stride, float* logits, void* workspace, size_t ws_bytes, void* stream) {
     return hldgn_forward_impl(w, aggregator, obs, bs, n, obs_stride, false, logits, workspace, ws_bytes, stream);
+}
+
+mel_status mel_hldgn_forward_envs_select(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
+                                         int32_t obs_stride, float* logits, const mel_select* select, void* workspace,
+                                         size_t ws_bytes, void* stream) {
+    if (select && select->act) {
+        if (!select->live || select->n_nodes != n)
+            return fail(MEL_ERR_INVALID_ARG, "per-env selection needs select->live and select->n_nodes == n_nodes");
+    }
+    return hldgn_forward_impl(w, aggregator, obs, bs, n, obs_stride, false, logits, workspace, ws_bytes, stream, select);
 }
 
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,

@@ -40,6 +40,29 @@ __device__ __forceinline__ void select_fused(const float (&q)[8], float mean, fl
     sel.act[b] = best;
 }
 
+// per-env logits (HL-DGN): agent i of env b takes argmax / eps-greedy from the env's values with the stream of
+// select_envs_kernel (key b*64 + i); act is the dense [bs, n_nodes] layout
+__device__ __forceinline__ void select_env_agent(const float (&q)[8], float mean, float v, int na, const mel_select& sel,
+                                                 int b, int i) {
+    int best = 0;
+    float bv = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (a < na && q[a] - mean + v > bv) bv = q[a] - mean + v, best = a;
+    if (sel.eps > 0.f) {
+        const uint32_t step = sel.step_dev ? *sel.step_dev : 0u;
+        const uint32_t base = mix32(sel.seed ^ mix32(step * 0x9e3779b9U + (uint32_t)(b * 64 + i)));
+        if (u01(base) < sel.eps) {
+            best = 0, bv = -1.f;
+            for (int a = 0; a < na; ++a) {
+                const float u = u01(mix32(base + 0x85ebca6bU * (uint32_t)(a + 1)));
+                if (u > bv) bv = u, best = a;
+            }
+        }
+    }
+    sel.act[(size_t)b * sel.n_nodes + i] = best;
+}
+
 // last Linear of Q and V + dueling combine + selection for ONE row held by one wave; hq / hv: the row's hidden
 // activations (global or LDS)
 __device__ __forceinline__ void dueling_row(const float* hq, int kq, const float* hv, int kv, const mel_linear& q_last,
@@ -70,7 +93,11 @@ __device__ __forceinline__ void dueling_row(const float* hq, int kq, const float
 #pragma unroll
     for (int a = 0; a < 8; ++a)
         if (a < na && lane == a) logits[(size_t)b * na + a] = q[a] - mean + v;
-    if (sel.act && lane == 0) select_fused(q, mean, v, na, sel, b);
+    if (sel.act && sel.live) {                // every lane holds the row's values after the butterfly sums
+        if (lane < sel.n_nodes && ((sel.live[b] >> lane) & 1ull)) select_env_agent(q, mean, v, na, sel, b, lane);
+    } else if (sel.act && lane == 0) {
+        select_fused(q, mean, v, na, sel, b);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -222,7 +249,13 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
 #pragma unroll
                 for (int a = 0; a < HF_MAX_ACTIONS; ++a)
                     if (a < na && j16 == a) f.logits[(size_t)b * na + a] = q[a] - mean + v;
-                if (f.sel.act && j16 == 0) select_fused(q, mean, v, na, f.sel, b);
+                if (f.sel.act && f.sel.live) {        // the row's 16 lanes share its agents (all of them hold q and v)
+                    const uint64_t lv = f.sel.live[b];
+                    for (int i = j16; i < f.sel.n_nodes; i += 16)
+                        if ((lv >> i) & 1ull) select_env_agent(q, mean, v, na, f.sel, b, i);
+                } else if (f.sel.act && j16 == 0) {
+                    select_fused(q, mean, v, na, f.sel, b);
+                }
             }
         }
         // no barrier here: the next iteration's h0 writes come after this one's h0 reads (barrier 2 above), and its h1 writes

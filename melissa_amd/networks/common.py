@@ -234,8 +234,9 @@ class HipForwardMixin:
         return out
 
     def hip_forward_envs(self, obs_matrix: torch.Tensor, out: torch.Tensor | None = None,
-                         workspace: torch.Tensor | None = None) -> torch.Tensor:
-        """HL-DGN on env rows without an index column (round-batched loop): one logits row per env."""
+                         workspace: torch.Tensor | None = None, select: "_lib.MelSelect | None" = None) -> torch.Tensor:
+        """HL-DGN on env rows without an index column (round-batched loop): one logits row per env.  ``select`` (with
+        ``live`` / ``n_nodes`` set): the per-(env, agent) argmax / eps-greedy fused into the launch that writes the logits."""
         if self._MODEL != _lib.MODEL_HLDGN:
             raise RuntimeError("hip_forward_envs is the HL-DGN entry point")
         lib = _lib.load()
@@ -245,6 +246,12 @@ class HipForwardMixin:
         ws = workspace if workspace is not None else self._workspace(w, bs, obs_matrix.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
+        if select is not None:
+            st = lib.mel_hldgn_forward_envs_select(C.byref(w), _lib.AGG[self.aggregator_name], obs_matrix.data_ptr(), bs,
+                                                   self.agents_num, obs_matrix.stride(0), out.data_ptr(), C.byref(select),
+                                                   ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+            _lib.check(st, "mel_hldgn_forward_envs_select")
+            return out
         st = lib.mel_hldgn_forward_envs(C.byref(w), _lib.AGG[self.aggregator_name], obs_matrix.data_ptr(), bs,
                                         self.agents_num, obs_matrix.stride(0), out.data_ptr(), ws.data_ptr(),
                                         ws.numel(), _lib.current_stream_ptr(obs_matrix.device))

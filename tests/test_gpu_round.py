@@ -360,3 +360,41 @@ def test_watch_single_env(model):
     from melissa_amd.watch import watch
     out = watch(model=model, n_nodes=20, envs=1, episodes=6)
     assert out["n/ep"] >= 6 and 0.0 < out["coverage"] <= 1.0 and out["total_messages_transmitted"] >= 1
+
+
+@pytest.mark.parametrize("dueling", [True, False])
+def test_hldgn_fused_selection_equals_the_separate_launch(dueling):
+    """mel_hldgn_forward_envs_select writes, for every agent of live[b], the action mel_select_action_envs draws from the
+    same logits (same counter-based stream), for the dueling heads (fused finish kernel) and a plain out_linear head."""
+    import ctypes as C
+    from melissa_amd import _lib
+    from melissa_amd.networks import HLDGNNetwork
+    n, bs = 20, 300
+    torch.manual_seed(4)
+    net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL() if dueling else None, device="cuda",
+                       backend="hip")
+    rng = np.random.RandomState(8)
+    m = np.zeros((bs, n, 8), dtype=np.float32)
+    m[:, :, 0:2] = rng.uniform(0, 1, size=(bs, n, 2))
+    m[:, :, 2:7] = rng.randint(0, 3, size=(bs, n, 5))
+    m[:, :, 7] = 1.0
+    obs = torch.from_numpy(m.reshape(bs, n * 8)).cuda()
+    live_np = rng.randint(0, 1 << n, size=bs).astype(np.int64)
+    live_np[::7] = 0
+    live = torch.from_numpy(live_np).cuda()
+    rounds = torch.tensor([5], dtype=torch.int32, device="cuda")
+    lib = _lib.load()
+    for eps in (0.0, 0.4):
+        act = torch.full((bs * n,), -1, dtype=torch.int32, device="cuda")
+        sel = _lib.MelSelect()
+        sel.act, sel.eps, sel.seed, sel.step_dev = act.data_ptr(), eps, 1234, rounds.data_ptr()
+        sel.live, sel.n_nodes = live.data_ptr(), n
+        with torch.no_grad():
+            logits = net.hip_forward_envs(obs, select=sel)
+            plain = net.hip_forward_envs(obs)
+        assert torch.equal(logits, plain)
+        want = torch.full((bs * n,), -1, dtype=torch.int32, device="cuda")
+        _lib.check(lib.mel_select_action_envs(logits.data_ptr(), live.data_ptr(), bs, n, 2, C.c_float(eps), 1234,
+                                              rounds.data_ptr(), want.data_ptr(), _lib.current_stream_ptr()))
+        assert torch.equal(act, want)
+        assert (act.view(bs, n)[0] >= 0).sum().item() == bin(int(live_np[0])).count("1")
