@@ -115,3 +115,45 @@ def test_scripted_argument_checks_and_partition():
             assert bin(scripted).count("1") in (9, 10) and not (scripted >> int(origin[b])) & 1
             assert int(sets[b, L.SET_AGENTS]) & scripted == 0
             np.testing.assert_array_equal(dm[b], [0.0 if (scripted >> i) & 1 else 1.0 for i in range(20)])
+
+
+def test_distance_rule_on_threshold_pairs():
+    """The float64 edge rule dx*dx + dy*dy <= 0.2**2 (nx.geometric_edges, core.py:311) on positions where it is decided
+    in the last bits: a lattice of multiples of 0.2 (0.4 - 0.2 gives an edge, 0.8 - 0.6 does not), movement offsets
+    zeroed so that every world step re-evaluates the rule on the same points.  The expectation is numpy's float64 expression."""
+    from melissa_amd import _lib
+    from melissa_amd.collect import RoundLoop, sample_episode_table
+    from melissa_amd.env import Graph, HipGraphVectorEnv
+    from melissa_amd.networks import LDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    n = 30
+    xs = np.array([0.2 * k for k in range(6)], dtype=np.float64)
+    pos = np.array([[xs[i % 6], xs[i // 6]] for i in range(n)], dtype=np.float64)
+    shifted = pos * 3.0 + 1.0                               # second graph: coordinates up to 4, spacing 0.6 (no edges)
+    near = pos.copy()
+    near[:, 0] += np.linspace(-3e-9, 3e-9, n)               # third: the same lattice perturbed at the 1e-9 level
+    graphs = [Graph.from_positions(p, 0.2) for p in (pos, shifted, near)]
+    venv = HipGraphVectorEnv(env_num=6, number_of_agents=n, graph_pool=graphs, dynamic_graph=True, seed=3, max_moves=8,
+                             device="cuda", construct_like_reference=False)
+    packed, table = sample_episode_table(venv, 6, seed=11)
+    packed["moves"][:] = 0.0
+    net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]}),
+                      device="cuda", backend="hip")
+    loop = RoundLoop(venv, DQNPolicy(net), episodes=(packed, table), seed=11, eps=0.5, use_graph=False)
+    seen = set()
+    for _ in range(12):
+        loop.step()
+        torch.cuda.synchronize()
+        p = venv.positions().cpu().numpy()
+        hop = venv.one_hop().cpu().numpy().view(np.uint64)
+        for b in range(6):
+            dx = p[b, :, None, 0] - p[b, None, :, 0]
+            dy = p[b, :, None, 1] - p[b, None, :, 1]
+            adj = (dx * dx + dy * dy) <= 0.2 ** 2
+            np.fill_diagonal(adj, False)
+            want = (adj.astype(np.uint64) << np.arange(n, dtype=np.uint64)[None, :]).sum(axis=1, dtype=np.uint64)
+            np.testing.assert_array_equal(hop[b, :n], want)
+            seen.add(int(adj.sum()))
+    assert len(seen) >= 2                                    # lattices with and without edges were both exercised
+    # (bit 0 = an episode outlived max_moves - the edgeless lattice does; anything else is a fault)
+    assert int((venv.scalars()[:, _lib.S_ERROR] & ~1).sum()) == 0
