@@ -352,6 +352,13 @@ typedef struct mel_episode_pool {
     const int32_t*  origin;    /* [E]                                                            */
     const double*   moves;     /* [E, max_moves, 2, N] 0.06*U(-1,1): all x then all y (core.py:316-319) */
     const uint64_t* scripted;  /* [E] World.scripted_indices (core.py:197-221), or NULL = no scripted agents */
+    /* Optional reset snapshots (mel_env_round only): HOST pointer to an env batch of >= n_episodes envs in which
+     * mel_env_reset has been run once per episode (env e <- episode e, same dynamic_graph / local_ratio / heuristic /
+     * is_testing settings).  GraphEnv.reset + World.reset are a pure function of the pre-drawn episode, so an env
+     * whose episode ends loads that state instead of recomputing it (positions after the reset's move, one- / two-hop
+     * masks, the source's first transmission); per-env counters and the sticky reward vector are carried over.
+     * NULL: resets are computed in the round kernel. */
+    const struct mel_env_batch* snapshot;
 } mel_episode_pool;
 
 /* Scripted agents (scripted_agents_ratio > 0): the deterministic heuristics of

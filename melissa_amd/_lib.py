@@ -85,7 +85,7 @@ class MelEpisodePool(C.Structure):
     _fields_ = [("n_episodes", C.c_int32), ("n_nodes", C.c_int32), ("max_moves", C.c_int32),
                 ("reserved", C.c_int32), ("pos", C.c_void_p), ("one_hop", C.c_void_p),
                 ("interested", C.c_void_p), ("origin", C.c_void_p), ("moves", C.c_void_p),
-                ("scripted", C.c_void_p)]
+                ("scripted", C.c_void_p), ("snapshot", C.c_void_p)]
 
 
 class MelEnvObs(C.Structure):

@@ -100,7 +100,7 @@ class RoundLoop:
         self.replay = replay                       # optional melissa_amd.replay.RoundReplay
         dev = venv.device
         packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
-        self.pool = venv.load_pool(packed)
+        self.pool = venv.load_pool(packed, reset_snapshots=True)        # episode ends load their next state
         self.table = torch.from_numpy(table).to(dev)
         self.n_actions = policy.model.output_dim
         # HL-DGN's logits do not depend on the agent (hl_dgn.py:108): one row per env, dense action layout

@@ -446,7 +446,22 @@ struct RoundArgs {
     int first;                     // 1: only publish the active set (no step) - used right after a reset
     uint32_t* round_counter;       // optional: rounds played (device), drives the device-side RNG step
     mel_round_replay replay;       // optional (capacity 0 = off)
+    mel_env_batch snap;            // optional reset snapshots (mel_episode_pool::snapshot), env e = episode e after its reset
+    int has_snap;
 };
+
+// GraphEnv.reset from a snapshot: the state env_reset would compute for this episode was computed once when the pool was
+// loaded (same kernel, same settings); what a reset does NOT touch is carried over from the live env.
+__device__ __forceinline__ void env_reset_from_snapshot(const mel_env_batch& e, const mel_env_batch& snap, int b, Env& s,
+                                                        int episode, int lane) {
+    Env t;
+    env_load(snap, episode, lane, t);
+    t.new_round = s.new_round, t.decisions = s.decisions, t.episodes_done = s.episodes_done;
+    t.error = s.error | t.error, t.ep_cursor = s.ep_cursor + 1;
+    t.pz_reward = s.pz_reward;                 // the sticky Tianshou reward vector survives a reset
+    s = t;
+    write_obs_matrix(e, b, s, lane);
+}
 
 #ifdef MEL_ENV_PROF
 // tuning builds: cycles a sample of the env wavefronts spends in [0] state load, [1] the round loop, [2] the env_step call
@@ -541,7 +556,8 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
 #endif
                 log_episode(a.env, b, s, lane);
                 const int ep = uniform_i32(a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)]);
-                env_reset(a.env, a.pool, b, s, ep, 0, lane);
+                if (a.has_snap) env_reset_from_snapshot(a.env, a.snap, b, s, ep, lane);
+                else env_reset(a.env, a.pool, b, s, ep, 0, lane);
                 env_observe(a.env, b, s, none, 0, lane);
 #ifdef MEL_ENV_PROF
                 ENV_MARK(s.sel);
@@ -744,6 +760,14 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     RoundArgs a{};
     a.env = *env, a.pool = *pool, a.actions = actions, a.row_offsets = row_offsets, a.live = live;
     a.episode_table = episode_table, a.table_stride = table_stride, a.first = first, a.round_counter = round_counter;
+    if (pool->snapshot) {
+        const mel_env_batch* sn = pool->snapshot;
+        if (sn->n_nodes != env->n_nodes || sn->n_envs < pool->n_episodes || sn->dynamic_graph != env->dynamic_graph ||
+            sn->heuristic != env->heuristic || sn->is_testing != env->is_testing)
+            return fail(MEL_ERR_INVALID_ARG, "reset snapshots do not fit the env batch / pool");
+        if (mel_status st = check_env(sn, sn->n_envs)) return st;
+        a.snap = *sn, a.has_snap = 1;
+    }
     if (replay) {
         if (replay->capacity < 1 || !replay->obs || !replay->obs_next || !replay->acted || !replay->done ||
             !replay->act || !replay->rew || !replay->episode || !replay->cursor)

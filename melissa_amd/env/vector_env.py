@@ -49,6 +49,7 @@ class DevicePool:
         self.struct.n_episodes = packed["origin"].shape[0]
         self.struct.n_nodes = n
         self.struct.max_moves = packed["moves"].shape[1]
+        self.snapshot_env = self.snapshot_state = None
         self.refresh()
 
     def refresh(self):
@@ -58,7 +59,31 @@ class DevicePool:
         s.origin, s.moves = t["origin"].data_ptr(), t["moves"].data_ptr()
         s.scripted = t["scripted"].data_ptr() if "scripted" in t else None
 
+    def drop_snapshots(self):
+        self.struct.snapshot = None
+        self.snapshot_env = self.snapshot_state = None
+
+    def build_snapshots(self, lib, like_env, stream_ptr):
+        """Reset snapshots (mel_episode_pool.snapshot): run mel_env_reset once per episode into a private env batch with
+        ``like_env``'s settings; mel_env_round then loads an ending env's next episode from there instead of recomputing
+        GraphEnv.reset + World.reset (a pure function of the pre-drawn episode)."""
+        e, n = int(self.struct.n_episodes), int(self.struct.n_nodes)
+        dev = self.tensors["origin"].device
+        self.drop_snapshots()
+        self.snapshot_state = torch.zeros(int(lib.mel_env_state_bytes(e, n)), dtype=torch.uint8, device=dev)
+        env = _lib.MelEnvBatch()
+        for name in ("dynamic_graph", "has_local_ratio", "local_ratio", "heuristic", "is_testing"):
+            setattr(env, name, getattr(like_env, name))
+        _lib.check(lib.mel_env_bind(C.byref(env), e, n, self.snapshot_state.data_ptr()), "mel_env_bind")
+        ids = torch.arange(e, dtype=torch.int32, device=dev)
+        _lib.check(lib.mel_env_reset(C.byref(env), C.byref(self.struct), None, ids.data_ptr(), e, 0, None, stream_ptr),
+                   "mel_env_reset (snapshots)")
+        torch.cuda.synchronize(dev)
+        self.snapshot_env = env                                  # keeps the host struct alive
+        self.struct.snapshot = C.addressof(env)
+
     def write(self, slot_ids: np.ndarray, packed: dict):
+        self.drop_snapshots()                                    # the episodes change: snapshots would be stale
         idx = torch.as_tensor(slot_ids, dtype=torch.long, device=self.tensors["origin"].device)
         for k, v in packed.items():
             src = np.ascontiguousarray(v).view(np.int64) if v.dtype == np.uint64 else np.ascontiguousarray(v)
@@ -298,9 +323,13 @@ class HipGraphVectorEnv:
         return np.array(obs, dtype=object), rew, term, np.array(info, dtype=object)
 
     # ------------------------------------------------------------------ device-resident path
-    def load_pool(self, packed: dict) -> DevicePool:
-        """Upload a pre-sampled episode pool (pack_episodes layout) to HBM."""
-        return DevicePool(packed, self.n, self.device)
+    def load_pool(self, packed: dict, reset_snapshots: bool = False) -> DevicePool:
+        """Upload a pre-sampled episode pool (pack_episodes layout) to HBM.  ``reset_snapshots``: also precompute every
+        episode's post-reset state for mel_env_round (DevicePool.build_snapshots)."""
+        pool = DevicePool(packed, self.n, self.device)
+        if reset_snapshots:
+            pool.build_snapshots(self.lib, self.env, self._stream())
+        return pool
 
     def reset_device(self, pool: DevicePool, episode_ids: torch.Tensor, out: ObsBuffers | None):
         _lib.check(self.lib.mel_env_reset(C.byref(self.env), C.byref(pool.struct), None, episode_ids.data_ptr(),
