@@ -199,6 +199,8 @@ class HipForwardMixin:
         if obs.dtype != torch.float32:
             obs = obs.float()
         bs = obs.shape[0]
+        if bs == 0:             # an empty batch has empty logits (nothing to launch), as the torch ops of the reference give
+            return out if out is not None else torch.empty(0, self.output_dim, dtype=torch.float32, device=obs.device)
         w = self._weights()
         ws = self._workspace(w, bs, obs.device)
         if out is None:

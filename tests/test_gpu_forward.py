@@ -184,6 +184,8 @@ def test_shape_errors_and_no_fallback():
         net(np.zeros((2, 160), np.float32))
     with pytest.raises(RuntimeError, match="no CPU"):
         net.hip_forward(torch.zeros(2, 161))
+    empty, _ = net(np.zeros((0, 161), np.float32))             # empty batch: empty logits, no launch
+    assert empty.shape == (0, 2) and empty.is_cuda
 
 
 def test_non_dueling_head_and_select_action():
