@@ -856,7 +856,7 @@ size_t mel_abi_sizeof(int32_t which) {
         default: return 0;
     }
 }
-const char* mel_version(void) { return "melissa_hip 0.2 (gfx950)"; }
+const char* mel_version(void) { return "melissa_hip 0.3 (gfx950)"; }
 
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {
     if (!w || bs <= 0 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return 0;
