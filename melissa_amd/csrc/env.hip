@@ -39,6 +39,9 @@ struct Env {
     uint64_t one_hop, two_hop;
     int msgs, received, cover;
     int act, cur_act, steps, sel_steps;
+    // not stored: the three wave sums of get_info (graph.py:166-178); they only change in World.step / reset, so the AEC
+    // sub-steps of a round reuse them
+    int info_sent, info_recv, info_nbrs, info_sums_valid;
 };
 
 __device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane, Env& s) {
@@ -67,6 +70,7 @@ __device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane
     s.msgs = on ? e.agent_msgs[k] : 0, s.received = on ? e.received[k] : 0, s.cover = on ? e.two_hop_cover[k] : 0;
     s.act = on ? e.agent_action[k] : NONE, s.cur_act = on ? e.current_actions[k] : NONE;
     s.steps = on ? e.steps_taken[k] : 0, s.sel_steps = on ? e.sel_steps[k] : 0;
+    s.info_sent = s.info_recv = s.info_nbrs = 0, s.info_sums_valid = 0;
 }
 
 __device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lane, const Env& s) {
@@ -136,6 +140,7 @@ __device__ __forceinline__ void selector_enable(Env& s, uint64_t agents, int lan
 __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env& s,
                                            int lane) {
     const int n = e.n_nodes;
+    s.info_sums_valid = 0;                                   // message counters and (dynamic graph) degrees change here
     // :226-234 scripted agents: action = heuristic(agent) (the heuristics offered return no relay mask, so the
     // relays_for pass :236-243 never fires)
     // (no heuristic: Agent.action_callback stays None, World.scripted_agents is empty, nothing is overridden)
@@ -226,11 +231,15 @@ __device__ __forceinline__ double agent_reward(const Env& s) {
 }
 
 // graph.py:149-179 -> infos[agent]['logger_stats'] (10 float64 in dict order)
-__device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, int agent, const Env& s, int lane) {
+__device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, int agent, Env& s, int lane) {
     const int n = e.n_nodes;
-    const int sent = wave_sum_i32(lane < n ? s.msgs : 0);
-    const int recv = wave_sum_i32(lane < n ? s.received : 0);
-    const int nbrs = wave_sum_i32(lane < n ? __popcll(s.one_hop) : 0);
+    if (!s.info_sums_valid) {
+        s.info_sent = wave_sum_i32(lane < n ? s.msgs : 0);
+        s.info_recv = wave_sum_i32(lane < n ? s.received : 0);
+        s.info_nbrs = wave_sum_i32(lane < n ? __popcll(s.one_hop) : 0);
+        s.info_sums_valid = 1;
+    }
+    const int sent = s.info_sent, recv = s.info_recv, nbrs = s.info_nbrs;
     if (lane == 0) {
         double* st = e.info_stats + ((size_t)b * n + agent) * MEL_ENV_LOGGER_STATS;
         const int n_int = __popcll(s.interested);
