@@ -39,9 +39,10 @@ struct Env {
     uint64_t one_hop, two_hop;
     int msgs, received, cover;
     int act, cur_act, steps, sel_steps;
-    // not stored: the three wave sums of get_info (graph.py:166-178); they only change in World.step / reset, so the AEC
-    // sub-steps of a round reuse them
-    int info_sent, info_recv, info_nbrs, info_sums_valid;
+    // not stored: get_info's ten values (graph.py:166-178), lane k holds value k; they only change in World.step / reset, so
+    // the AEC sub-steps of a round reuse them (three wave sums and two float64 divisions once instead of per sub-step)
+    double info_val;
+    int info_valid_cache;
 };
 
 __device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane, Env& s) {
@@ -70,7 +71,7 @@ __device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane
     s.msgs = on ? e.agent_msgs[k] : 0, s.received = on ? e.received[k] : 0, s.cover = on ? e.two_hop_cover[k] : 0;
     s.act = on ? e.agent_action[k] : NONE, s.cur_act = on ? e.current_actions[k] : NONE;
     s.steps = on ? e.steps_taken[k] : 0, s.sel_steps = on ? e.sel_steps[k] : 0;
-    s.info_sent = s.info_recv = s.info_nbrs = 0, s.info_sums_valid = 0;
+    s.info_val = 0.0, s.info_valid_cache = 0;
 }
 
 __device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lane, const Env& s) {
@@ -140,7 +141,7 @@ __device__ __forceinline__ void selector_enable(Env& s, uint64_t agents, int lan
 __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env& s,
                                            int lane) {
     const int n = e.n_nodes;
-    s.info_sums_valid = 0;                                   // message counters and (dynamic graph) degrees change here
+    s.info_valid_cache = 0;                                  // message counters, coverage and (dynamic graph) degrees change here
     // :226-234 scripted agents: action = heuristic(agent) (the heuristics offered return no relay mask, so the
     // relays_for pass :236-243 never fires)
     // (no heuristic: Agent.action_callback stays None, World.scripted_agents is empty, nothing is overridden)
@@ -233,28 +234,28 @@ __device__ __forceinline__ double agent_reward(const Env& s) {
 // graph.py:149-179 -> infos[agent]['logger_stats'] (10 float64 in dict order)
 __device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, int agent, Env& s, int lane) {
     const int n = e.n_nodes;
-    if (!s.info_sums_valid) {
-        s.info_sent = wave_sum_i32(lane < n ? s.msgs : 0);
-        s.info_recv = wave_sum_i32(lane < n ? s.received : 0);
-        s.info_nbrs = wave_sum_i32(lane < n ? __popcll(s.one_hop) : 0);
-        s.info_sums_valid = 1;
-    }
-    const int sent = s.info_sent, recv = s.info_recv, nbrs = s.info_nbrs;
-    if (lane == 0) {
-        double* st = e.info_stats + ((size_t)b * n + agent) * MEL_ENV_LOGGER_STATS;
+    if (!s.info_valid_cache) {
+        const int sent = wave_sum_i32(lane < n ? s.msgs : 0);
+        const int recv = wave_sum_i32(lane < n ? s.received : 0);
+        const int nbrs = wave_sum_i32(lane < n ? __popcll(s.one_hop) : 0);
         const int n_int = __popcll(s.interested);
         const int cov_int = __popcll(s.has_msg & s.interested);
-        st[0] = (double)s.world_msgs;
-        st[1] = (double)__popcll(s.has_msg) / (double)n;
-        st[2] = (double)sent;
-        st[3] = (double)recv;
-        st[4] = (double)nbrs;
-        st[5] = (double)n_int;
-        st[6] = n_int > 0 ? (double)cov_int / (double)n_int : 0.0;
-        st[7] = (double)cov_int;
-        st[8] = (double)__popcll(s.has_msg & ~s.interested);
-        st[9] = s.episode_rewards;
+        const double st1 = (double)__popcll(s.has_msg) / (double)n;
+        const double st6 = n_int > 0 ? (double)cov_int / (double)n_int : 0.0;
+        double v = (double)s.world_msgs;                                   // lane 0
+        v = lane == 1 ? st1 : v;
+        v = lane == 2 ? (double)sent : v;
+        v = lane == 3 ? (double)recv : v;
+        v = lane == 4 ? (double)nbrs : v;
+        v = lane == 5 ? (double)n_int : v;
+        v = lane == 6 ? st6 : v;
+        v = lane == 7 ? (double)cov_int : v;
+        v = lane == 8 ? (double)__popcll(s.has_msg & ~s.interested) : v;
+        v = lane == 9 ? s.episode_rewards : v;
+        s.info_val = v;
+        s.info_valid_cache = 1;
     }
+    if (lane < MEL_ENV_LOGGER_STATS) e.info_stats[((size_t)b * n + agent) * MEL_ENV_LOGGER_STATS + lane] = s.info_val;
 }
 
 // one row of the episode log: the logger_stats of the final observation of the episode that just ended
