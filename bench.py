@@ -226,6 +226,8 @@ def main():
                     help="f32 (default): the reference's arithmetic, logits within 1e-4.  bf16: BASELINE's 'bf16 feature "
                          "path' (feature rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true",
+                    help="skip the second timed pass of the default (fp32) run on BASELINE's 'bf16 feature path'")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
@@ -383,6 +385,33 @@ def main():
                  "env_only_agent_steps_per_s": (args.envs / (stages["env_step"] * 1e-6)
                                                 if args.mode == "aec" and stages.get("env_step", 0) > 0 else None)}
 
+    # ---- second timed pass: the same workload on BASELINE configs[2]'s "bf16 feature path" -------------------------
+    # `value` stays the fp32 number (logits within the 1e-4 parity bar); this leg records, in the same line, the rate of
+    # the configuration as BASELINE.json words it (feature rows + projection weights bf16, fp32 accumulate / softmax /
+    # logits; logits within 5e-4 of fp32, greedy actions identical on every test row).  Same barriers, same counters.
+    bf16_leg = None
+    if (args.dtype == "f32" and args.mode == "round" and args.streams == 1 and args.model == "l_dgn"
+            and not args.no_bf16_leg):
+        del loop, venv
+        net2, venv2, loop2 = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph,
+                                            1, dtype="bf16")
+        loop2.run(args.warmup)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        b0 = loop2.counters()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        t0 = time.perf_counter()
+        loop2.run(args.steps)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dt2 = parallel.all_reduce_max(time.perf_counter() - t0, device)
+        b1 = loop2.counters()
+        dec2 = parallel.all_reduce_sum(float(b1["decisions"] - b0["decisions"]), device)
+        bf16_leg = {"dtype": "bf16", "value": dec2 / dt2, "unit": "agent-decisions/s", "ms_per_step": dt2 / args.steps * 1e3,
+                    "note": "same workload on BASELINE's 'bf16 feature path' (feature rows + projection weights bf16, fp32 "
+                            "accumulate / softmax / logits; logits within 5e-4 of the fp32 path)"}
+
     parallel.barrier()
     if rank != 0:
         return
@@ -404,6 +433,7 @@ def main():
                    "decisions_per_step": decisions / args.steps, "live_decisions": decisions, "episodes_finished": episodes,
                    "env_error_flags": errors},
         "roofline": roofline,
+        "bf16_feature_path": bf16_leg,
         "stage_us": {k: round(v, 2) for k, v in (stages or {}).items() if v > 0},
         "parts": parts,
         "roofline_hbm": hbm_rooflines,
