@@ -10,7 +10,7 @@ for SET in "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-profile --no-graph > /dev/null 2> $OUT/p$i.log || echo "pass $i failed"
+  rocprofv3 --pmc $SET -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-extra-legs --no-profile --no-graph > /dev/null 2> $OUT/p$i.log || echo "pass $i failed"
 done
 cd $ROOT
 python3 - <<'PY'

@@ -1,5 +1,5 @@
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, MI355X_MICROARCH.md section HBM) of
-    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-graph
+    python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-profile --no-graph
 into profiles/<name>_pmc_traffic.json: HBM-side bytes per launch of the grouped GEMM launches of the round step.
 gfx950 correction: FETCH_SIZE tallies 128-B requests at 64 B -> doubled; both counters are in KiB.
 
@@ -26,7 +26,7 @@ def mean_counter(directory, counter, needle):
 
 
 def main():
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 "
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 --no-extra-legs "
                       "--no-cpu-baseline --no-profile --no-graph",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
                          "MI355X_MICROARCH.md section HBM)",

@@ -7,9 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-graph > $OUT/bench_line_nograph.json 2> $OUT/stats.log
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-graph > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile --no-graph > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra-legs --no-graph > $OUT/bench_line_nograph.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-profile --no-graph > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-profile --no-graph > /dev/null 2> $OUT/pmc_write.log
 cd $ROOT
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_round_kernel_stats.csv
