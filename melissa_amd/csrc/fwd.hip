@@ -815,6 +815,17 @@ using namespace mel;
 extern "C" {
 
 const char* mel_last_error(void) { return g_err; }
+// tuning builds only (-DMEL_FIN_PROF): read and reset the head finish kernel's cycle counters
+void mel_debug_fin_prof(unsigned long long* out5) {
+#ifdef MEL_FIN_PROF
+    (void)hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_fin_prof), 5 * sizeof(unsigned long long));
+    unsigned long long z[5] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fin_prof), z, sizeof(z));
+#else
+    for (int i = 0; i < 5; ++i) out5[i] = 0;
+#endif
+}
+
 #ifdef MEL_RING_PROF
 // tuning builds only (-DMEL_RING_PROF=<tag>): read and reset the ring kernel's in-kernel cycle counters (tools/ring_prof.py)
 void mel_debug_ring_prof(unsigned long long* out8) {

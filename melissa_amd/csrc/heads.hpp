@@ -138,9 +138,18 @@ struct HeadFinish {
     mel_select sel;
     int likely_blocks;                     // workgroups below this index expect rows: they fetch W1 before the row count is known
 };
+#ifdef MEL_FIN_PROF
+// tuning builds: cycles of wave 0 of the busy workgroups from kernel start to [0] first barrier (operands fetched, h0 in LDS),
+// [1] second barrier (hidden layer 1 done), [2] end; [3] workgroups counted; [4] kernel start to the row count known
+__device__ unsigned long long g_fin_prof[5];
+#endif
 template <int MB>
 __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
     constexpr int HF_ROWS = 16 * MB;
+#ifdef MEL_FIN_PROF
+    const unsigned long long fp0 = __builtin_readcyclecounter();
+    unsigned long long fp1 = fp0, fp2 = fp0, fpr = fp0;
+#endif
     __shared__ __attribute__((aligned(16))) float h0[HF_ROWS * HF_LD];
     __shared__ __attribute__((aligned(16))) float h1[HF_ROWS * HF_LD];
     __shared__ float wl[(HF_MAX_ACTIONS + 1) * HF_W + HF_MAX_ACTIONS + 1];        // last-layer weights + biases
@@ -158,6 +167,10 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
     // must not pull its 128 KB of W1 through the L2 before it finds out that it has nothing to do
     const bool likely = (int)blockIdx.x < f.likely_blocks;
     if (!likely && (int)blockIdx.x * HF_ROWS >= rows) return;
+#ifdef MEL_FIN_PROF
+    asm volatile("s_nop 0" ::"s"(rows));
+    fpr = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         wf[0][t] = *reinterpret_cast<const f32x4*>(wrow0 + 16 * t);
@@ -190,6 +203,9 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
                 f32x4{fmaxf(acc[0] + b[0], 0.f), fmaxf(acc[1] + b[1], 0.f), fmaxf(acc[2] + b[2], 0.f), fmaxf(acc[3] + b[3], 0.f)};
         }
         __syncthreads();
+#ifdef MEL_FIN_PROF
+        fp1 = __builtin_readcyclecounter();
+#endif
         // 2. hidden layer 1: this wave's (16 MB) x 32 block (two 16 x 16 accumulators per row block) over K = 128
         f32x4_acc acc0[MB], acc1[MB];
 #pragma unroll
@@ -217,6 +233,9 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
                 dst[16] = fmaxf(acc1[mb][e] + b1_1, 0.f);
             }
         __syncthreads();
+#ifdef MEL_FIN_PROF
+        fp2 = __builtin_readcyclecounter();
+#endif
         // 3. last layer + dueling combine + selection: 16 threads per row
         if (trow < HF_ROWS) {
             const float* hq = h1 + trow * HF_LD;
@@ -261,6 +280,13 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
         // no barrier here: the next iteration's h0 writes come after this one's h0 reads (barrier 2 above), and its h1 writes
         // come after its own barrier 1, which no wave passes before it has finished these h1 reads
     }
+#ifdef MEL_FIN_PROF
+    if (tid == 0 && (int)blockIdx.x * HF_ROWS < rows) {
+        const unsigned long long fp3 = __builtin_readcyclecounter();
+        atomicAdd(&g_fin_prof[0], fp1 - fp0), atomicAdd(&g_fin_prof[1], fp2 - fp0), atomicAdd(&g_fin_prof[2], fp3 - fp0);
+        atomicAdd(&g_fin_prof[3], 1ull), atomicAdd(&g_fin_prof[4], fpr - fp0);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
