@@ -101,8 +101,9 @@ typedef struct mel_weights {
     mel_mlp   q_head;      /* latent -> ... -> n_actions                             */
     mel_mlp   v_head;      /* latent -> ... -> 1                                     */
     int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4), MEL_PREC_BF16 or MEL_PREC_F32_SPLIT */
-    int32_t reserved;
+    int32_t flags;         /* MEL_FWD_PLAN_READY: the plan masks of this call were written by mel_env_round (plan_* sink) */
 } mel_weights;
+#define MEL_FWD_PLAN_READY 1
 
 /* Feature precision of the L-DGN / DGN-R forward (BASELINE config "bf16 feature path").  MEL_PREC_BF16: the
  * node-feature rows between layers (encoder output, lin_l / lin_r projections, conv outputs, head input and
@@ -154,6 +155,11 @@ typedef struct mel_select {
 } mel_select;
 
 size_t mel_workspace_bytes_agents(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap);
+/* Where, inside `workspace`, a forward of these dimensions keeps its plan masks (rows_cap = 0: the single-agent / HL-DGN
+ * layout of mel_workspace_bytes): out5 = {adj, live, u1, u2, cnt} (u1 / u2 / cnt NULL for HL-DGN) - the values for
+ * mel_env_batch.plan_*. */
+mel_status mel_plan_pointers(const mel_weights* w, int64_t bs, int32_t n_nodes, int64_t rows_cap, void* workspace,
+                             void** out5);
 mel_status mel_ldgn_forward_agents(const mel_weights* w, const float* obs, int64_t bs, int32_t n_nodes,
                                    int32_t obs_stride, const uint64_t* agent_mask, int64_t rows_cap,
                                    float* logits, int32_t* row_offsets, const mel_select* select,
@@ -337,6 +343,16 @@ typedef struct mel_env_batch {
     int32_t*  log_cursor;      /* [1]  episodes logged so far (device, atomically advanced)      */
     double*   log_stats;       /* [capacity, 10]                                                 */
     int32_t*  log_meta;        /* [capacity, 3] env, pool episode, num_moves                     */
+    /* Optional forward-plan sink (mel_env_round only; all NULL = off): device pointers into the forward workspace the
+     * NEXT mel_*_forward_agents / mel_hldgn_forward_envs call will use (mel_plan_pointers).  The round kernel then also
+     * writes what that forward's first launch would compute from the obs it just wrote and the next active sets -
+     * the fp32 radius-graph adjacency (networks/common.py:48) and, for L-DGN / DGN-R, the agent / one-hop / two-hop
+     * node sets and their sizes - and the forward is called with MEL_FWD_PLAN_READY in mel_weights.flags. */
+    uint64_t* plan_adj;        /* [B*N] */
+    uint64_t* plan_live;       /* [B]   (NULL for HL-DGN: adjacency only) */
+    uint64_t* plan_u1;         /* [B]   */
+    uint64_t* plan_u2;         /* [B]   */
+    int32_t*  plan_cnt;        /* [3*B] */
 } mel_env_batch;
 
 /* An episode pool: what World.reset samples (core.py:372-394), pre-drawn on the host with the

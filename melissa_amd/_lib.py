@@ -21,12 +21,14 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
 
 # every symbol include/melissa_hip.h declares
 EXPORTS = ("mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
-           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
 PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
+FWD_PLAN_READY = 1          # mel_weights.flags: the plan masks of this call were written by mel_env_round
+FWD_PLAN_READY = 1
 HEURISTICS = {None: 0, "simple_broadcast": 1, "broadcast_if_any_interested": 2, "silent": 3}
 LOGGER_KEYS = ("total_messages_transmitted", "coverage", "messages_sent", "messages_received", "n_neighbours",
                "interested_agents", "coverage_interested_fraction", "coverage_interested_count",
@@ -53,7 +55,7 @@ class MelMlp(C.Structure):
 class MelWeights(C.Structure):
     _fields_ = [("model", C.c_int32), ("in_dim", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32),
                 ("encoder", MelMlp), ("conv1", MelGatv2), ("conv2", MelGatv2), ("q_head", MelMlp),
-                ("v_head", MelMlp), ("precision", C.c_int32), ("reserved", C.c_int32)]
+                ("v_head", MelMlp), ("precision", C.c_int32), ("flags", C.c_int32)]
 
 
 class MelSelect(C.Structure):
@@ -78,7 +80,9 @@ class MelEnvBatch(C.Structure):
                 ("sel_steps", C.c_void_p), ("rewards", C.c_void_p), ("pz_rewards", C.c_void_p),
                 ("episode_rewards", C.c_void_p), ("obs_matrix", C.c_void_p), ("info_stats", C.c_void_p),
                 ("log_capacity", C.c_int32), ("log_reserved", C.c_int32), ("log_cursor", C.c_void_p),
-                ("log_stats", C.c_void_p), ("log_meta", C.c_void_p)]
+                ("log_stats", C.c_void_p), ("log_meta", C.c_void_p),
+                ("plan_adj", C.c_void_p), ("plan_live", C.c_void_p), ("plan_u1", C.c_void_p), ("plan_u2", C.c_void_p),
+                ("plan_cnt", C.c_void_p)]
 
 
 class MelEpisodePool(C.Structure):
@@ -157,6 +161,8 @@ def load(build_if_missing: bool = True):
     lib.mel_pool_backward.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
     lib.mel_hldgn_forward_envs.restype = i32
     lib.mel_hldgn_forward_envs.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_plan_pointers.restype = i32
+    lib.mel_plan_pointers.argtypes = [W, i64, i32, i64, vp, C.POINTER(C.c_void_p)]
     lib.mel_hldgn_forward_envs_select.restype = i32
     lib.mel_hldgn_forward_envs_select.argtypes = [W, i32, vp, i64, i32, i32, vp, C.POINTER(MelSelect), vp, sz, vp]
     lib.mel_select_action_envs.restype = i32

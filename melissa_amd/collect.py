@@ -122,9 +122,19 @@ class RoundLoop:
         # own forward scratch: several loops may share one network on different streams
         self.workspace = torch.empty(policy.model.agents_workspace_bytes(venv.env_num, self.rows_cap),
                                      dtype=torch.uint8, device=dev)
+        # the env round also writes the plan masks of the next forward into this workspace (mel_env_batch.plan_*): one
+        # launch less per round
+        self._plan = policy.model.plan_pointers(venv.env_num, 0 if self.per_env_logits else self.rows_cap, self.workspace)
         venv.reset_device(self.pool, self.table[:, 0].contiguous(), None)
+        self._bind_plan()
         venv.round_device(self.pool, None, None, self.live, None, first=True)
         torch.cuda.synchronize(dev)
+
+    def _bind_plan(self):
+        """Point the venv's plan sink at THIS loop's workspace (cheap; done before every launch because the struct belongs to
+        the venv and another loop may have used it in between)."""
+        e = self.venv.env
+        e.plan_adj, e.plan_live, e.plan_u1, e.plan_u2, e.plan_cnt = self._plan
 
     def _launch(self):
         """The fixed launch sequence of one round (no host reads, no allocation: capturable)."""
@@ -134,13 +144,16 @@ class RoundLoop:
         if self.per_env_logits:
             # forward + per-(env, agent) argmax / eps-greedy in the launch that writes the logits (same stream of draws as
             # mel_select_action_envs)
-            net.hip_forward_envs(self._obs_matrix, out=self.logits, workspace=self.workspace, select=self._select)
+            net.hip_forward_envs(self._obs_matrix, out=self.logits, workspace=self.workspace, select=self._select,
+                                 plan_ready=True)
+            self._bind_plan()
             self.venv.round_device(self.pool, self.act, None, self.live, self.table, round_counter=self.rounds,
                                    replay=self.replay)
             return
         # forward + fused argmax / eps-greedy (the dueling tail writes the action next to the logits)
         net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets,
-                               select=self._select, workspace=self.workspace)
+                               select=self._select, workspace=self.workspace, plan_ready=True)
+        self._bind_plan()
         self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds,
                                replay=self.replay)
 

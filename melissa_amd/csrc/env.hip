@@ -13,6 +13,7 @@
 //   [3P] AECEnv._deads_step_first / _was_dead_step, tianshou PettingZooEnv.step
 // Scripted agents run the deterministic heuristics of heuristics/core.py (MEL_HEURISTIC_*).
 #include "common.hpp"
+#include "plan_masks.hpp"
 
 namespace mel {
 
@@ -585,6 +586,14 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     // agents that will act in the coming round: exactly the selector's active set (selector.py:22-34,43-44)
     if (lane == 0) a.live[b] = s.sel_active;
     env_store(a.env, b, lane, s);
+    // optional plan sink: what the next forward's plan_masks launch would compute from the obs this launch wrote (the
+    // obs positions are (float)px, (float)py: write_obs_matrix) and the active set it just published
+    if (a.env.plan_adj) {
+        const uint64_t full = (n == 64) ? ~0ull : (bit(n) - 1ull);
+        const float x = lane < n ? (float)s.px : 0.f, y = lane < n ? (float)s.py : 0.f;
+        plan_masks_env(x, y, s.sel_active & full, a.env.plan_u1 ? 1 : -1, b, a.env.n_envs, n, lane,
+                       PlanSink{a.env.plan_adj, a.env.plan_live, a.env.plan_u1, a.env.plan_u2, a.env.plan_cnt});
+    }
 #ifdef MEL_ENV_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long p3 = ENV_T();
@@ -719,6 +728,8 @@ mel_status mel_env_bind(mel_env_batch* env, int32_t n_envs, int32_t n_nodes, voi
     env->dynamic_graph = dyn, env->has_local_ratio = hlr, env->local_ratio = lr, env->heuristic = heu, env->is_testing = tst;
     env->log_capacity = keep.log_capacity, env->log_cursor = keep.log_cursor, env->log_stats = keep.log_stats,
     env->log_meta = keep.log_meta;
+    env->plan_adj = keep.plan_adj, env->plan_live = keep.plan_live, env->plan_u1 = keep.plan_u1, env->plan_u2 = keep.plan_u2,
+    env->plan_cnt = keep.plan_cnt;
     return MEL_OK;
 }
 
@@ -766,6 +777,8 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     if (!live) return fail(MEL_ERR_INVALID_ARG, "live mask buffer is null");
     if (!first && (!actions || !episode_table || table_stride < 1))
         return fail(MEL_ERR_INVALID_ARG, "round step needs actions and an episode table");
+    if (env->plan_adj && env->plan_u1 && (!env->plan_live || !env->plan_u2 || !env->plan_cnt))
+        return fail(MEL_ERR_INVALID_ARG, "incomplete plan sink (plan_live / plan_u2 / plan_cnt)");
     clear_stale_error();
     RoundArgs a{};
     a.env = *env, a.pool = *pool, a.actions = actions, a.row_offsets = row_offsets, a.live = live;

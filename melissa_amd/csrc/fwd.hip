@@ -732,8 +732,12 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
-        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
-        if (mel_status st = check_launch("plan_masks")) return st;
+        if (w->flags & MEL_FWD_PLAN_READY) {       // mel_env_round's plan sink wrote the masks of this call
+            if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "MEL_FWD_PLAN_READY needs the agent-set entry points");
+        } else {
+            hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
+            if (mel_status st = check_launch("plan_masks")) return st;
+        }
         const int inline_scan = bs <= 8192;           // beyond that the per-wave re-scan (O(bs^2 / 64) loads) loses
         if (!inline_scan) {
             hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
@@ -939,9 +943,11 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     {
         StageScope t(MEL_STAGE_PLAN, s);
         // hl_dgn.py:108 pools over the whole graph: the controlling index is read (and clamped) but unused
-        hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
-                           (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
-        if (mel_status st = check_launch("plan_masks")) return st;
+        if (!((w->flags & MEL_FWD_PLAN_READY) && !index_col)) {      // (else: written by mel_env_round's plan sink)
+            hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
+                               (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
+            if (mel_status st = check_launch("plan_masks")) return st;
+        }
     }
     {
         GemmArgs g;
@@ -983,6 +989,17 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,
                                   int32_t obs_stride, float* logits, void* workspace, size_t ws_bytes, void* stream) {
     return hldgn_forward_impl(w, aggregator, obs, bs, n, obs_stride, false, logits, workspace, ws_bytes, stream);
+}
+
+mel_status mel_plan_pointers(const mel_weights* w, int64_t bs, int32_t n, int64_t rows_cap, void* workspace, void** out5) {
+    if (!w || !workspace || !out5 || bs <= 0 || n < 1 || n > MEL_MAX_NODES || rows_cap < 0)
+        return fail(MEL_ERR_INVALID_ARG, "bad mel_plan_pointers arguments");
+    const bool single = rows_cap == 0;
+    const FwdLayout L = carve(w, make_dims(bs, n, single ? bs : rows_cap, single), workspace);
+    const bool hl = w->model == MEL_MODEL_HLDGN;
+    out5[0] = L.plan.adj, out5[1] = hl ? nullptr : (void*)L.plan.live;
+    out5[2] = hl ? nullptr : (void*)L.plan.u1, out5[3] = hl ? nullptr : (void*)L.plan.u2, out5[4] = hl ? nullptr : (void*)L.plan.cnt;
+    return MEL_OK;
 }
 
 mel_status mel_hldgn_forward_envs_select(const mel_weights* w, int32_t aggregator, const float* obs, int64_t bs, int32_t n,

@@ -2,6 +2,7 @@
 // descriptors (networks/common.py:6-64; the row lists serve l_dgn.py:117-135).  Included by fwd.hip.
 #pragma once
 #include "common.hpp"
+#include "plan_masks.hpp"
 
 namespace mel {
 
@@ -46,22 +47,6 @@ struct PlanBuffers {
     float* dm_g;        // [R]
 };
 
-// [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
-// positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
-// the first 33 hits in index order (self included) survive, then self is dropped.
-__device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
-    const float r2 = (float)(0.2 * 0.2);
-    uint64_t m = 0;
-    for (int j = 0; j < n; ++j) {
-        const float xj = lane_f32(x, j), yj = lane_f32(y, j);     // j is the loop counter: v_readlane
-        const float dx = x - xj, dy = y - yj;
-        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-        if (d2 < r2) m |= 1ull << j;
-    }
-    while (__popcll(m) > 33) m &= ~(1ull << (63 - __clzll((long long)m)));
-    return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
-}
-
 // standalone adjacency for the learn path (one wave per observation row)
 __global__ __launch_bounds__(256) void radius_graph_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
                                                            int node_cols, uint64_t* __restrict__ adj) {
@@ -91,34 +76,18 @@ __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict
         x = row[lane * node_cols];
         y = row[lane * node_cols + 1];
     }
-    const uint64_t src = radius_sources(x, y, lane, n);
-    if (lane < n) p.adj[(size_t)b * n + lane] = src;
     const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-    uint64_t live;
-    if (want_receptive < 0) {              // adjacency only: the row has no index column
-        return;
-    } else if (agent_mask) {
-        live = agent_mask[b] & full;
-    } else {                               // obs[:, -1].clamp(0, N-1).long()
-        float gf = row[n * node_cols];
-        gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
-        live = 1ull << (int)gf;
+    uint64_t live = 0;
+    if (want_receptive >= 0) {
+        if (agent_mask) {
+            live = agent_mask[b] & full;
+        } else {                               // obs[:, -1].clamp(0, N-1).long()
+            float gf = row[n * node_cols];
+            gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
+            live = 1ull << (int)gf;
+        }
     }
-    if (!want_receptive) {
-        if (lane == 0) p.live[b] = live;
-        return;
-    }
-    const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
-    const uint64_t u1 = wave_or_u64(((live >> lane) & 1ull) ? closed : 0ull);
-    const uint64_t u2 = wave_or_u64(((u1 >> lane) & 1ull) ? closed : 0ull);
-    if (lane == 0) {
-        p.live[b] = live;
-        p.u1[b] = u1;
-        p.u2[b] = u2;
-        p.cnt[b] = __popcll(live);
-        p.cnt[bs + b] = __popcll(u1);
-        p.cnt[2 * bs + b] = __popcll(u2);
-    }
+    plan_masks_env(x, y, live, want_receptive, b, bs, n, lane, PlanSink{p.adj, p.live, p.u1, p.u2, p.cnt});
 }
 
 // exclusive scans of |L|, |U1|, |U2| over the batch (single workgroup, any bs)

@@ -1,0 +1,57 @@
+// Device functions behind the forward's plan masks (fp32 radius adjacency; agent / one-hop / two-hop node sets), shared by
+// plan_masks_kernel (plan.hpp, fwd.hip) and the env round kernel's plan sink (env.hip, mel_env_batch.plan_*).  No kernels
+// here: the header is included by two translation units.
+#pragma once
+#include "common.hpp"
+
+namespace mel {
+
+// [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
+// positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
+// the first 33 hits in index order (self included) survive, then self is dropped.
+__device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
+    const float r2 = (float)(0.2 * 0.2);
+    uint64_t m = 0;
+    for (int j = 0; j < n; ++j) {
+        const float xj = lane_f32(x, j), yj = lane_f32(y, j);     // j is the loop counter: v_readlane
+        const float dx = x - xj, dy = y - yj;
+        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        if (d2 < r2) m |= 1ull << j;
+    }
+    while (__popcll(m) > 33) m &= ~(1ull << (63 - __clzll((long long)m)));
+    return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
+}
+
+// the plan masks of one env from its fp32 node positions (lane = node) and its agent set; want_receptive < 0: adjacency
+// only (HL-DGN), 0: adjacency + agent set, 1: + one- / two-hop sets and sizes.  Shared by plan_masks_kernel and the env
+// round kernel's plan sink (mel_env_batch.plan_*), which therefore write bit-identical buffers.
+struct PlanSink {
+    uint64_t* adj;
+    uint64_t* live;
+    uint64_t* u1;
+    uint64_t* u2;
+    int32_t* cnt;
+};
+__device__ __forceinline__ void plan_masks_env(float x, float y, uint64_t live, int want_receptive, int b, int bs, int n,
+                                               int lane, const PlanSink& p) {
+    const uint64_t src = radius_sources(x, y, lane, n);
+    if (lane < n) p.adj[(size_t)b * n + lane] = src;
+    if (want_receptive < 0) return;
+    if (!want_receptive) {
+        if (lane == 0) p.live[b] = live;
+        return;
+    }
+    const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
+    const uint64_t u1 = wave_or_u64(((live >> lane) & 1ull) ? closed : 0ull);
+    const uint64_t u2 = wave_or_u64(((u1 >> lane) & 1ull) ? closed : 0ull);
+    if (lane == 0) {
+        p.live[b] = live;
+        p.u1[b] = u1;
+        p.u2[b] = u2;
+        p.cnt[b] = __popcll(live);
+        p.cnt[bs + b] = __popcll(u1);
+        p.cnt[2 * bs + b] = __popcll(u2);
+    }
+}
+
+}  // namespace mel

@@ -235,8 +235,17 @@ class HipForwardMixin:
                                        _lib.current_stream_ptr(ws.device)), "mel_forward_tap")
         return out
 
+    def plan_pointers(self, bs: int, rows_cap: int, workspace: torch.Tensor):
+        """Device addresses (adj, live, u1, u2, cnt) of the plan masks inside ``workspace`` for a forward of these dimensions
+        (``rows_cap`` = 0: the hip_forward / hip_forward_envs layout) - the values of mel_env_batch.plan_*."""
+        out = (C.c_void_p * 5)()
+        _lib.check(_lib.load().mel_plan_pointers(C.byref(self._weights()), bs, self.agents_num, rows_cap, workspace.data_ptr(),
+                                                 out), "mel_plan_pointers")
+        return [out[i] for i in range(5)]
+
     def hip_forward_envs(self, obs_matrix: torch.Tensor, out: torch.Tensor | None = None,
-                         workspace: torch.Tensor | None = None, select: "_lib.MelSelect | None" = None) -> torch.Tensor:
+                         workspace: torch.Tensor | None = None, select: "_lib.MelSelect | None" = None,
+                         plan_ready: bool = False) -> torch.Tensor:
         """HL-DGN on env rows without an index column (round-batched loop): one logits row per env.  ``select`` (with
         ``live`` / ``n_nodes`` set): the per-(env, agent) argmax / eps-greedy fused into the launch that writes the logits."""
         if self._MODEL != _lib.MODEL_HLDGN:
@@ -248,15 +257,18 @@ class HipForwardMixin:
         ws = workspace if workspace is not None else self._workspace(w, bs, obs_matrix.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
+        w.flags = _lib.FWD_PLAN_READY if plan_ready else 0        # (the struct is cached: always set, never left behind)
         if select is not None:
             st = lib.mel_hldgn_forward_envs_select(C.byref(w), _lib.AGG[self.aggregator_name], obs_matrix.data_ptr(), bs,
                                                    self.agents_num, obs_matrix.stride(0), out.data_ptr(), C.byref(select),
                                                    ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+            w.flags = 0
             _lib.check(st, "mel_hldgn_forward_envs_select")
             return out
         st = lib.mel_hldgn_forward_envs(C.byref(w), _lib.AGG[self.aggregator_name], obs_matrix.data_ptr(), bs,
                                         self.agents_num, obs_matrix.stride(0), out.data_ptr(), ws.data_ptr(),
                                         ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+        w.flags = 0
         _lib.check(st, "mel_hldgn_forward_envs")
         return out
 
@@ -267,7 +279,8 @@ class HipForwardMixin:
 
     def hip_forward_agents(self, obs_matrix: torch.Tensor, agent_mask: torch.Tensor, rows_cap: int,
                            out: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None,
-                           select: "_lib.MelSelect | None" = None, workspace: torch.Tensor | None = None):
+                           select: "_lib.MelSelect | None" = None, workspace: torch.Tensor | None = None,
+                           plan_ready: bool = False):
         """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
         [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
         patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
@@ -292,9 +305,11 @@ class HipForwardMixin:
         if row_offsets is None:
             row_offsets = torch.empty(bs + 1, dtype=torch.int32, device=obs_matrix.device)
         fn = lib.mel_ldgn_forward_agents if self._MODEL == _lib.MODEL_LDGN else lib.mel_dgnr_forward_agents
+        w.flags = _lib.FWD_PLAN_READY if plan_ready else 0        # mel_env_round's plan sink wrote this call's masks
         st = fn(C.byref(w), obs_matrix.data_ptr(), bs, self.agents_num, obs_matrix.stride(0), agent_mask.data_ptr(),
                 rows_cap, out.data_ptr(), row_offsets.data_ptr(), C.byref(select) if select is not None else None,
                 ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
+        w.flags = 0
         _lib.check(st, "mel_ldgn_forward_agents")
         return out, row_offsets
 
