@@ -120,14 +120,18 @@ __device__ __forceinline__ int wave_sum_i32_dpp(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// OR of a 64-bit value over the wave: the DPP butterfly of wave_sum_i32_dpp on each half, then four readlanes
+__device__ __forceinline__ uint32_t wave_or_u32_dpp(uint32_t u) {
+    int v = (int)u;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return (uint32_t)(__builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) |
+                      __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48));
+}
 __device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)v, o, 64);
-        uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
-        v |= ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+    return ((uint64_t)wave_or_u32_dpp((uint32_t)(v >> 32)) << 32) | wave_or_u32_dpp((uint32_t)v);
 }
 
 }  // namespace mel
