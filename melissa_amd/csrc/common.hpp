@@ -120,6 +120,15 @@ __device__ __forceinline__ int wave_sum_i32_dpp(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// sum of a float over each 16-lane row (every lane of the row gets it): the same DPP butterfly
+__device__ __forceinline__ float row16_sum_f32(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+}
+
 // OR of a 64-bit value over the wave: the DPP butterfly of wave_sum_i32_dpp on each half, then four readlanes
 __device__ __forceinline__ uint32_t wave_or_u32_dpp(uint32_t u) {
     int v = (int)u;

@@ -250,13 +250,10 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
                 for (int a = 0; a < HF_MAX_ACTIONS; ++a)
                     if (a < na) q[a] = fmaf(xq, wl[a * HF_W + j16 + 16 * i], q[a]);
             }
+            v = row16_sum_f32(v);                  // the row's 16 lanes are one DPP row
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                v += __shfl_xor(v, o, 64);
-#pragma unroll
-                for (int a = 0; a < HF_MAX_ACTIONS; ++a)
-                    if (a < na) q[a] += __shfl_xor(q[a], o, 64);
-            }
+            for (int a = 0; a < HF_MAX_ACTIONS; ++a)
+                if (a < na) q[a] = row16_sum_f32(q[a]);
             const int b = m0 + trow;
             if (b < rows) {
                 float qsum = 0.f;
