@@ -112,11 +112,18 @@ __device__ __forceinline__ uint64_t two_hop_of(uint64_t one_hop, int lane, int n
     return m & ~bit(lane);
 }
 
-// nx.geometric_edges (core.py:311): edge iff dx*dx + dy*dy <= 0.2**2 in float64
+// nx.geometric_edges (core.py:311): edge iff dx*dx + dy*dy <= 0.2**2 in float64.
+// Node j's position reaches the lanes as an LDS broadcast (every lane reads the same address) instead of four
+// v_readlane into SGPRs: the loop body is then pure VALU on VGPR operands, without the SGPR write -> VALU read wait
+// states that dominated it with one wavefront per SIMD (workgroups of the env kernels are 4 wavefronts).
 __device__ __forceinline__ uint64_t geometric_one_hop(double px, double py, int lane, int n) {
+    __shared__ double sx[4][64], sy[4][64];
+    const int w = (threadIdx.x >> 6) & 3;
+    sx[w][lane] = px, sy[w][lane] = py;
     uint64_t m = 0;
+#pragma unroll 5
     for (int j = 0; j < n; ++j) {
-        const double dx = px - shfl_f64(px, j), dy = py - shfl_f64(py, j);
+        const double dx = px - sx[w][j], dy = py - sy[w][j];
         const double d2 = dx * dx + dy * dy;
         if (d2 <= R2_F64) m |= bit(j);
     }

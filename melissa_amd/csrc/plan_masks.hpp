@@ -10,11 +10,16 @@ namespace mel {
 // positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
 // the first 33 hits in index order (self included) survive, then self is dropped.
 __device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
+    // node j's position as an LDS broadcast instead of two v_readlane (see geometric_one_hop in env.hip); the callers'
+    // workgroups are 4 wavefronts
+    __shared__ float sx[4][64], sy[4][64];
+    const int w = (threadIdx.x >> 6) & 3;
+    sx[w][lane] = x, sy[w][lane] = y;
     const float r2 = (float)(0.2 * 0.2);
     uint64_t m = 0;
+#pragma unroll 5
     for (int j = 0; j < n; ++j) {
-        const float xj = lane_f32(x, j), yj = lane_f32(y, j);     // j is the loop counter: v_readlane
-        const float dx = x - xj, dy = y - yj;
+        const float dx = x - sx[w][j], dy = y - sy[w][j];
         const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
         if (d2 < r2) m |= 1ull << j;
     }
