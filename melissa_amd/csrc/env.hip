@@ -104,10 +104,19 @@ __device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lan
 
 // core.py:334-341: one-hop OR neighbours' one-hop, minus self
 __device__ __forceinline__ uint64_t two_hop_of(uint64_t one_hop, int lane, int n) {
-    uint64_t m = one_hop;
-    for (int j = 0; j < n; ++j) {
-        const uint64_t t = lane_u64(one_hop, j);
-        if ((one_hop >> j) & 1ull) m |= t;
+    // every lane walks ITS OWN neighbours (a handful, not all n nodes) and ORs their rows in, fetched from LDS by a
+    // per-lane gather; the wave iterates max-degree times instead of n times with two v_readlane each
+    __shared__ uint64_t rows[4][64];
+    const int w = (threadIdx.x >> 6) & 3;
+    (void)n;
+    rows[w][lane] = one_hop;                    // (lanes >= n hold 0)
+    uint64_t m = one_hop, rest = one_hop;
+    while (__ballot(rest != 0ull)) {
+        if (rest) {
+            const int j = __ffsll((long long)rest) - 1;
+            rest &= rest - 1ull;
+            m |= rows[w][j];
+        }
     }
     return m & ~bit(lane);
 }
@@ -145,10 +154,19 @@ __device__ __forceinline__ void selector_enable(Env& s, uint64_t agents, int lan
     s.sel_active = (s.sel_active & ~agents) | (agents & can);
 }
 
+#ifdef MEL_ENV_PROF
+// finer split of the world step (wave 0 lane 0 of every eighth env adds): [0] relay + scripted, [1] move + all-pairs edges,
+// [2] two-hop masks, [3] calls
+__device__ unsigned long long g_world_prof[4];
+#endif
+
 // World.step core.py:225-266
 __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env& s,
                                            int lane) {
     const int n = e.n_nodes;
+#ifdef MEL_ENV_PROF
+    const unsigned long long wp0 = __builtin_readcyclecounter();
+#endif
     s.info_valid_cache = 0;                                  // message counters, coverage and (dynamic graph) degrees change here
     // :226-234 scripted agents: action = heuristic(agent) (the heuristics offered return no relay mask, so the
     // relays_for pass :236-243 never fires)
@@ -180,6 +198,11 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
             s.has_msg |= nb;
         }
     }
+#ifdef MEL_ENV_PROF
+    asm volatile("s_nop 0" ::"s"(s.has_msg), "v"(s.received));
+    const unsigned long long wp1 = __builtin_readcyclecounter();
+    unsigned long long wp2 = wp1, wp3 = wp1;
+#endif
     // :256-257 move_graph -> update_position + one/two hop recompute (core.py:281-341)
     if (e.dynamic_graph) {
         int mv = s.move_cursor;
@@ -194,8 +217,22 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
         }
         s.move_cursor += 1;
         s.one_hop = geometric_one_hop(s.px, s.py, lane, n);
+#ifdef MEL_ENV_PROF
+        asm volatile("s_nop 0" ::"v"(s.one_hop));
+        wp2 = __builtin_readcyclecounter();
+#endif
         s.two_hop = two_hop_of(s.one_hop, lane, n);
+#ifdef MEL_ENV_PROF
+        asm volatile("s_nop 0" ::"v"(s.two_hop));
+        wp3 = __builtin_readcyclecounter();
+#endif
     }
+#ifdef MEL_ENV_PROF
+    if (lane == 0 && (blockIdx.x & 1) == 0 && (threadIdx.x >> 6) == 0) {
+        atomicAdd(&g_world_prof[0], wp1 - wp0), atomicAdd(&g_world_prof[1], wp2 - wp1), atomicAdd(&g_world_prof[2], wp3 - wp2);
+        atomicAdd(&g_world_prof[3], 1ull);
+    }
+#endif
     // :260-261 -> Agent.update_two_hop_cover_from_one_hopper (core.py:94-102)
     s.cover = __popcll(s.two_hop & (s.has_msg | s.origin_set));
     if (scripted_lane) s.act = 0;                                // :264-266
@@ -810,6 +847,15 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
 }
 
 // tuning builds only (-DMEL_ENV_PROF): read and reset the round kernel's cycle counters (tools/env_prof.py)
+void mel_debug_world_prof(unsigned long long* out4) {
+#ifdef MEL_ENV_PROF
+    (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_world_prof), 4 * sizeof(unsigned long long));
+    unsigned long long z[4] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_world_prof), z, sizeof(z));
+#else
+    for (int i = 0; i < 4; ++i) out4[i] = 0;
+#endif
+}
 void mel_debug_env_prof(unsigned long long* out9) {
 #ifdef MEL_ENV_PROF
     (void)hipMemcpyFromSymbol(out9, HIP_SYMBOL(g_env_prof), 9 * sizeof(unsigned long long));

@@ -22,3 +22,12 @@ print("wavefronts sampled", v[7], "loop iterations per env round", v[8] / w)
 names = ["state load", "round loop", "  env_step with the world step", "  other env_step calls", "  env_observe", "  episode end (log + reset)", "state store"]
 for i, name in enumerate(names):
     print(f"{name:34s} {v[i] / w:9.0f} cycles per env round")
+fw = lib.mel_debug_world_prof
+fw.argtypes = [C.c_void_p]
+wb = (C.c_ulonglong * 4)()
+fw(wb)
+loop.run(20)
+torch.cuda.synchronize()
+fw(wb)
+c = max(wb[3], 1)
+print(f"world step (sample of {wb[3]} calls): relay + scripted {wb[0] / c:.0f}, move + all-pairs edges {wb[1] / c:.0f}, two-hop masks {wb[2] / c:.0f} cycles")
