@@ -570,6 +570,54 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
             }
             rec_next = a.replay.obs_next + rec * n * 8;
         }
+        // ---- fast-forward of the bookkeeping-only AEC sub-steps of the round ------------------------------------------
+        // (1) Pending dead agents (GraphEnv.step :304-310 + _deads_step_first :359: the selection is the first terminated
+        //     agent, the real one waits in skip).  Each dead step only removes its agent and moves the selection to the
+        //     next dead agent, at last back to skip; every observe that lands on a dead agent counts one done.  Done in one
+        //     go unless the episode could end inside the sequence (every active agent dead, or the done count reaching n):
+        //     those rare rounds take the sequential path.
+        {
+            const uint64_t dead = s.agents & s.terminated;
+            if (dead && s.skip >= 0 && s.sel == lowest_bit(dead) && (s.agents & ~dead) != 0ull &&
+                s.done_count + __popcll(dead) - 1 < n && s.error == 0) {
+                s.sel_active &= ~dead, s.alive &= ~dead, s.terminated &= ~dead, s.info_valid &= ~dead, s.agents &= ~dead;
+                s.done_count += __popcll(dead) - 1;
+                s.sel = s.skip;
+                s.skip = SKIP_NONE;
+                if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;   // PettingZooEnv.step (A.6), idempotent
+            }
+        }
+        // (2) No pending dead agent, the selection is the first active agent and the forward covered exactly the active
+        //     set: the sub-steps of every acting agent but the LAST change nothing but bookkeeping - its action and step
+        //     count, the selector's marks, the stored info of the next selection (the same ten values: nothing moves
+        //     before the world step) - so they are applied in one go (graph.py:312-321,358, k - 1 times); the last agent
+        //     takes the sequential path below, which runs the world step.
+        if (s.skip == SKIP_NONE && (s.agents & s.terminated) == 0ull && live_in != 0ull && live_in == s.sel_active &&
+            (live_in & ~s.agents) == 0ull && s.sel >= 0 && s.sel == lowest_bit(live_in) && s.sel_selected == bit(s.sel) &&
+            s.error == 0) {
+            const int last = 63 - __clzll((long long)live_in);
+            const uint64_t early = live_in & ~bit(last);             // agents whose sub-step is fast-forwarded
+            if (early) {
+                s.decisions += __popcll(early);
+                if ((early >> lane) & 1ull) {                        // :314-318
+                    s.cur_act = my_action;
+                    s.steps += 1;
+                }
+                const uint64_t later = live_in & ~bit(s.sel);        // every agent that becomes the selection: a_2 .. a_k
+                if ((later >> lane) & 1ull) s.sel_steps += 1;       // selector.py:25-34
+                s.sel_selected = live_in;
+                uint64_t rest = later;                               // :358 infos[next] = get_info()
+                while (rest) {
+                    const int nxt = lowest_bit(rest);
+                    rest &= rest - 1ull;
+                    write_info_stats(a.env, b, nxt, s, lane);
+                }
+                s.info_valid |= later;
+                if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;
+                s.new_round = 0;                                     // the first observe of the round (:209-211)
+                s.sel = last;
+            }
+        }
         for (int it = 0; it < 3 * n + 4; ++it) {
             const int sel = s.sel;
             if (sel < 0) {
