@@ -319,7 +319,7 @@ def main():
         # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied there); only valid for the
         # workload those passes were taken on.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")
         if (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
                 and args.dtype == "f32" and os.path.exists(pmc_path)):
             pmc = json.load(open(pmc_path))["per_launch"]
@@ -355,9 +355,9 @@ def main():
         att2 = (u1 + r) * row + r * row                                      # x_l2 rows + x_r2 rows read, x_3 written
         env_b = 2.0 * args.envs * (8968 if args.nodes == 50 else float(lib.mel_env_state_bytes(args.envs, args.nodes)) / args.envs)
         pmc_extra = {}
-        if traffic is not None or os.path.exists(os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json")):
+        if traffic is not None or os.path.exists(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")):
             try:
-                pmc_extra = json.load(open(os.path.join(ROOT, "profiles", "r01j_pmc_traffic.json"))).get("per_launch", {})
+                pmc_extra = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json"))).get("per_launch", {})
             except (OSError, ValueError):
                 pmc_extra = {}
         same = (args.nodes == N_NODES and args.envs == ENVS_PER_GPU and args.dtype == "f32")

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-end profile refresh (run on the GPU box through gpurun): kernel-trace stats of the bench command, the two
-# PMC passes behind roofline.traffic, and the bench line itself.  Usage: bash tools/refresh_profiles.sh r01j
+# PMC passes behind roofline.traffic, and the bench line itself.  Usage: bash tools/refresh_profiles.sh r01k
 set -e
-TAG=${1:-r01j}
+TAG=${1:-r01k}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
