@@ -235,6 +235,15 @@ def main():
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
 
+    # --gpus N without an external launcher: this process is still GPU-free (no torch.cuda call, no library load), so it
+    # may start the N ranks as fresh children, relay rank 0's JSON line and leave with their exit code.  Under
+    # torch.distributed.run (WORLD_SIZE set) it IS a rank; a WORLD_SIZE that contradicts --gpus is refused.
+    from melissa_amd import launch
+    rc = launch.maybe_spawn(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                            check_devices=not args.rehearse_on_one_gpu)
+    if rc is not None:
+        raise SystemExit(rc)
+
     # CPU baseline variant (b) starts child processes: do it BEFORE anything touches the GPU (no fork / exec from a
     # process with an initialised HIP runtime)
     subproc_baseline = None

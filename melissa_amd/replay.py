@@ -155,7 +155,8 @@ class DQNLearner:
             else:
                 best = q_next.max(dim=1).values
             returns = b["ret"] + b["boot_w"] * best
-        return self.policy.learn(dict(obs=b["obs"], act=b["act"], returns=returns), grad_hook=self.grad_hook)
+        self.last_batch = dict(obs=b["obs"], act=b["act"], returns=returns)        # what the update regressed on (tests)
+        return self.policy.learn(dict(self.last_batch), grad_hook=self.grad_hook)
 
 
 class DGNLearner(DQNLearner):
@@ -173,5 +174,5 @@ class DGNLearner(DQNLearner):
             else:
                 best = q_next.max(dim=1).values
             returns = b["ret"] + b["boot_w"] * best
-        return self.policy.learn(dict(active_obs=b["active_obs"], active_act=b["active_act"], segment=b["segment"],
-                                      returns=returns), grad_hook=self.grad_hook)
+        self.last_batch = dict(active_obs=b["active_obs"], active_act=b["active_act"], segment=b["segment"], returns=returns)
+        return self.policy.learn(dict(self.last_batch), grad_hook=self.grad_hook)

@@ -36,7 +36,10 @@ def build_network(name: str, n_nodes: int, device, hidden=128, heads=4):
 
 
 def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4, batch_size=32, n_step=4,
-          gamma=0.99, lr=1e-3, target_update_freq=500, eps=0.1, replay_rounds=64, seed=9, backend=None, log=print):
+          gamma=0.99, lr=1e-3, target_update_freq=500, eps=0.1, replay_rounds=64, seed=9, backend=None, log=print,
+          probe=None):
+    """``probe(update_index, net, learner, phase)`` (optional) is called with phase "before" / "after" around every
+    update - tests use it to re-derive an update's loss from the sampled batch with the oracle."""
     rank, local_rank, world = parallel.init_distributed(backend)
     device = torch.device("cuda", local_rank if backend != "gloo" else 0)
     torch.cuda.set_device(device)
@@ -61,7 +64,11 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     for _ in range(updates):
         with torch.no_grad():
             loop.run(rounds_per_update)
+        if probe is not None:
+            probe(len(losses), net, learner, "before")
         losses.append(learner.step()["loss"])
+        if probe is not None:
+            probe(len(losses) - 1, net, learner, "after")
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
     c = loop.counters()

@@ -55,11 +55,12 @@ def _glorot(gen, *shape):
 
 
 def init_weights(model: str, input_dim=5, hidden=128, heads=4, n_actions=2, seed=9,
-                 dueling_hidden=(128, 128), random_conv_bias=False):
+                 dueling_hidden=(128, 128), random_conv_bias=False, dueling=True):
     """Random-init weights with the reference's parameter names and shapes.  ``model`` in
     {"l_dgn", "hl_dgn"}.  Distribution follows the [3P] defaults (nn.Linear default for MLPs, glorot
     for lin_l/lin_r/att, zeros for the conv bias unless ``random_conv_bias`` - tests set it so that a
-    missing bias add is caught)."""
+    missing bias add is caught).  ``dueling=False``: the single ``out_linear`` head the reference builds when
+    ``dueling_param`` is None (l_dgn.py:90, hl_dgn.py:80, dgn_r.py:80)."""
     gen = np.random.RandomState(seed)
     sd = {}
 
@@ -99,8 +100,11 @@ def init_weights(model: str, input_dim=5, hidden=128, heads=4, n_actions=2, seed
         latent = hidden * heads                                  # hl_dgn.py:64
     else:
         raise ValueError(model)
-    mlp("Q", [latent, *dueling_hidden, n_actions])
-    mlp("V", [latent, *dueling_hidden, 1])
+    if dueling:
+        mlp("Q", [latent, *dueling_hidden, n_actions])
+        mlp("V", [latent, *dueling_hidden, 1])
+    else:
+        sd["out_linear.weight"], sd["out_linear.bias"] = _linear_init(gen, n_actions, latent)
     return sd
 
 
@@ -247,6 +251,8 @@ _TCONV = {"edges": transformer_edges, "dense": transformer_dense}
 
 
 def _dueling(sd, x):
+    if "out_linear.weight" in sd:                                         # l_dgn.py:149, hl_dgn.py:117, dgn_r.py:127
+        return F.linear(x, sd["out_linear.weight"], sd["out_linear.bias"])
     q = _mlp(sd, "Q", x, _n_layers(sd, "Q"))
     v = _mlp(sd, "V", x, _n_layers(sd, "V"))
     return q - q.mean(dim=1, keepdim=True) + v                            # l_dgn.py:142-147

@@ -188,6 +188,27 @@ def test_shape_errors_and_no_fallback():
     assert empty.shape == (0, 2) and empty.is_cuda
 
 
+@pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])
+def test_out_linear_head_matches_oracle(model):
+    """dueling_param=None: the single out_linear head (l_dgn.py:90,149; hl_dgn.py:80,117; dgn_r.py:80,127) against the
+    oracle's out_linear branch (not the product's own torch formulation)."""
+    from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
+    from oracle import net_oracle as no
+    for path in GOLDENS:
+        g = np.load(path)
+        n, obs = int(g["n"]), g["obs"]
+        sd = no.init_weights(model, seed=23, random_conv_bias=True, dueling=False)
+        cls = {"l_dgn": LDGNNetwork, "hl_dgn": HLDGNNetwork, "dgn_r": DGNRNetwork}[model]
+        kw = dict(aggregator="max") if model == "hl_dgn" else {}
+        net = cls(5, 128, 2, 4, n, dueling_param=None, device="cuda", backend="hip", **kw)
+        net.load_state_dict(sd)
+        fwd = {"l_dgn": no.ldgn_forward, "hl_dgn": no.hldgn_forward, "dgn_r": no.dgnr_forward}[model]
+        with torch.no_grad():
+            got = net(obs)[0].cpu().numpy()
+            want = fwd(sd, obs, n).numpy()
+        np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+
+
 def test_non_dueling_head_and_select_action():
     import ctypes as C
     from melissa_amd import _lib
@@ -198,12 +219,13 @@ def test_non_dueling_head_and_select_action():
     obs = g["obs"] if int(g["n"]) == n else None
     if obs is None:
         pytest.skip("n20 golden missing")
-    torch.manual_seed(0)
+    sd = no.init_weights("hl_dgn", seed=0, random_conv_bias=True, dueling=False)
     net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=None, device="cuda", backend="hip")
+    net.load_state_dict(sd)
     with torch.no_grad():
         got = net(obs)[0]
-        want = net.torch_forward(torch.from_numpy(obs).cuda())
-    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=TOL, rtol=0)
+        want = no.hldgn_forward(sd, obs, n)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=TOL, rtol=0)
     # DQN masking + argmax + eps-greedy
     lib = _lib.load()
     bs = got.shape[0]

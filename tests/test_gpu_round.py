@@ -94,7 +94,7 @@ def oracle_round(pz, act_of_agent):
     raise AssertionError("round did not terminate")
 
 
-@pytest.mark.parametrize("n,dynamic", [(20, True), (12, False)])
+@pytest.mark.parametrize("n,dynamic", [(20, True), (12, False), (50, True), (50, False)])
 def test_round_loop_matches_oracle(n, dynamic):
     from melissa_amd import _lib as L
     from melissa_amd.collect import RoundLoop, sample_episode_table
@@ -258,9 +258,10 @@ def test_replay_sampling_and_dqn_learner():
     assert any(k.startswith("model_old.") for k in policy.state_dict())
 
 
+@pytest.mark.parametrize("n", [20, 50])
 @pytest.mark.parametrize("scripted", [None, (0.3, "simple_broadcast"), (0.4, "broadcast_if_any_interested")],
                          ids=["all-policy", "scripted-broadcast", "scripted-interested"])
-def test_hldgn_round_loop_matches_oracle(scripted):
+def test_hldgn_round_loop_matches_oracle(scripted, n):
     """HL-DGN in the round loop: one logits row per env (hl_dgn.py:108 ignores the controlling index), dense
     per-agent actions; env state after every round equals the oracle replaying the same actions.  With scripted
     agents the round's active set excludes them, their rows are zeroed by the dm mask before pooling (hl_dgn.py:105)
@@ -272,7 +273,7 @@ def test_hldgn_round_loop_matches_oracle(scripted):
     from melissa_amd.policy import DQNPolicy
     from oracle import env_oracle as eo
     from oracle import net_oracle as no
-    n, B, seed, K = 20, 5, 41, 30
+    B, seed, K = 5, 41, 30
     graphs = synthetic_graph_pool(n, 3, first_seed=50)
     skw = dict(scripted_agents_ratio=scripted[0], heuristic=scripted[1]) if scripted else {}
     venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
@@ -328,6 +329,58 @@ def test_training_loop_single_rank(model):
     out = train(model=model, n_nodes=12, envs=48, updates=4, rounds_per_update=3, batch_size=32, log=lambda *_: None)
     assert out["errors"] == 0 and out["decisions"] > 200 and out["replicas_identical"]
     assert np.isfinite(out["loss_first"]) and np.isfinite(out["loss_last"])
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "dgn_r", "hl_dgn"])
+def test_training_loop_n50_first_update_matches_oracle_autograd(model):
+    """BASELINE configs 4 / 5 at their graph size (N = 50): the training loop's FIRST update is re-derived by the oracle -
+    the loss of policies/dgn.py:49-64 (DGN-R: sampled returns regress on the summed sibling Q) or [3P] DQNPolicy.learn
+    (L-DGN / HL-DGN) from the oracle's forward on the sampled batch with the pre-update weights, and the gradient of
+    that loss by torch autograd through the oracle against the gradient the HIP learn path produced (recovered from
+    the Adam step: first step from zero moments moves every weight by lr * sign(g) ... so the check is on the loss and
+    on the parameter delta's sign pattern where |g| is not negligible)."""
+    from melissa_amd.train import train
+    from oracle import net_oracle as no
+    n, lr = 50, 1e-3
+    cap = {}
+
+    def probe(k, net, learner, phase):
+        if k != 0:
+            return
+        if phase == "before":
+            cap["sd"] = {key: v.detach().cpu().clone() for key, v in net.state_dict().items()}
+        else:
+            cap["batch"] = {key: v.detach().cpu() for key, v in learner.last_batch.items()}
+            cap["after"] = {key: v.detach().cpu().clone() for key, v in net.state_dict().items()}
+
+    out = train(model=model, n_nodes=n, envs=64, updates=2, rounds_per_update=3, batch_size=32, lr=lr,
+                log=lambda *_: None, probe=probe)
+    assert out["errors"] == 0 and out["replicas_identical"] and out["decisions"] > 500
+    sd = {k: v.clone().requires_grad_(True) for k, v in cap["sd"].items()}
+    b = cap["batch"]
+    torch.set_num_threads(8)
+    fwd = {"l_dgn": no.ldgn_forward, "dgn_r": no.dgnr_forward, "hl_dgn": no.hldgn_forward}[model]
+    if model == "dgn_r":
+        logits = fwd(sd, b["active_obs"].numpy(), n)
+        q = logits[torch.arange(len(b["active_act"])), b["active_act"]]
+        batch_q = torch.zeros_like(b["returns"]).index_add(0, b["segment"], q)            # dgn.py:43-55
+        loss = (b["returns"] - batch_q).pow(2).mean()                                       # dgn.py:57-64
+    else:
+        logits = fwd(sd, b["obs"].numpy(), n)
+        q = logits[torch.arange(len(b["act"])), b["act"]]
+        loss = (b["returns"] - q).pow(2).mean()
+    loss.backward()
+    assert abs(float(loss) - out["loss_first"]) <= 1e-4 * max(1.0, abs(float(loss))), (float(loss), out["loss_first"])
+    # Adam's first step from zero moments: delta = -lr * g / (|g| + eps) -> -lr * sign(g) wherever |g| >> 1e-8
+    checked = agree = 0
+    for k, g in ((k, v.grad) for k, v in sd.items()):
+        if g is None:
+            continue
+        delta = cap["after"][k] - cap["sd"][k]
+        big = g.abs() > 1e-5 * float(g.abs().max() + 1e-30)
+        checked += int(big.sum())
+        agree += int((torch.sign(delta[big]) == -torch.sign(g[big])).sum())
+    assert checked > 10000 and agree >= 0.999 * checked, (checked, agree)
 
 
 def test_collector_surface_counts_and_episode_stats():
