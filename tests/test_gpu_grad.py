@@ -66,7 +66,7 @@ def oracle_loss_and_grads(model, agg, sd, obs_np, n, act_np, target_np, dueling=
     bs = obs_np.shape[0]
     loss = (logits[torch.arange(bs), torch.from_numpy(act_np)] - torch.from_numpy(target_np)).pow(2).mean()
     loss.backward()
-    return logits.detach(), float(loss), {k: v.grad for k, v in leaves.items()}
+    return logits.detach(), float(loss.detach()), {k: v.grad for k, v in leaves.items()}
 
 
 @pytest.mark.parametrize("model,agg", [("l_dgn", "max"), ("dgn_r", "max"), ("hl_dgn", "max"), ("hl_dgn", "mean"), ("hl_dgn", "add")])
