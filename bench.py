@@ -36,6 +36,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0            # same guide, HBM3E ~8 TB/s
 N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
+N_GRAPHS, RING = 1024, 16
 HC = HIDDEN * HEADS
 
 
@@ -59,22 +60,25 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
                            device=device, backend="hip")
     net.eval()
     net.set_feature_dtype(dtype)
-    graphs = synthetic_graph_pool(n_nodes, 64, first_seed=0)
+    # the first 1024 accepted seeds of nx.random_geometric_graph(n, 0.2, seed=s), connected ones only
+    graphs = synthetic_graph_pool(n_nodes, N_GRAPHS, first_seed=0)
     make_venv = lambda count, seed: HipGraphVectorEnv(count, n_nodes, graph_pool=graphs, dynamic_graph=True,
                                                       device=device, max_moves=48, seed=seed,
                                                       construct_like_reference=False)
     policy = DQNPolicy(net)
     base = 1000 + rank * envs
     if mode == "round" and streams > 1:
-        loop = MultiStreamRoundLoop(make_venv, policy, envs, streams=streams, episodes_per_env=12, seed=base,
+        loop = MultiStreamRoundLoop(make_venv, policy, envs, streams=streams, seed=base,
                                     eps=0.001, use_graph=use_graph)                       # test eps (l_dgn.py:107)
         venv = loop.loops[0].venv
     elif mode == "round":
         venv = make_venv(envs, base)
-        loop = RoundLoop(venv, policy, episodes_per_env=12, seed=base, eps=0.001, use_graph=use_graph)
+        # episodes: the device episode stream (every reset draws a new episode, core.py:372-394; ring of 16 slots per env
+        # refilled every 7 rounds on a side stream INSIDE the timed region, resets included)
+        loop = RoundLoop(venv, policy, seed=base, eps=0.001, use_graph=use_graph, ring=RING)
     else:
         venv = make_venv(envs, base)
-        loop = DecisionLoop(venv, policy, episodes_per_env=12, seed=base, eps=0.001)
+        loop = DecisionLoop(venv, policy, seed=base, eps=0.001)
     return net, venv, loop
 
 

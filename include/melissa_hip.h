@@ -303,7 +303,7 @@ mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int
 #define MEL_S_DECISIONS        8   /* live (non-dead) agent decisions since bind                 */
 #define MEL_S_DONE_COUNT       9   /* done observations this episode (multi_agent_collector.py:261-263) */
 #define MEL_S_EPISODES_DONE   10   /* episodes finished (auto-reset mode)                        */
-#define MEL_S_ERROR           11   /* bit 0: ran out of stored movement offsets                  */
+#define MEL_S_ERROR           11   /* MEL_ENV_ERR_* bits                                         */
 #define MEL_S_EP_CURSOR       12   /* episodes started (indexes the auto-reset episode table)    */
 #define MEL_ENV_SCALARS       16
 
@@ -375,7 +375,66 @@ typedef struct mel_episode_pool {
      * masks, the source's first transmission); per-env counters and the sticky reward vector are carried over.
      * NULL: resets are computed in the round kernel. */
     const struct mel_env_batch* snapshot;
+    /* Optional (device int32 [n_envs of the env batch]): how many episodes of env b the table holds so far.  An env that
+     * starts episode number ep_cursor >= produced[b] sets MEL_ENV_ERR_EPISODE_UNDERRUN (the table would hand it an episode
+     * it has already played: a static table that wraps, or a stream that was not refilled in time).  NULL: no check. */
+    const int32_t* produced;
 } mel_episode_pool;
+
+/* bits of scalars[b][MEL_S_ERROR] */
+#define MEL_ENV_ERR_MOVES_EXHAUSTED   1   /* an episode needed more than max_moves movement draws               */
+#define MEL_ENV_ERR_NO_SELECTION      2   /* step with no agent selected (the reference would raise KeyError)   */
+#define MEL_ENV_ERR_UNCOVERED_AGENT   4   /* mel_env_round: an agent acts that the action rows do not cover     */
+#define MEL_ENV_ERR_EPISODE_UNDERRUN  8   /* see mel_episode_pool.produced                                      */
+
+/* ------------------------------------------------------------------------------------------------
+ * Continuous episode supply: World.reset's sampling (core.py:343-395) ON THE DEVICE.
+ *
+ * The reference draws, on every reset, an episode seed and a graph from the env's own generator
+ * (np_random = Generator(PCG64), core.py:372,378) and - from RandomState(episode_seed), MT19937 - the movement seed,
+ * the source, the interest density and the interested set (core.py:381-394); node movement then consumes
+ * RandomState(movement_seed).uniform(-1, 1) (core.py:316-319).  mel_episode_refill performs exactly those draws, bit for
+ * bit (numpy's PCG64 next_uint32 buffering + Lemire bounded integers; legacy MT19937 seeding, masked rejection
+ * sampling, random_sample doubles and the Fisher-Yates shuffle of RandomState.choice(replace=False)), into a RING of
+ * `ring` episode slots per env: episode j of env b lives in pool slot b*ring + j % ring.  The graph comes from a packed
+ * device-resident dataset (mel_graph_pool: positions + adjacency masks of the G graphs that stand for
+ * graph_topologies/training_N/*.pickle, core.py:165-175,450-452).  Each call also runs GraphEnv.reset + World.reset
+ * for the new slots into the pool's snapshot batch (same code as mel_env_reset), so an ending episode loads its
+ * successor's state.  Not covered (use a host-sampled table): is_testing's fixed seed list, scripted_agents_ratio > 0
+ * (a Generator.choice without replacement), a fixed graph that moves (its positions carry over between episodes).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct mel_graph_pool {
+    int32_t n_graphs;
+    int32_t n_nodes;
+    const double*   pos;       /* [G, N, 2] device float64 node positions ("pos" node attribute)              */
+    const uint64_t* one_hop;   /* [G, N]    device adjacency masks (graph edges)                              */
+} mel_graph_pool;
+
+typedef struct mel_episode_stream {
+    int32_t n_envs;            /* B                                                                            */
+    int32_t ring;              /* K >= 3 episode slots per env                                                  */
+    int32_t fixed_graph;       /* 1: GraphEnv(graph=...) - no graph draw (core.py:377), graphs->n_graphs == 1   */
+    int32_t has_density;       /* 1: fixed_interest_density is used instead of ep_rng.uniform(0.1, 1.0) (:385) */
+    double  fixed_interest_density;
+    uint64_t* pcg;             /* [B, 4] device: PCG64 state lo, state hi, inc lo, inc hi of env b's np_random  */
+    uint32_t* pcg_half;        /* [B, 2] device: has_uint32, uinteger (numpy buffers the upper half of a draw)  */
+    int32_t*  produced;        /* [B]    device: episodes drawn into the ring so far (= mel_episode_pool.produced) */
+    uint32_t* draw_seed;       /* [B, K] device scratch: episode_seed per slot (core.py:372)                    */
+    int32_t*  draw_graph;      /* [B, K] device scratch: graph index per slot (core.py:378)                     */
+    int32_t*  work;            /* [1 + 2*B*K] device scratch: work-item count, then (pool slot, unused) pairs   */
+    int32_t*  new_count;       /* [B]    device scratch                                                         */
+} mel_episode_stream;
+
+/* For every env b draw episodes produced[b], produced[b]+1, ... while the slot they go to is free - i.e. up to episode
+ * ep_cursor[b] + ring - 2 (the episode the env is playing keeps its slot) - and at most max_new of them; fill their
+ * pool slots (pos / one_hop / origin / interested / scripted = 0 / moves), run their reset into pool->snapshot, then
+ * publish produced[b].  `discard` episodes are drawn and dropped first (the samplings the reference performs while an
+ * env is CONSTRUCTED, so that streams line up with a reference run).  `pool` must have n_episodes == B*ring, device
+ * arrays the library may WRITE, a snapshot batch of B*ring envs, and produced == stream->produced.  ep_cursor is read
+ * from env->scalars.  Launches on `stream`; the caller orders it against the env launches (a refill may overlap env
+ * rounds on another stream as long as no env can reach an episode >= the produced[] value of the previous refill). */
+mel_status mel_episode_refill(const mel_episode_stream* st, const mel_graph_pool* graphs, const mel_episode_pool* pool,
+                              const mel_env_batch* env, int32_t max_new, int32_t discard, void* stream);
 
 /* Scripted agents (scripted_agents_ratio > 0): the deterministic heuristics of
  * graph_env/env/utils/heuristics/core.py.  The probabilistic ones (probabilistic_gossip / _relay) draw from the
@@ -493,7 +552,7 @@ int32_t    mel_prof_read(void* prof, double* ms_sum, int64_t* count);
 const char* mel_last_error(void);
 /* sizeof() of the structs of this header as the library was compiled, for binding authors to check their mirrors
  * against: which = 0 mel_linear, 1 mel_gatv2, 2 mel_mlp, 3 mel_weights, 4 mel_select, 5 mel_env_batch,
- * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay; 0 for anything else. */
+ * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay, 9 mel_graph_pool, 10 mel_episode_stream; 0 for anything else. */
 size_t mel_abi_sizeof(int32_t which);
 const char* mel_version(void);
 

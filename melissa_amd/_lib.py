@@ -20,7 +20,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
+EXPORTS = ("mel_episode_refill", "mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
            "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
@@ -89,7 +89,21 @@ class MelEpisodePool(C.Structure):
     _fields_ = [("n_episodes", C.c_int32), ("n_nodes", C.c_int32), ("max_moves", C.c_int32),
                 ("reserved", C.c_int32), ("pos", C.c_void_p), ("one_hop", C.c_void_p),
                 ("interested", C.c_void_p), ("origin", C.c_void_p), ("moves", C.c_void_p),
-                ("scripted", C.c_void_p), ("snapshot", C.c_void_p)]
+                ("scripted", C.c_void_p), ("snapshot", C.c_void_p), ("produced", C.c_void_p)]
+
+
+class MelGraphPool(C.Structure):
+    _fields_ = [("n_graphs", C.c_int32), ("n_nodes", C.c_int32), ("pos", C.c_void_p), ("one_hop", C.c_void_p)]
+
+
+class MelEpisodeStream(C.Structure):
+    _fields_ = [("n_envs", C.c_int32), ("ring", C.c_int32), ("fixed_graph", C.c_int32), ("has_density", C.c_int32),
+                ("fixed_interest_density", C.c_double), ("pcg", C.c_void_p), ("pcg_half", C.c_void_p),
+                ("produced", C.c_void_p), ("draw_seed", C.c_void_p), ("draw_graph", C.c_void_p), ("work", C.c_void_p),
+                ("new_count", C.c_void_p)]
+
+
+ENV_ERR_MOVES_EXHAUSTED, ENV_ERR_NO_SELECTION, ENV_ERR_UNCOVERED_AGENT, ENV_ERR_EPISODE_UNDERRUN = 1, 2, 4, 8
 
 
 class MelEnvObs(C.Structure):
@@ -189,6 +203,8 @@ def load(build_if_missing: bool = True):
     lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MelRoundReplay), vp]
     lib.mel_env_observe.restype = i32
     lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
+    lib.mel_episode_refill.restype = i32
+    lib.mel_episode_refill.argtypes = [C.POINTER(MelEpisodeStream), C.POINTER(MelGraphPool), P, E, i32, i32, vp]
     lib.mel_prof_create.restype = vp
     lib.mel_prof_create.argtypes = [i32]
     lib.mel_prof_destroy.restype = None

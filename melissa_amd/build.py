@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmelissa_hip.so")
 SOURCES = ["fwd.hip", "env.hip", "grad.hip"]
-HEADERS = ["common.hpp", "gemm_f32.hpp", "gemm_bf16.hpp", "gemm_split.hpp", "gemm_ring.hpp", "plan.hpp", "plan_masks.hpp", "attention.hpp", "heads.hpp", os.path.join("..", "..", "include", "melissa_hip.h")]
+HEADERS = ["common.hpp", "gemm_f32.hpp", "gemm_bf16.hpp", "gemm_split.hpp", "gemm_ring.hpp", "plan.hpp", "plan_masks.hpp", "attention.hpp", "heads.hpp", "episode_stream.hpp", os.path.join("..", "..", "include", "melissa_hip.h")]
 
 
 def _hipcc() -> str:

@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 from .env.episodes import EpisodeSampler, pack_episodes
+from .env.stream import make_supply
 from .env.vector_env import HipGraphVectorEnv, ObsBuffers
 
 
@@ -39,12 +40,13 @@ class DecisionLoop:
     """AEC-order loop: one agent decision per env per iteration (the reference collector's granularity)."""
 
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
-                 eps: float = 0.0, episodes=None):
+                 eps: float = 0.0, episodes=None, stream: bool | None = None, ring: int = 64, discard: int = 0):
+        """Episodes: a device stream (fresh episodes for ever, ``melissa_amd.env.stream``) unless ``episodes`` =
+        (packed, table) is given or ``stream`` is False (a host-drawn table of ``episodes_per_env`` per env)."""
         self.venv, self.policy, self.eps = venv, policy, eps
         dev = venv.device
-        packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
-        self.pool = venv.load_pool(packed)
-        self.table = torch.from_numpy(table).to(dev)
+        self.supply = make_supply(venv, seed, episodes, episodes_per_env, stream, ring, discard, reset_snapshots=False)
+        self.pool, self.table = self.supply.pool, self.supply.table
         self.n_actions = policy.model.output_dim
         self.obs = torch.empty(venv.env_num, 8 * venv.n + 1, dtype=torch.float32, device=dev)
         self.out = ObsBuffers(venv.env_num, venv.n, dev, obs=self.obs)
@@ -53,10 +55,11 @@ class DecisionLoop:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self.iterations = 0
-        venv.reset_device(self.pool, self.table[:, 0].contiguous(), self.out)
+        venv.reset_device(self.pool, self.supply.first_episode_ids(), self.out)
 
     def step(self):
         """One collector iteration for every env (one agent decision per env)."""
+        self.supply.before_step(self.iterations)
         net = self.policy.model
         net.hip_forward(self.obs, out=self.logits)
         if self.eps > 0.0:
@@ -93,15 +96,23 @@ class RoundLoop:
 
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
                  eps: float = 0.0, episodes=None, rows_cap: int | None = None, use_graph: bool = False,
-                 stream: "torch.cuda.Stream | None" = None, replay=None):
+                 stream: "torch.cuda.Stream | None" = None, replay=None, episode_stream: bool | None = None,
+                 ring: int = 16, discard: int = 0):
+        """Episodes: by default a device STREAM (``melissa_amd.env.stream.EpisodeStream``: every reset draws a new episode
+        like World.reset does, core.py:372-394; ``ring`` slots per env, ``discard`` construction-time samplings dropped);
+        ``episodes`` = (packed, table) or ``episode_stream=False`` give a fixed table of ``episodes_per_env`` episodes."""
         self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
         self.use_graph, self.graph = use_graph, None
         self.stream = stream                       # None: torch's current stream
         self.replay = replay                       # optional melissa_amd.replay.RoundReplay
         dev = venv.device
-        packed, table = episodes if episodes is not None else sample_episode_table(venv, episodes_per_env, seed)
-        self.pool = venv.load_pool(packed, reset_snapshots=True)        # episode ends load their next state
-        self.table = torch.from_numpy(table).to(dev)
+        # episode ends load their next state from reset snapshots (static tables: precomputed here; streams: by the refill)
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self.supply = make_supply(venv, seed, episodes, episodes_per_env, episode_stream, ring, discard)
+        else:
+            self.supply = make_supply(venv, seed, episodes, episodes_per_env, episode_stream, ring, discard)
+        self.pool, self.table = self.supply.pool, self.supply.table
         self.n_actions = policy.model.output_dim
         # HL-DGN's logits do not depend on the agent (hl_dgn.py:108): one row per env, dense action layout
         self.per_env_logits = policy.model._MODEL == _lib.MODEL_HLDGN
@@ -125,7 +136,8 @@ class RoundLoop:
         # the env round also writes the plan masks of the next forward into this workspace (mel_env_batch.plan_*): one
         # launch less per round
         self._plan = policy.model.plan_pointers(venv.env_num, 0 if self.per_env_logits else self.rows_cap, self.workspace)
-        venv.reset_device(self.pool, self.table[:, 0].contiguous(), None)
+        torch.cuda.synchronize(dev)
+        venv.reset_device(self.pool, self.supply.first_episode_ids(), None)
         self._bind_plan()
         venv.round_device(self.pool, None, None, self.live, None, first=True)
         torch.cuda.synchronize(dev)
@@ -165,6 +177,7 @@ class RoundLoop:
             self._step()
 
     def _step(self):
+        self.supply.before_step(self.iterations)      # episode stream: refill on a side stream every few rounds
         if self.use_graph:
             if self.graph is None:
                 self._launch()                        # warm-up outside capture (lazy init)
@@ -196,7 +209,7 @@ class MultiStreamRoundLoop:
     this changes nothing about any env's trajectory."""
 
     def __init__(self, make_venv, policy, n_envs: int, streams: int = 2, episodes_per_env: int = 8, seed: int = 0,
-                 eps: float = 0.0, use_graph: bool = True):
+                 eps: float = 0.0, use_graph: bool = True, ring: int = 16):
         per = (n_envs + streams - 1) // streams
         self.loops = []
         for k in range(streams):
@@ -205,7 +218,7 @@ class MultiStreamRoundLoop:
                 break
             venv = make_venv(hi - lo, seed + lo)
             self.loops.append(RoundLoop(venv, policy, episodes_per_env=episodes_per_env, seed=seed + lo, eps=eps,
-                                        use_graph=use_graph, stream=torch.cuda.Stream(device=venv.device)))
+                                        use_graph=use_graph, stream=torch.cuda.Stream(device=venv.device), ring=ring))
         self.iterations = 0
 
     @property

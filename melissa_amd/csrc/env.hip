@@ -208,7 +208,7 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
         int mv = s.move_cursor;
         if (mv >= pool.max_moves) {
             mv = pool.max_moves - 1;
-            s.error |= 1;
+            s.error |= MEL_ENV_ERR_MOVES_EXHAUSTED;
         }
         if (lane < n) {
             const double* off = pool.moves + ((size_t)s.episode * pool.max_moves + mv) * 2 * n;
@@ -658,6 +658,7 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
                 const unsigned long long r0 = ENV_T();
 #endif
                 log_episode(a.env, b, s, lane);
+                if (a.pool.produced && s.ep_cursor >= uniform_i32(a.pool.produced[b])) s.error |= MEL_ENV_ERR_EPISODE_UNDERRUN;
                 const int ep = uniform_i32(a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)]);
                 if (a.has_snap) env_reset_from_snapshot(a.env, a.snap, b, s, ep, lane);
                 else env_reset(a.env, a.pool, b, s, ep, 0, lane);
@@ -734,6 +735,7 @@ __global__ __launch_bounds__(256) void env_kernel(StepArgs a) {
                 if ((r & 1) && ((r & 2) || s.done_count == a.env.n_nodes)) {
                     s.episodes_done += 1;
                     log_episode(a.env, b, s, lane);
+                    if (a.pool.produced && s.ep_cursor >= a.pool.produced[b]) s.error |= MEL_ENV_ERR_EPISODE_UNDERRUN;
                     const int ep = a.episode_table[(size_t)b * a.table_stride + (s.ep_cursor % a.table_stride)];
                     env_reset(a.env, a.pool, b, s, ep, 0, lane);
                     env_observe(a.env, b, s, a.out, row, lane);
@@ -797,6 +799,8 @@ static EnvLayout carve_env(int32_t B, int32_t n, void* state) {
 }
 
 }  // namespace mel
+
+#include "episode_stream.hpp"
 
 using namespace mel;
 
@@ -892,6 +896,11 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_round");
+}
+
+mel_status mel_episode_refill(const mel_episode_stream* st, const mel_graph_pool* graphs, const mel_episode_pool* pool,
+                              const mel_env_batch* env, int32_t max_new, int32_t discard, void* stream) {
+    return launch_episode_refill(st, graphs, pool, env, max_new, discard, static_cast<hipStream_t>(stream));
 }
 
 // tuning builds only (-DMEL_ENV_PROF): read and reset the round kernel's cycle counters (tools/env_prof.py)

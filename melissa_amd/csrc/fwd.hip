@@ -868,10 +868,12 @@ size_t mel_abi_sizeof(int32_t which) {
         case 6: return sizeof(mel_episode_pool);
         case 7: return sizeof(mel_env_obs);
         case 8: return sizeof(mel_round_replay);
+        case 9: return sizeof(mel_graph_pool);
+        case 10: return sizeof(mel_episode_stream);
         default: return 0;
     }
 }
-const char* mel_version(void) { return "melissa_hip 0.3 (gfx950)"; }
+const char* mel_version(void) { return "melissa_hip 0.4 (gfx950)"; }
 
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {
     if (!w || bs <= 0 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return 0;

@@ -84,6 +84,57 @@ def synthetic_graph_pool(n: int, count: int, first_seed: int = 0, radius: float 
     return out
 
 
+def packed_graph_pool(n: int, count: int, first_seed: int = 0, radius: float = RADIUS_OF_INFLUENCE):
+    """The same accepted graphs as :func:`synthetic_graph_pool` (seeds first_seed, first_seed + 1, ... keeping the
+    connected ones) as packed arrays - ``pos`` float64 [G, N, 2], ``one_hop`` uint64 [G, N], ``seeds`` int64 [G].  This is
+    the on-disk / in-HBM dataset format that replaces the per-episode ``pickle.load`` of an ``nx.Graph``
+    (core.py:165-175,450-452; the reference trains on 50 000-graph pools, README.md:92-93): see :func:`save_graph_pool`.
+    About 0.5 ms per accepted graph at N = 50 (one in four candidates is connected)."""
+    import random
+    pos_out = np.empty((count, n, 2), dtype=np.float64)
+    hop_out = np.empty((count, n), dtype=np.uint64)
+    seeds = np.empty(count, dtype=np.int64)
+    got, s = 0, first_seed
+    while got < count:
+        rng = random.Random(s)
+        g = Graph.from_positions(np.array([[rng.random(), rng.random()] for _ in range(n)], dtype=np.float64), radius)
+        if g.is_connected():
+            pos_out[got], hop_out[got], seeds[got] = g.pos, g.one_hop, s
+            got += 1
+        s += 1
+    return pos_out, hop_out, seeds
+
+
+def save_graph_pool(path: str, pos: np.ndarray, one_hop: np.ndarray, seeds=None):
+    """Packed graph dataset on disk: ``pos`` f64 [G, N, 2] + ``adj`` u64 [G, N] (bit j of adj[g, i] = edge i - j)."""
+    np.savez(path, pos=np.ascontiguousarray(pos, dtype=np.float64), adj=np.ascontiguousarray(one_hop, dtype=np.uint64),
+             **({"seeds": np.asarray(seeds)} if seeds is not None else {}))
+
+
+def load_graph_pool(path: str):
+    """-> list of :class:`Graph` views over the packed arrays of :func:`save_graph_pool` (no per-graph copies)."""
+    with np.load(path, allow_pickle=False) as z:
+        pos, adj = z["pos"], z["adj"]
+    return [Graph(pos[g], adj[g]) for g in range(pos.shape[0])]
+
+
+def cached_graph_pool(n: int, count: int, first_seed: int = 0, cache_dir: str | None = None):
+    """:func:`packed_graph_pool` through an on-disk cache (``graph_pool_n{n}_{count}_{first_seed}.npz``, default
+    directory ``$MEL_GRAPH_CACHE`` or the system temp dir): a 50 000-graph pool takes tens of seconds to draw once and
+    a fraction of a second to load afterwards."""
+    import os
+    import tempfile
+    cache_dir = cache_dir or os.environ.get("MEL_GRAPH_CACHE") or os.path.join(tempfile.gettempdir(), "melissa_graph_pools")
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, f"graph_pool_n{n}_{count}_{first_seed}.npz")
+    if not os.path.exists(path):
+        pos, hop, seeds = packed_graph_pool(n, count, first_seed)
+        tmp = f"{path}.tmp.{os.getpid()}.npz"
+        save_graph_pool(tmp, pos, hop, seeds)
+        os.replace(tmp, path)
+    return load_graph_pool(path)
+
+
 @dataclass
 class Episode:
     graph_index: int

@@ -52,6 +52,37 @@ class DevicePool:
         self.snapshot_env = self.snapshot_state = None
         self.refresh()
 
+    @classmethod
+    def empty(cls, n_episodes: int, n: int, max_moves: int, dynamic: bool, device) -> "DevicePool":
+        """An all-zero pool allocated ON the device (the ring of an episode stream: hundreds of MB of movement offsets that
+        the device sampler fills - nothing to upload)."""
+        self = cls.__new__(cls)
+        z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=device)
+        self.tensors = dict(pos=z(n_episodes, n, 2, dtype=torch.float64), one_hop=z(n_episodes, n, dtype=torch.int64),
+                            interested=z(n_episodes, dtype=torch.int64), origin=z(n_episodes, dtype=torch.int32),
+                            moves=z(n_episodes, max_moves if dynamic else 1, 2, n, dtype=torch.float64),
+                            scripted=z(n_episodes, dtype=torch.int64))
+        self.struct = _lib.MelEpisodePool()
+        self.struct.n_episodes, self.struct.n_nodes = n_episodes, n
+        self.struct.max_moves = max_moves if dynamic else 1
+        self.snapshot_env = self.snapshot_state = None
+        self.refresh()
+        return self
+
+    def alloc_snapshots(self, lib, like_env):
+        """A snapshot batch (one env per pool slot, ``like_env``'s settings) whose resets somebody else runs
+        (mel_episode_refill)."""
+        e, n = int(self.struct.n_episodes), int(self.struct.n_nodes)
+        self.drop_snapshots()
+        self.snapshot_state = torch.zeros(int(lib.mel_env_state_bytes(e, n)), dtype=torch.uint8,
+                                          device=self.tensors["origin"].device)
+        env = _lib.MelEnvBatch()
+        for name in ("dynamic_graph", "has_local_ratio", "local_ratio", "heuristic", "is_testing"):
+            setattr(env, name, getattr(like_env, name))
+        _lib.check(lib.mel_env_bind(C.byref(env), e, n, self.snapshot_state.data_ptr()), "mel_env_bind")
+        self.snapshot_env = env
+        self.struct.snapshot = C.addressof(env)
+
     def refresh(self):
         t = self.tensors
         s = self.struct

@@ -37,9 +37,12 @@ def build_network(name: str, n_nodes: int, device, hidden=128, heads=4):
 
 def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4, batch_size=32, n_step=4,
           gamma=0.99, lr=1e-3, target_update_freq=500, eps=0.1, replay_rounds=64, seed=9, backend=None, log=print,
-          probe=None):
+          probe=None, graphs=16, ring=16):
     """``probe(update_index, net, learner, phase)`` (optional) is called with phase "before" / "after" around every
-    update - tests use it to re-derive an update's loss from the sampled batch with the oracle."""
+    update - tests use it to re-derive an update's loss from the sampled batch with the oracle.
+    ``graphs``: size of the synthetic training-graph dataset (the reference trains on 50 000 graphs per size, README.md:92-93;
+    pools >= 4096 go through the on-disk packed cache, ``melissa_amd.env.cached_graph_pool``).  Episodes come from the
+    device episode stream: every reset draws a new (graph, source, interested set, movement seed) like World.reset."""
     rank, local_rank, world = parallel.init_distributed(backend)
     device = torch.device("cuda", local_rank if backend != "gloo" else 0)
     torch.cuda.set_device(device)
@@ -50,11 +53,12 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     policy_cls, learner_cls = (DGNPolicy, DGNLearner) if model == "dgn_r" else (DQNPolicy, DQNLearner)
     policy = policy_cls(net, torch.optim.Adam(net.parameters(), lr=lr), discount_factor=gamma,
                         estimation_step=n_step, target_update_freq=target_update_freq)
-    graphs = synthetic_graph_pool(n_nodes, 16, first_seed=0)
-    venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graphs, dynamic_graph=True, device=device, max_moves=48,
+    from .env import cached_graph_pool
+    graph_list = cached_graph_pool(n_nodes, graphs, 0) if graphs >= 4096 else synthetic_graph_pool(n_nodes, graphs, first_seed=0)
+    venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graph_list, dynamic_graph=True, device=device, max_moves=48,
                              seed=1000 + rank * envs, construct_like_reference=False)
     replay = RoundReplay(envs, n_nodes, replay_rounds, device)
-    loop = RoundLoop(venv, policy, episodes_per_env=16, seed=1000 + rank * envs, eps=eps, replay=replay)
+    loop = RoundLoop(venv, policy, seed=1000 + rank * envs, eps=eps, replay=replay, ring=ring)
     learner = learner_cls(policy, replay, batch_size=batch_size, n_step=n_step, gamma=gamma,
                          grad_hook=parallel.FlatGradAllReducer(net), seed=seed + rank)
     with torch.no_grad():
@@ -94,9 +98,17 @@ def main():
     ap.add_argument("--rounds-per-update", type=int, default=4)
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--backend", default=None)
+    ap.add_argument("--graphs", type=int, default=16, help="training-graph dataset size (50000 = the reference's)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to start (one per GPU) when not under torch.distributed.run")
     a = ap.parse_args()
+    import os
+    import sys
+    from . import launch
+    rc = launch.maybe_spawn("-m", ["melissa_amd.train", *sys.argv[1:]], a.gpus, check_devices=a.backend != "gloo")
+    if rc is not None:
+        raise SystemExit(rc)
     train(model=a.model, n_nodes=a.nodes, envs=a.envs, updates=a.updates, rounds_per_update=a.rounds_per_update,
-          batch_size=a.batch_size, backend=a.backend)
+          batch_size=a.batch_size, backend=a.backend, graphs=a.graphs)
 
 
 if __name__ == "__main__":

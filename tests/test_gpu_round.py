@@ -94,8 +94,12 @@ def oracle_round(pz, act_of_agent):
     raise AssertionError("round did not terminate")
 
 
-@pytest.mark.parametrize("n,dynamic", [(20, True), (12, False), (50, True), (50, False)])
-def test_round_loop_matches_oracle(n, dynamic):
+@pytest.mark.parametrize("n,dynamic,supply", [(20, True, "table"), (12, False, "table"), (50, True, "table"),
+                                               (50, False, "table"), (20, True, "stream"), (12, False, "stream"),
+                                               (50, True, "stream")])
+def test_round_loop_matches_oracle(n, dynamic, supply):
+    """``supply`` "stream": the episodes come from the device sampler through a 5-slot ring (3 slots at N = 50; refilled every 2 rounds - every round -
+    on a side stream), so every env's k-th reset - far beyond the first ring - must equal the oracle env's k-th reset."""
     from melissa_amd import _lib as L
     from melissa_amd.collect import RoundLoop, sample_episode_table
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
@@ -112,8 +116,14 @@ def test_round_loop_matches_oracle(n, dynamic):
     packed, table = sample_episode_table(venv, 14, seed)
     from melissa_amd.replay import RoundReplay
     replay = RoundReplay(B, n, 8, "cuda")
-    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed, replay=replay,
-                     episodes=({k: v for k, v in packed.items()}, np.ascontiguousarray(table[:, 1:])))
+    if supply == "stream":
+        # (N = 50: the greedy random-weight policy plays ~12-round episodes, so a 3-slot ring refilled EVERY round)
+        ring = 5 if n < 50 else 3
+        loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed, replay=replay, ring=ring, discard=1)
+        K = 70
+    else:
+        loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed, replay=replay,
+                         episodes=({k: v for k, v in packed.items()}, np.ascontiguousarray(table[:, 1:])))
     refs = []
     for b in range(B):
         env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in graphs],
@@ -173,6 +183,8 @@ def test_round_loop_matches_oracle(n, dynamic):
             assert [int(x) for x in one_hop[b]] == e.adj
     c = loop.counters()
     assert c["errors"] == 0 and c["episodes"] >= 3 and checked_rows > 100 and recorded_rounds > 100
+    if supply == "stream":                     # every env went round its ring at least once
+        assert int(venv.scalars()[:, L.S_EP_CURSOR].min()) > ring
     # episode log: one row per finished episode = the logger_stats of its final observation (graph.py:166-178), per env
     # in the order the episodes ended
     stats, meta, total = venv.read_episode_log()
