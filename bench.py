@@ -97,9 +97,21 @@ def stage_flops(totals, model="l_dgn"):
     }
 
 
-def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
-    """The CPU oracle timed on the host cores: torch fp32 restatement of the forward (all cores) +
-    step-for-step Python restatement of the env loop, 40 envs (the reference's --training-num)."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(n_nodes, envs=40, warm=3, reps=10, rep_seconds=1.0):
+    """The CPU oracle timed on the host cores: torch fp32 restatement of the forward (all usable cores)
+    + step-for-step Python restatement of the env loop, 40 envs (the reference's --training-num).  3 warm-up + 10 timed
+    repetitions of a fixed number of collector iterations (calibrated to ~1 s each): median (= ``value``), min, max."""
     import torch
     from oracle import env_oracle as eo
     from oracle import net_oracle as no
@@ -114,25 +126,37 @@ def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
         np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(1000 + k))))) for k in range(envs)]
     sd = no.init_weights("l_dgn", seed=9)
     obs = [w.reset()[0] for w in workers]
-    decisions, iters = 0, 0
-    with torch.no_grad():                        # warm-up (thread pool, allocator), not timed
-        no.ldgn_forward(sd, np.stack([o["obs"] for o in obs]), n_nodes)
+
+    def iterate(count):
+        live_total = 0
+        with torch.no_grad():
+            for _ in range(count):
+                batch = np.stack([o["obs"] for o in obs])
+                act = no.dqn_act(no.ldgn_forward(sd, batch, n_nodes), np.stack([o["mask"] for o in obs])).numpy()
+                for k, w in enumerate(workers):
+                    live_total += int(bool(obs[k]["mask"][0]))
+                    o, _r, term, _tr, info = w.step(int(act[k]))
+                    if term and info.get("explicit_reset"):
+                        o, _ = w.reset()
+                    obs[k] = o
+        return live_total
+
     t0 = time.perf_counter()
-    with torch.no_grad():
-        while time.perf_counter() - t0 < budget_s:
-            batch = np.stack([o["obs"] for o in obs])
-            act = no.dqn_act(no.ldgn_forward(sd, batch, n_nodes), np.stack([o["mask"] for o in obs])).numpy()
-            for k, w in enumerate(workers):
-                live = bool(obs[k]["mask"][0])
-                o, _r, term, _tr, info = w.step(int(act[k]))
-                decisions += int(live)
-                if term and info.get("explicit_reset"):
-                    o, _ = w.reset()
-                obs[k] = o
-            iters += 1
-    dt = time.perf_counter() - t0
+    iterate(2)                                    # thread pool / allocator warm-up + calibration
+    per_iter = (time.perf_counter() - t0) / 2
+    iters = max(1, int(round(rep_seconds / max(per_iter, 1e-4))))
+    rates, decisions = [], 0
+    for r in range(warm + reps):
+        t0 = time.perf_counter()
+        d = iterate(iters)
+        dt = time.perf_counter() - t0
+        if r >= warm:
+            rates.append(d / dt)
+            decisions += d
+    rates.sort()
+    median = rates[len(rates) // 2] if len(rates) % 2 else 0.5 * (rates[len(rates) // 2 - 1] + rates[len(rates) // 2])
     # bs = 1 (the --watch configuration, BASELINE config 0): one env, a few seconds
-    one, obs1, d1 = workers[0], None, 0
+    one, d1 = workers[0], 0
     obs1, _ = one.reset()
     t1 = time.perf_counter()
     with torch.no_grad():
@@ -143,11 +167,12 @@ def cpu_baseline(n_nodes, budget_s=12.0, envs=40):
             if term and info.get("explicit_reset"):
                 obs1, _ = one.reset()
     bs1 = d1 / (time.perf_counter() - t1)
-    return {"value": decisions / dt, "unit": "agent-decisions/s", "cores": cores, "kind": "port",
-            "value_bs1": bs1,
-            "sample": f"{iters} collector iterations over {envs} envs ({decisions} live decisions, {dt:.1f} s): "
-                      f"oracle L-DGN forward (torch CPU fp32, {cores} threads) + Python env restatement, "
-                      f"N={n_nodes}, dynamic graph"}
+    return {"value": median, "unit": "agent-decisions/s", "cores": cores, "kind": "port",
+            "median": median, "min": rates[0], "max": rates[-1], "repetitions": reps, "warmup_repetitions": warm,
+            "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "value_bs1": bs1,
+            "sample": f"{reps} timed repetitions (after {warm} warm-up) of {iters} collector iterations over {envs} envs "
+                      f"({decisions} live decisions): oracle L-DGN forward (torch CPU fp32, {cores} threads) + Python env "
+                      f"restatement, N={n_nodes}, dynamic graph"}
 
 
 def _env_worker(conn, n_nodes, seeds):
@@ -213,6 +238,219 @@ def cpu_baseline_subproc(n_nodes, budget_s=8.0, workers=None, envs_per_worker=5)
             "sample": f"{iters} iterations, {workers} env-worker processes x {envs_per_worker} envs + one learner ({dt:.1f} s)"}
 
 
+def timed_run(loop, steps, warmup, device, parallel):
+    """W untimed warm-up steps, then EXACTLY ``steps`` steps bracketed by barrier + synchronize on both sides; the time is
+    the max over ranks, the counters are summed over ranks (whole-job throughput)."""
+    import torch
+    loop.run(warmup)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    c0 = loop.counters()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    loop.run(steps)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt_local = time.perf_counter() - t0
+    c1 = loop.counters()
+    local_dec = float(c1["decisions"] - c0["decisions"])
+    dt = parallel.all_reduce_max(dt_local, device)
+    return {"dt": dt, "dt_local": dt_local, "local_decisions": local_dec,
+            "decisions": parallel.all_reduce_sum(local_dec, device),
+            "episodes": parallel.all_reduce_sum(float(c1["episodes"] - c0["episodes"]), device),
+            "errors": parallel.all_reduce_sum(float(c1["errors"]), device)}
+
+
+def pmc_traffic():
+    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE in separate
+    passes, gfx950 correction applied by tools/pmc_traffic.py).  The file records the hash of the library sources it was
+    taken on; if the kernels have changed since, the bytes no longer belong to the timed launches and are NOT reported."""
+    from melissa_amd import build
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if rec.get("source_hash") == build.source_hash():
+            return rec.get("per_launch", {}), f"profiles/{name} (rocprofv3 --pmc, same library sources: {rec['source_hash'][:12]})"
+        return {}, f"none: profiles/{name} was taken on other library sources ({str(rec.get('source_hash'))[:12]})"
+    return {}, "none: no PMC pass committed"
+
+
+def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
+    """Per-stage HIP-event timing of the same step in a separate, untimed pass (eager launches of ONE launch chain, each
+    launch group bracketed by an event pair on its stream) -> stage_us, the MFMA roofline of the dominant GEMM launch,
+    HBM-side rooflines of the gather / env kernels, forward-only and env-only rates."""
+    import torch
+    from melissa_amd import _lib
+    if args.mode == "round" and args.streams > 1:
+        torch.cuda.synchronize()
+        _n, _v, ploop = build_workload(device, rank, args.envs, args.nodes, args.model, "round", False, 1, dtype=args.dtype)
+        ploop.run(args.warmup)
+    else:
+        ploop = loop
+        if args.mode == "round":
+            ploop.use_graph = False
+    steps = min(args.steps, 200)
+    rows_cap = ploop.rows_cap if (args.mode == "round" and args.model != "hl_dgn") else 0
+    torch.cuda.synchronize()
+    prof = lib.mel_prof_create(steps * 24)
+    totals = torch.zeros(steps, 3, dtype=torch.int32, device=device)
+    ws = ploop.workspace if args.mode == "round" else net._ws
+    lib.mel_prof_attach(prof)
+    for k in range(steps):
+        ploop.step()
+        if args.model != "hl_dgn":
+            _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, rows_cap, ws.data_ptr(),
+                                           totals[k].data_ptr(), _lib.current_stream_ptr(device)))
+    lib.mel_prof_attach(None)
+    torch.cuda.synchronize()
+    ms = (C.c_double * _lib.N_STAGES)()
+    cnt = (C.c_int64 * _lib.N_STAGES)()
+    lib.mel_prof_read(prof, ms, cnt)
+    lib.mel_prof_destroy(prof)
+    # us per STEP: a stage that brackets several launches per step is their sum; env_reset = the episode stream's refill
+    # launches (issued every few rounds on a side stream), averaged over the steps
+    stages = {name: (ms[i] / steps * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}
+    mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model != "hl_dgn"
+                else (0.0, float(args.envs * args.nodes), float(args.envs)))
+    if args.model == "hl_dgn":
+        fl = {"encoder": args.envs * args.nodes * 34048.0, "conv1_lin": 2.0 * args.envs * args.nodes * 2 * HC * HIDDEN,
+              "head_hidden": 2.0 * args.envs * (HC * 256 + 2 * 128 * 128)}
+    else:
+        fl = stage_flops(mean_tot, args.model)
+    dom = max(fl, key=lambda k: stages.get(k, 0.0))
+    pmc, pmc_source = pmc_traffic()
+    same = (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
+            and args.dtype == "f32")
+    key = {"conv1_lin": "conv1 (lin_l+lin_r)", "conv2_lin": "conv2 (lin_l+lin_r)"}.get(dom)
+    traffic = pmc.get(key, {}).get("hbm_bytes_corrected") if same else None
+    achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
+    # f32s: six bf16 MFMAs per product term set -> the matrix-pipe ceiling for fp32-accurate FLOPs is 2.5 PF / 6
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
+    tag = {"conv1_lin": 1, "conv2_lin": 2, "head_hidden": 3}.get(dom, 0)
+    if args.dtype == "f32" and args.mode == "round" and args.model == "l_dgn" and dom != "encoder":
+        kname = f"mel::gemm_f32_persistent_kernel<2, 2, 1, 1, 0, {tag}> ({dom})"   # as rocprofv3 summaries name it
+    else:
+        kname = f"gemm_{args.dtype} ({dom})"
+    whole_flops = float(sum(fl.values()))
+    step_us = sum(v for k, v in stages.items() if k != "env_reset")
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": pmc_source if same else "none: PMC passes exist for the default workload only",
+                "avg_launch_us": round(stages[dom], 2), "algorithmic_flops_per_launch": fl[dom],
+                "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]), "agent_rows": float(mean_tot[2])},
+                "whole_step": {"algorithmic_flops": whole_flops, "stage_sum_us": round(step_us, 2),
+                               "achieved": round(whole_flops / (step_us * 1e-6) / 1e12, 3) if step_us > 0 else None,
+                               "frac": round(whole_flops / (step_us * 1e-6) / 1e12 / peak, 4) if step_us > 0 else None}}
+
+    # HBM-side rooflines of the non-contraction kernels (SURVEY.md 8(d)): COMPULSORY bytes per launch - every row the launch
+    # needs read once, every row it produces written once - over the launch's average duration, against the HBM peak.  They
+    # are latency / VALU bound (DESIGN.md section 5); the fractions say how far from a streaming kernel they are.
+    hbm_rooflines = None
+    if args.mode == "round" and args.model == "l_dgn":
+        esz = 2 if args.dtype == "bf16" else 4
+        u1, u2, r = (float(x) for x in mean_tot)
+        row = HC * esz
+        att1 = (u2 + u1) * row + u1 * row + r * (HIDDEN + HC) * esz        # x_l rows + x_r rows read, h1 + x_1|x_2 written
+        att2 = (u1 + r) * row + r * row                                      # x_l2 rows + x_r2 rows read, x_3 written
+        env_b = 2.0 * float(lib.mel_env_state_bytes(args.envs, args.nodes))  # every env's state read + written once
+        hbm_rooflines = []
+        for name, stage, nbytes, key in (("gat_attend_rows_kernel<8, 0, ...> (conv1 attention)", "conv1_att", att1, "conv1 attention"),
+                                         ("gat_attend_rows_kernel<8, 2, ...> (conv2 attention)", "conv2_att", att2, "conv2 attention"),
+                                         ("env_round_kernel", "env_step", env_b, "env round")):
+            us = stages.get(stage, 0.0)
+            if us <= 0:
+                continue
+            gbs = nbytes / (us * 1e-6) / 1e9
+            hbm_rooflines.append({"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                                  "avg_launch_us": round(us, 2),
+                                  "traffic": pmc.get(key, {}).get("hbm_bytes_corrected") if same else None})
+    fwd_us = sum(v for k, v in stages.items() if k not in ("env_step", "env_reset"))
+    rows = decisions_per_step if args.mode == "round" else float(args.envs)
+    parts = {"forward_only_rows_per_s": rows / (fwd_us * 1e-6) if fwd_us > 0 else None, "forward_us": round(fwd_us, 2),
+             "env_only_world_rounds_per_s": (args.envs / (stages["env_step"] * 1e-6)
+                                             if args.mode == "round" and stages.get("env_step", 0) > 0 else None),
+             "env_only_agent_steps_per_s": (args.envs / (stages["env_step"] * 1e-6)
+                                            if args.mode == "aec" and stages.get("env_step", 0) > 0 else None),
+             "episode_refill_us_per_step": round(stages.get("env_reset", 0.0), 2)}
+    return roofline, stages, hbm_rooflines, parts
+
+
+def extra_leg(args, device, rank, parallel, note, **over):
+    """Another configuration timed exactly like the headline (same barriers, same counters, same steps / warm-up)."""
+    kw = dict(envs=args.envs, nodes=args.nodes, model=args.model, mode=args.mode, dtype=args.dtype)
+    kw.update(over)
+    import torch
+    net, venv, lp = build_workload(device, rank, kw["envs"], kw["nodes"], kw["model"], kw["mode"],
+                                   kw["mode"] == "round" and not args.no_graph, 1, dtype=kw["dtype"])
+    t = timed_run(lp, args.steps, args.warmup, device, parallel)
+    out = {"value": t["decisions"] / t["dt"], "unit": "agent-decisions/s", "ms_per_step": t["dt"] / args.steps * 1e3,
+           "decisions_per_step": t["decisions"] / args.steps, "env_error_flags": t["errors"],
+           "workload": f"{kw['model'].upper().replace('_', '-')} {kw['nodes']}-node, {kw['envs']} envs per GPU, {kw['dtype']}, "
+                       f"{'round-batched' if kw['mode'] == 'round' else 'AEC-order'} loop", "note": note}
+    del lp, venv, net
+    torch.cuda.empty_cache()
+    return out
+
+
+def learner_leg(args, device, rank, world, parallel, updates=30, rounds_per_update=4, envs=512):
+    """BASELINE configs[3]'s per-GPU share WITH its one collective: HL-DGN, 512 envs per GPU, collect 4 rounds then one
+    DQN update of batch 32 whose flat fp32 gradient (315 139 elements = 1.26 MB) is summed over the ranks with ONE
+    all-reduce (RCCL over xGMI; `allreduce_us` = that collective alone, HIP events, mean of 50)."""
+    import torch
+    import torch.distributed as dist
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import HLDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from melissa_amd.replay import DQNLearner, RoundReplay
+    torch.manual_seed(9)
+    net = HLDGNNetwork(5, HIDDEN, 2, HEADS, args.nodes, aggregator="max", dueling_param=dueling(), device=device)
+    parallel.broadcast_parameters(net, src=0)
+    policy = DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-3), estimation_step=4, target_update_freq=500)
+    venv = HipGraphVectorEnv(envs, args.nodes, graph_pool=synthetic_graph_pool(args.nodes, 64, 0), dynamic_graph=True,
+                             device=device, max_moves=48, seed=5000 + rank * envs, construct_like_reference=False)
+    replay = RoundReplay(envs, args.nodes, 32, device)
+    loop = RoundLoop(venv, policy, seed=5000 + rank * envs, eps=0.1, replay=replay, ring=RING)
+    reducer = parallel.FlatGradAllReducer(net)
+    learner = DQNLearner(policy, replay, batch_size=32, n_step=4, gamma=0.99, grad_hook=reducer, seed=rank)
+    with torch.no_grad():
+        loop.run(8)
+    learner.step()                                             # warm-up update (lazy init of the autograd kernels, RCCL)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    c0 = loop.counters()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        with torch.no_grad():
+            loop.run(rounds_per_update)
+        learner.step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = parallel.all_reduce_max(time.perf_counter() - t0, device)
+    dec = parallel.all_reduce_sum(float(loop.counters()["decisions"] - c0["decisions"]), device)
+    allreduce_us = None
+    if world > 1:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(5):
+            dist.all_reduce(reducer.flat)
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(50):
+            dist.all_reduce(reducer.flat)
+        ev[1].record()
+        torch.cuda.synchronize()
+        allreduce_us = parallel.all_reduce_max(ev[0].elapsed_time(ev[1]) / 50 * 1e3, device)
+    return {"workload": f"HL-DGN {args.nodes}-node, {envs} envs per GPU, fp32: {rounds_per_update} rounds + 1 DQN update (batch 32 per "
+                        f"rank, n-step 4) per iteration, flat-gradient all-reduce over {world} rank(s)",
+            "updates": updates, "updates_per_s": updates / dt, "value": dec / dt, "unit": "agent-decisions/s",
+            "grad_elements": reducer.numel, "grad_bytes": reducer.numel * 4, "allreduce_us": allreduce_us,
+            "backend": (dist.get_backend() if world > 1 else None)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,17 +462,16 @@ def main():
     ap.add_argument("--mode", default="round", choices=["round", "aec"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--streams", type=int, default=1,
-                    help="round mode: sub-batches of the GPU's envs on separate HIP streams (measured: no gain "
-                         "in one process, 16.3 vs 16.2 M/s at 2 streams, worse at 3-4)")
+                    help="round mode: sub-batches of the GPU's envs on separate HIP streams")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"],
                     help="f32 (default): the reference's arithmetic, logits within 1e-4.  bf16: BASELINE's 'bf16 feature "
                          "path' (feature rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the extra timed pass of the default (fp32) run on BASELINE's 'bf16 feature path' (its kernels "
-                         "carry other names, so a rocprofv3 summary of the default command still prices the fp32 kernels; "
-                         "the two-stream schedule is `--streams 2`: its half-batch launches would not)")
+                    help="skip the extra timed legs of the default run (bf16 feature path, BASELINE configs[1] and [3], "
+                         "AEC-order loop, sustained run, learner leg)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
@@ -260,6 +497,8 @@ def main():
     import torch
     from melissa_amd import _lib, parallel
     rank, local_rank, world = parallel.init_distributed("gloo" if args.rehearse_on_one_gpu else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -270,194 +509,92 @@ def main():
                                      args.streams, dtype=args.dtype)
     lib = _lib.load()
 
-    loop.run(args.warmup)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    c0 = loop.counters()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    t0 = time.perf_counter()
-    loop.run(args.steps)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
-    c1 = loop.counters()
-    dt = parallel.all_reduce_max(dt, device)
-    decisions = parallel.all_reduce_sum(float(c1["decisions"] - c0["decisions"]), device)
-    episodes = parallel.all_reduce_sum(float(c1["episodes"] - c0["episodes"]), device)
-    errors = parallel.all_reduce_sum(float(c1["errors"]), device)
+    t = timed_run(loop, args.steps, args.warmup, device, parallel)
+    dt, decisions, episodes, errors = t["dt"], t["decisions"], t["episodes"], t["errors"]
+    # per-rank rates (each rank's own decisions over its own wall time), gathered for the line
+    per_rank = [0.0] * world
+    per_rank[rank] = t["local_decisions"] / t["dt_local"]
+    per_rank = [parallel.all_reduce_sum(v, device) for v in per_rank]
+    supply = loop.supply.describe() if hasattr(loop, "supply") else loop.loops[0].supply.describe()
 
-    # ---- per-stage HIP-event timing of the same step (separate, untimed pass) ----------------------
-    roofline, stages = None, None
+    # ---- sustained leg: the same loop for >= ~2.5 s of wall time (the timed region above is a few ms at the driver's
+    # --steps 20, too short for a utilisation sampler to see the GPU busy)
+    sustained = None
+    if not args.no_extra_legs and args.sustained_seconds > 0:
+        n_sus = max(args.steps, int(args.sustained_seconds / max(dt / args.steps, 1e-6)))
+        ts = timed_run(loop, n_sus, 0, device, parallel)
+        sustained = {"steps": n_sus, "seconds": ts["dt"], "value": ts["decisions"] / ts["dt"], "unit": "agent-decisions/s",
+                     "ms_per_step": ts["dt"] / n_sus * 1e3, "episodes_finished": ts["episodes"], "env_error_flags": ts["errors"]}
+
+    roofline = stages = hbm_rooflines = parts = None
     if not args.no_profile and rank == 0:
-        # stage timers bracket eager launches of ONE launch chain over all of the GPU's envs (same kernels,
-        # same row counts per launch as a single-stream step; the timed pass above may overlap sub-batches)
-        if args.mode == "round" and args.streams > 1:
-            torch.cuda.synchronize()
-            _n, _v, ploop = build_workload(device, rank, args.envs, args.nodes, args.model, "round", False, 1,
-                                           dtype=args.dtype)
-            ploop.run(args.warmup)
-        else:
-            ploop = loop
-            if args.mode == "round":
-                ploop.use_graph = False
-        rows_cap = ploop.rows_cap if (args.mode == "round" and args.model != "hl_dgn") else 0
-        torch.cuda.synchronize()
-        prof = lib.mel_prof_create(args.steps * 16)
-        totals = torch.zeros(args.steps, 3, dtype=torch.int32, device=device)
-        ws = ploop.workspace if args.mode == "round" else net._ws
-        lib.mel_prof_attach(prof)
-        for k in range(args.steps):
-            ploop.step()
-            if args.model != "hl_dgn":
-                _lib.check(lib.mel_forward_tap(C.byref(net._weights()), 2, args.envs, args.nodes, rows_cap, ws.data_ptr(),
-                                               totals[k].data_ptr(), _lib.current_stream_ptr(device)))
-        lib.mel_prof_attach(None)
-        torch.cuda.synchronize()
-        ms = (C.c_double * _lib.N_STAGES)()
-        cnt = (C.c_int64 * _lib.N_STAGES)()
-        lib.mel_prof_read(prof, ms, cnt)
-        lib.mel_prof_destroy(prof)
-        # us per STEP: a stage that brackets several launches per step (the heads' two hidden layers) is their sum
-        stages = {name: (ms[i] / args.steps * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}
-        mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model != "hl_dgn"
-                    else (0.0, float(args.envs * args.nodes), float(args.envs)))
-        if args.model == "hl_dgn":
-            fl = {"encoder": args.envs * args.nodes * 34048.0, "conv1_lin": 2.0 * args.envs * args.nodes * 2 * HC * HIDDEN,
-                  "head_hidden": 2.0 * args.envs * (HC * 256 + 2 * 128 * 128)}
-        else:
-            fl = stage_flops(mean_tot, args.model)
-        dom = max(fl, key=lambda k: stages.get(k, 0.0))
-        # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-        # (FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied there); only valid for the
-        # workload those passes were taken on.
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")
-        if (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
-                and args.dtype == "f32" and os.path.exists(pmc_path)):
-            pmc = json.load(open(pmc_path))["per_launch"]
-            key = {"conv1_lin": "conv1 (lin_l+lin_r)", "conv2_lin": "conv2 (lin_l+lin_r)", "head_hidden": None}.get(dom)
-            if key in pmc:
-                traffic = pmc[key]["hbm_bytes_corrected"]
-        achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
-        # f32s: six bf16 MFMAs per product term set -> the matrix-pipe ceiling for fp32-accurate FLOPs is 2.5 PF / 6
-        peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
-        # name as it appears in rocprofv3 summaries (fp32 round loop: the persistent kernel tagged per call site)
-        tag = {"conv1_lin": 1, "conv2_lin": 2, "head_hidden": 3}.get(dom, 0)
-        if args.dtype == "f32" and args.mode == "round" and args.model == "l_dgn" and dom != "encoder":
-            kname = f"mel::gemm_f32_persistent_kernel<2, 2, 1, 1, 0, {tag}> ({dom})"
-        else:
-            kname = f"gemm_{args.dtype} ({dom})"
-        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 3),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": traffic, "avg_launch_us": round(stages[dom], 2),
-                    "algorithmic_flops_per_launch": fl[dom],
-                    "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]),
-                                        "agent_rows": float(mean_tot[2])}}
+        roofline, stages, hbm_rooflines, parts = stage_profile(args, lib, net, loop, device, rank,
+                                                               decisions / args.steps / world)
+    parallel.barrier()
 
-    # HBM-side rooflines of the non-contraction kernels ("the gather / edge-softmax / pool stage ...
-    # reported separately as achieved GB/s ... env step: report GB/s"): COMPULSORY bytes per launch - every row the
-    # launch needs read once, every row it produces written once - over the launch's average duration, against HBM peak.
-    # They are latency / VALU bound, the fractions say how far from a streaming kernel they are.
-    hbm_rooflines = None
-    if stages and args.mode == "round" and args.model == "l_dgn":
-        esz = 2 if args.dtype == "bf16" else 4
-        u1, u2, r = (float(x) for x in mean_tot)
-        row = HC * esz
-        att1 = (u2 + u1) * row + u1 * row + r * (HIDDEN + HC) * esz        # x_l rows + x_r rows read, h1 + x_1|x_2 written
-        att2 = (u1 + r) * row + r * row                                      # x_l2 rows + x_r2 rows read, x_3 written
-        env_b = 2.0 * args.envs * (8968 if args.nodes == 50 else float(lib.mel_env_state_bytes(args.envs, args.nodes)) / args.envs)
-        pmc_extra = {}
-        if traffic is not None or os.path.exists(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json")):
-            try:
-                pmc_extra = json.load(open(os.path.join(ROOT, "profiles", "r01k_pmc_traffic.json"))).get("per_launch", {})
-            except (OSError, ValueError):
-                pmc_extra = {}
-        same = (args.nodes == N_NODES and args.envs == ENVS_PER_GPU and args.dtype == "f32")
-        hbm_rooflines = []
-        for name, stage, nbytes, key in (("gat_attend_rows_kernel<8, 0, ...> (conv1 attention)", "conv1_att", att1, "conv1 attention"),
-                                         ("gat_attend_rows_kernel<8, 2, ...> (conv2 attention)", "conv2_att", att2, "conv2 attention"),
-                                         ("env_round_kernel", "env_step", env_b, "env round")):
-            us = stages.get(stage, 0.0)
-            if us <= 0:
-                continue
-            gbs = nbytes / (us * 1e-6) / 1e9
-            hbm_rooflines.append({"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes),
-                                  "avg_launch_us": round(us, 2),
-                                  "traffic": pmc_extra.get(key, {}).get("hbm_bytes_corrected") if same else None})
-
-    # forward-only rows/s and env-only world-rounds/s, from the same stage timers: agent rows
-    # of one step / the forward stages' time, envs of one step / the env launch's time
-    parts = None
-    if stages:
-        fwd_us = sum(v for k, v in stages.items() if k != "env_step")
-        rows = decisions / args.steps / world if args.mode == "round" else float(args.envs)
-        parts = {"forward_only_rows_per_s": rows / (fwd_us * 1e-6) if fwd_us > 0 else None,
-                 "forward_us": round(fwd_us, 2),
-                 "env_only_world_rounds_per_s": (args.envs / (stages["env_step"] * 1e-6)
-                                                 if args.mode == "round" and stages.get("env_step", 0) > 0 else None),
-                 "env_only_agent_steps_per_s": (args.envs / (stages["env_step"] * 1e-6)
-                                                if args.mode == "aec" and stages.get("env_step", 0) > 0 else None)}
-
-    # ---- second timed pass: the same workload on BASELINE configs[2]'s "bf16 feature path" -------------------------
-    # `value` stays the fp32 number (logits within the 1e-4 parity bar); this leg records, in the same line, the rate of
-    # the configuration as BASELINE.json words it (feature rows + projection weights bf16, fp32 accumulate / softmax /
-    # logits; logits within 5e-4 of fp32, greedy actions identical on every test row).  Same barriers, same counters.
-    bf16_leg = None
-    if (args.dtype == "f32" and args.mode == "round" and args.streams == 1 and args.model == "l_dgn"
-            and not args.no_extra_legs):
+    # ---- extra legs: other BASELINE configurations, timed like the headline -----------------------------------------------
+    legs = None
+    default_cfg = (args.dtype == "f32" and args.mode == "round" and args.streams == 1 and args.model == "l_dgn"
+                   and args.nodes == N_NODES)
+    if default_cfg and not args.no_extra_legs:
         del loop, venv
-
-        def timed_leg(dtype, streams):
-            _net, _venv, lp = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph,
-                                             streams, dtype=dtype)
-            lp.run(args.warmup)
-            torch.cuda.synchronize()
-            parallel.barrier()
-            b0 = lp.counters()
-            torch.cuda.synchronize()
-            parallel.barrier()
-            t0 = time.perf_counter()
-            lp.run(args.steps)
-            torch.cuda.synchronize()
-            parallel.barrier()
-            dt2 = parallel.all_reduce_max(time.perf_counter() - t0, device)
-            b1 = lp.counters()
-            dec2 = parallel.all_reduce_sum(float(b1["decisions"] - b0["decisions"]), device)
-            return {"value": dec2 / dt2, "unit": "agent-decisions/s", "ms_per_step": dt2 / args.steps * 1e3}
-
+        torch.cuda.empty_cache()
+        specs = {
+            "bf16_feature_path": dict(note="BASELINE configs[2] as worded: feature rows + projection weights bf16, fp32 accumulate / "
+                                           "softmax / logits; logits within 5e-4 of the fp32 path", dtype="bf16"),
+            "config1_ldgn_n20_256envs": dict(note="BASELINE configs[1]: L-DGN 20-node, 256 vectorised envs, fp32", nodes=20, envs=256),
+            "config3_hldgn_512envs_per_gpu": dict(note="BASELINE configs[3]'s per-GPU share: HL-DGN 50-node, 4096 envs over 8 GPUs = 512 "
+                                                       "per GPU (collect path; its collective is in learner_leg)", model="hl_dgn", envs=512),
+            "aec_order_loop": dict(note="the reference collector's granularity (multi_agent_collector.py:150-308): one agent decision "
+                                        "per env per step", mode="aec"),
+        }
+        legs = {}
+        for name, spec in specs.items():
+            try:
+                legs[name] = extra_leg(args, device, rank, parallel, **spec)
+            except Exception as exc:          # an extra leg must never cost the headline line (one rank: no barrier to desync)
+                if world > 1:
+                    raise
+                legs[name] = {"error": repr(exc)}
         try:
-            bf16_leg = dict(dtype="bf16", **timed_leg("bf16", 1),
-                            note="same workload on BASELINE's 'bf16 feature path' (feature rows + projection weights bf16, "
-                                 "fp32 accumulate / softmax / logits; logits within 5e-4 of the fp32 path)")
-        except Exception as exc:              # an extra leg must never cost the headline line (one rank: no barrier to desync)
+            legs["learner_leg"] = learner_leg(args, device, rank, world, parallel)
+        except Exception as exc:
             if world > 1:
                 raise
-            bf16_leg = {"error": repr(exc)}
+            legs["learner_leg"] = {"error": repr(exc)}
 
     parallel.barrier()
     if rank != 0:
         return
     value = decisions / dt
+    prec = dict(f32="fp32", bf16="bf16 feature path", f32s="fp32 via split-bf16 MFMA")[args.dtype]
     line = {
         "metric": "env-steps/s (agent-decisions/s) L-DGN 50-node" if args.model == "l_dgn" and args.nodes == 50
                   else f"env-steps/s (agent-decisions/s) {args.model} {args.nodes}-node",
         "value": value, "unit": "agent-decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs "
-                               f"per GPU, {dict(f32='fp32', bf16='bf16 feature path', f32s='fp32 via split-bf16 MFMA')[args.dtype]}, dynamic graph, eps=0.001, "
+        "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs per GPU, {prec}, "
+                               f"dynamic graph, eps=0.001, "
                                + ("round-batched loop (one env round per step)" if args.mode == "round"
-                                  else "AEC-order loop (one agent decision per env per step)"),
+                                  else "AEC-order loop (one agent decision per env per step)")
+                               + f"; graphs: the first {N_GRAPHS} connected nx.random_geometric_graph(n, 0.2, seed=s); episodes: "
+                               + (f"device episode stream - every reset draws a NEW episode (graph, source, interested set, movement "
+                                  f"seed) with the reference's RNG protocol, ring of {supply.get('ring')} slots per env refilled every "
+                                  f"{supply.get('refill_every')} steps on a side stream inside the timed region, reset snapshots rebuilt "
+                                  f"by the refill (no episode is ever replayed)" if supply["mode"] == "device stream"
+                                  else f"static table of {supply.get('episodes_per_env')} pre-drawn episodes per env"),
                    "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),
                    "streams": args.streams if args.mode == "round" else 1,
                    "envs_per_gpu": args.envs, "n_nodes": args.nodes, "global_envs": args.envs * world,
-                   "parallelism": f"env-shard x{world} (no data-path collective)",
+                   "parallelism": f"env-shard x{world} (no data-path collective)", "episode_supply": supply,
                    "decisions_per_step": decisions / args.steps, "live_decisions": decisions, "episodes_finished": episodes,
                    "env_error_flags": errors},
+        "rccl_ranks": world if (world > 1 and not args.rehearse_on_one_gpu) else 0,
+        "per_rank_value": per_rank,
         "roofline": roofline,
-        "bf16_feature_path": bf16_leg,
+        "sustained": sustained,
+        "legs": legs,
         "stage_us": {k: round(v, 2) for k, v in (stages or {}).items() if v > 0},
         "parts": parts,
         "roofline_hbm": hbm_rooflines,
