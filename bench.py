@@ -36,7 +36,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0            # same guide, HBM3E ~8 TB/s
 N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
-N_GRAPHS, RING = 1024, 16
+N_GRAPHS, RING = 1024, int(os.environ.get("MEL_BENCH_RING", "16"))
+MAX_MOVES = int(os.environ.get("MEL_BENCH_MAX_MOVES", "48"))      # movement draws kept per episode (tuning knob)
 HC = HIDDEN * HEADS
 
 
@@ -44,7 +45,7 @@ def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
 
 
-def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9, dtype="f32"):
+def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9, dtype="f32", supply="stream"):
     import torch
     from melissa_amd.collect import DecisionLoop, MultiStreamRoundLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
@@ -63,19 +64,20 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
     # the first 1024 accepted seeds of nx.random_geometric_graph(n, 0.2, seed=s), connected ones only
     graphs = synthetic_graph_pool(n_nodes, N_GRAPHS, first_seed=0)
     make_venv = lambda count, seed: HipGraphVectorEnv(count, n_nodes, graph_pool=graphs, dynamic_graph=True,
-                                                      device=device, max_moves=48, seed=seed,
+                                                      device=device, max_moves=MAX_MOVES, seed=seed,
                                                       construct_like_reference=False)
     policy = DQNPolicy(net)
     base = 1000 + rank * envs
     if mode == "round" and streams > 1:
         loop = MultiStreamRoundLoop(make_venv, policy, envs, streams=streams, seed=base,
-                                    eps=0.001, use_graph=use_graph)                       # test eps (l_dgn.py:107)
+                                    eps=0.001, use_graph=use_graph, ring=RING)            # test eps (l_dgn.py:107)
         venv = loop.loops[0].venv
     elif mode == "round":
         venv = make_venv(envs, base)
         # episodes: the device episode stream (every reset draws a new episode, core.py:372-394; ring of 16 slots per env
         # refilled every 7 rounds on a side stream INSIDE the timed region, resets included)
-        loop = RoundLoop(venv, policy, seed=base, eps=0.001, use_graph=use_graph, ring=RING)
+        loop = RoundLoop(venv, policy, seed=base, eps=0.001, use_graph=use_graph, ring=RING,
+                         episode_stream=None if supply == "stream" else False, episodes_per_env=12)
     else:
         venv = make_venv(envs, base)
         loop = DecisionLoop(venv, policy, seed=base, eps=0.001)
@@ -472,6 +474,9 @@ def main():
                          "AEC-order loop, sustained run, learner leg)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--sustained-seconds", type=float, default=2.5)
+    ap.add_argument("--episode-supply", default="stream", choices=["stream", "table"],
+                    help="stream (default): every reset draws a new episode on the device.  table: round 1's 12 pre-drawn episodes "
+                         "per env that wrap (A/B of the stream's cost only; the wrap raises the env's underrun flag)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
@@ -506,7 +511,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     net, venv, loop = build_workload(device, rank, args.envs, args.nodes, args.model, args.mode, not args.no_graph,
-                                     args.streams, dtype=args.dtype)
+                                     args.streams, dtype=args.dtype, supply=args.episode_supply)
     lib = _lib.load()
 
     t = timed_run(loop, args.steps, args.warmup, device, parallel)

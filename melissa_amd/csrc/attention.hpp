@@ -398,11 +398,11 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         switch (hc / 64) {
 #define MEL_POOL_LAUNCH(V)                                                                                         \
     if (a.bs >= 2048) {                                                                                           \
-        if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true, 4>), dim3(a.bs), dim3(256), 0, s, a);     \
-        else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false, 4>), dim3(a.bs), dim3(256), 0, s, a);           \
+        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 4>), dim3(a.bs), dim3(256), 0, s, a);     \
+        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 4>), dim3(a.bs), dim3(256), 0, s, a);           \
     } else {                                                                                                      \
-        if (a.bf16) hipLaunchKernelGGL((gat_attend_pool_kernel<V, true, 16>), dim3(a.bs), dim3(1024), 0, s, a);   \
-        else hipLaunchKernelGGL((gat_attend_pool_kernel<V, false, 16>), dim3(a.bs), dim3(1024), 0, s, a);         \
+        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 16>), dim3(a.bs), dim3(1024), 0, s, a);   \
+        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 16>), dim3(a.bs), dim3(1024), 0, s, a);         \
     }
             case 2: MEL_POOL_LAUNCH(2) break;
             case 4: MEL_POOL_LAUNCH(4) break;
@@ -418,13 +418,13 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         const int grid = (int)((want + 7) & ~7L);       // multiple of 8: block id % 8 = XCD
 #define MEL_ATT_LAUNCH(V)                                                                                             \
     if (a.kind == MEL_CONV_TRANSFORMER && a.bf16)                                                                     \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, true>), dim3(grid), dim3(256), 0, s, a);  \
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, true>), dim3(grid), dim3(256), 0, s, a);  \
     else if (a.kind == MEL_CONV_TRANSFORMER)                                                                          \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, false>), dim3(grid), dim3(256), 0, s, a); \
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, false>), dim3(grid), dim3(256), 0, s, a); \
     else if (a.bf16)                                                                                                  \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, true>), dim3(grid), dim3(256), 0, s, a);        \
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, true>), dim3(grid), dim3(256), 0, s, a);        \
     else                                                                                                              \
-        hipLaunchKernelGGL((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, false>), dim3(grid), dim3(256), 0, s, a);
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, false>), dim3(grid), dim3(256), 0, s, a);
         switch (hc / 64) {
             case 2: MEL_ATT_LAUNCH(2) break;
             case 4: MEL_ATT_LAUNCH(4) break;

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libmelissa_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -32,30 +33,50 @@ inline mel_status check_launch(const char* what) {
     return MEL_OK;
 }
 
-// ---- optional stage timer (HIP events around each launch group; see mel_prof_* in melissa_hip.h) ----
+// ---- optional stage timer (see mel_prof_* in melissa_hip.h) ----
+// While a profiler is attached and a StageScope is open, every kernel launch made through MEL_LAUNCH carries its own
+// pair of HIP events ON THE DISPATCH ITSELF (hipExtLaunchKernelGGL's start / stop events: the begin / end timestamps of
+// that kernel, what a kernel trace reports) and is booked under the open stage; a stage's time is the sum of its
+// launches.  Bracketing a launch with hipEventRecord calls instead also measures the two event packets and the idle gaps
+// around them (4-7 us per stage on this stack), which is not kernel time.
 struct Profiler {
     int capacity = 0;
     int count = 0;
     hipEvent_t* ev = nullptr;     // 2 per record: begin, end
     int* stage = nullptr;
+    int open_stage = -1;
 };
 Profiler* current_profiler();
 
 struct StageScope {
     Profiler* p;
-    hipStream_t s;
-    int idx = -1;
-    StageScope(int stage, hipStream_t stream) : p(current_profiler()), s(stream) {
-        if (p && p->count < p->capacity) {
-            idx = p->count++;
-            p->stage[idx] = stage;
-            (void)hipEventRecord(p->ev[2 * idx], s);
-        }
+    int prev = -1;
+    StageScope(int stage, hipStream_t) : p(current_profiler()) {
+        if (p) prev = p->open_stage, p->open_stage = stage;
     }
     ~StageScope() {
-        if (idx >= 0) (void)hipEventRecord(p->ev[2 * idx + 1], s);
+        if (p) p->open_stage = prev;
     }
 };
+
+// event pair for the next launch, or false when nothing is being timed
+inline bool launch_events(hipEvent_t* begin, hipEvent_t* end) {
+    Profiler* p = current_profiler();
+    if (!p || p->open_stage < 0 || p->count >= p->capacity) return false;
+    const int idx = p->count++;
+    p->stage[idx] = p->open_stage;
+    *begin = p->ev[2 * idx], *end = p->ev[2 * idx + 1];
+    return true;
+}
+
+#define MEL_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                  \
+    do {                                                                                                     \
+        hipEvent_t mel_ev0_, mel_ev1_;                                                                       \
+        if (mel::launch_events(&mel_ev0_, &mel_ev1_))                                                        \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, mel_ev0_, mel_ev1_, 0, __VA_ARGS__);   \
+        else                                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                             \
+    } while (0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -842,7 +842,7 @@ mel_status mel_env_reset(mel_env_batch* env, const mel_episode_pool* pool, const
     a.env = *env, a.pool = *pool, a.env_ids = env_ids, a.episode_ids = episode_ids, a.n = n, a.keep_graph = keep_graph;
     if (out) a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_RESET, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(env_kernel<OP_RESET>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    MEL_LAUNCH(env_kernel<OP_RESET>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_reset");
 }
 
@@ -860,7 +860,7 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
     a.episode_table = episode_table, a.table_stride = table_stride;
     if (out) a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(env_kernel<OP_STEP>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    MEL_LAUNCH(env_kernel<OP_STEP>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_step");
 }
 
@@ -894,7 +894,7 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
         a.replay = *replay;
     }
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    MEL_LAUNCH(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_round");
 }
 
@@ -932,7 +932,7 @@ mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n
     StepArgs a{};
     a.env = *env, a.env_ids = env_ids, a.n = n, a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_OBSERVE, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(env_kernel<OP_OBSERVE>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    MEL_LAUNCH(env_kernel<OP_OBSERVE>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_observe");
 }
 

@@ -116,14 +116,20 @@ struct Mt {
     int pos;            // wave-uniform
 };
 
-// init_genrand (mt19937_seed): a serial recurrence - lane 0 runs it
+// init_genrand (mt19937_seed): a serial recurrence.  It is wave-uniform, so it is written for the SCALAR unit: the chain
+// s -> 1812433253 * (s ^ (s >> 30)) + i runs in SGPRs (four dependent SALU operations per word instead of a VALU chain with
+// a quarter-rate multiply), lane (i % 64) of a VGPR picks word i up with a compare + select, and 64 words go to LDS with one
+// ds_write.
 __device__ __forceinline__ void mt_seed(Mt& m, uint32_t seed, int lane) {
-    if (lane == 0) {
-        uint32_t s = seed;
-        for (int i = 0; i < 624; ++i) {
-            m.key[i] = s;
-            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+    uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)seed);
+    for (int c = 0; c < 624; c += 64) {
+        int mine = 0;
+#pragma unroll 16
+        for (int j = 0; j < 64; ++j) {
+            mine = (lane == j) ? (int)s : mine;                 // lane j keeps word c + j (s is an SGPR)
+            s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(c + j + 1);
         }
+        if (c + lane < 624) m.key[c + lane] = (uint32_t)mine;
     }
     m.pos = 624;
     __syncthreads();
@@ -303,12 +309,12 @@ static mel_status launch_episode_refill(const mel_episode_stream* st, const mel_
     a.st = *st, a.graphs = *graphs, a.pool = *pool, a.env = *env, a.snap = *sn;
     a.max_new = max_new > K ? K : max_new, a.discard = discard;
     StageScope t(MEL_STAGE_ENV_RESET, stream);
-    hipLaunchKernelGGL(episode_draw_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
+    MEL_LAUNCH(episode_draw_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
     // the work-item count lives on the device: a fixed grid loops over it (surplus workgroups leave at once)
     const long expect = (long)B * (a.max_new < 4 ? a.max_new : 4);
     const int grid = (int)(expect < 256 ? 256 : (expect > 4096 ? 4096 : expect));
-    hipLaunchKernelGGL(episode_fill_kernel, dim3(grid), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(episode_publish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
+    MEL_LAUNCH(episode_fill_kernel, dim3(grid), dim3(64), 0, stream, a);
+    MEL_LAUNCH(episode_publish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
     return check_launch("episode_refill");
 }
 

@@ -38,9 +38,9 @@ static void gemm_launch_t(const GemmArgs* gs, int count, int mode, hipStream_t s
     }
     batch.start[count] = total;
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
+        MEL_LAUNCH((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
+        MEL_LAUNCH((gemm_f32_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
 }
 
 template <int WM, int WN, int TM, int TN, int TAG = 0>
@@ -58,9 +58,9 @@ static void gemm_launch_persistent(const GemmArgs* gs, int count, int mode, hipS
     long grid = 256L * PER_CU;                    // 256 CUs; a multiple of 8 (XCD affinity of tile ids)
     if (grid > tiles) grid = tiles;
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+        MEL_LAUNCH((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
     else
-        hipLaunchKernelGGL((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+        MEL_LAUNCH((gemm_f32_persistent_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
 }
 
 // specialised-wavefront kernel (gemm_ring.hpp): two 8-wave workgroups per CU
@@ -76,7 +76,7 @@ static void gemm_launch_ring_t(const GemmArgs* gs, int count, hipStream_t s) {
     }
     long grid = 256L * Cfg::WG_PER_CU;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL((gemm_f32_ring_kernel<TAG, BK, WMC>), dim3((int)grid), dim3(Cfg::THREADS), 0, s, batch);
+    MEL_LAUNCH((gemm_f32_ring_kernel<TAG, BK, WMC>), dim3((int)grid), dim3(Cfg::THREADS), 0, s, batch);
 }
 
 // ragged 64 x 64 launches of the round step, named per call site
@@ -133,7 +133,7 @@ static void gemm_launch_glds(const GemmArgs* gs, int count, hipStream_t s) {
         total += (tiles + 7) & ~7;
     }
     batch.start[count] = total;
-    hipLaunchKernelGGL((gemm_f32_glds_kernel<WM, WN, TM, TN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
+    MEL_LAUNCH((gemm_f32_glds_kernel<WM, WN, TM, TN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
 }
 
 // bf16 feature path: one persistent launch for every case (ragged or not)
@@ -152,9 +152,9 @@ static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_
     long grid = 256L * PER_CU;
     if (grid > tiles) grid = tiles;
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+        MEL_LAUNCH((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_ENC>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
+        MEL_LAUNCH((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
 }
 
 // split path: one persistent 64 x 64 kernel, named per call site like the fp32 one
@@ -170,9 +170,9 @@ static void gemm_launch_split_t(const GemmArgs* gs, int count, int mode, hipStre
     long grid = 256L * 3;                          // 53 KB of LDS per workgroup: three per CU
     if (grid > tiles) grid = tiles;
     if (mode == GEMM_MODE_ENC)
-        hipLaunchKernelGGL((gemm_split_kernel<GEMM_MODE_ENC, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
+        MEL_LAUNCH((gemm_split_kernel<GEMM_MODE_ENC, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
     else
-        hipLaunchKernelGGL((gemm_split_kernel<GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
+        MEL_LAUNCH((gemm_split_kernel<GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
 }
 static void gemm_launch_split(const GemmArgs* gs, int count, int mode, hipStream_t s, int tag) {
     switch (tag) {
@@ -315,7 +315,7 @@ mel_status launch_gemm_splitk(const GemmArgs& g, int S, float* parts, long part_
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
     long blocks = (m_hint * (g.N / 4) + 255) / 256;
     blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, stream, f);
+    MEL_LAUNCH(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, stream, f);
     return check_launch(what);
 }
 
@@ -573,7 +573,7 @@ static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, 
         });
         if (bad) return fail(MEL_ERR_UNSUPPORTED, "split path: a projection weight is null or its shape is unsupported");
         b.start[b.n] = blocks;
-        hipLaunchKernelGGL(split_weights_kernel, dim3(blocks), dim3(256), 0, s, b);
+        MEL_LAUNCH(split_weights_kernel, dim3(blocks), dim3(256), 0, s, b);
         return check_launch("weights -> bf16 planes");
     }
     if (w->precision != MEL_PREC_BF16) {
@@ -595,7 +595,7 @@ static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, 
     });
     if (bad) return fail(MEL_ERR_UNSUPPORTED, "bf16 path: a projection weight is null or its size is not a multiple of 8");
     b.start[b.n] = blocks;
-    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(blocks), dim3(256), 0, s, b);
+    MEL_LAUNCH(cvt_bf16_kernel, dim3(blocks), dim3(256), 0, s, b);
     return check_launch("weights -> bf16");
 }
 
@@ -647,8 +647,8 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
             long blocks = rows_dev ? 2 * likely + 8 : need;
             blocks = blocks > need ? need : blocks < 1 ? 1 : blocks;
             f.likely_blocks = (int)(likely < blocks ? likely : blocks);
-            if (per == 16) hipLaunchKernelGGL(head_finish_kernel<1>, dim3((int)blocks), dim3(512), 0, s, f);
-            else hipLaunchKernelGGL(head_finish_kernel<2>, dim3((int)blocks), dim3(512), 0, s, f);
+            if (per == 16) MEL_LAUNCH(head_finish_kernel<1>, dim3((int)blocks), dim3(512), 0, s, f);
+            else MEL_LAUNCH(head_finish_kernel<2>, dim3((int)blocks), dim3(512), 0, s, f);
             return check_launch("head finish");
         }
     }
@@ -692,7 +692,7 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
     const mel_linear& ql = w->q_head.layer[nl - 1];
     const mel_linear& vl = w->v_head.layer[nl - 1];
     StageScope t(MEL_STAGE_HEAD_TAIL, s);
-    hipLaunchKernelGGL(dueling_tail_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
+    MEL_LAUNCH(dueling_tail_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, in_q, ld_q, ql.in_dim, in_v, ld_v,
                        vl.in_dim, ql, vl, (int)rows, rows_dev, w->dueling, logits, select ? *select : mel_select{});
     return check_launch("dueling tail");
 }
@@ -735,15 +735,15 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         if (w->flags & MEL_FWD_PLAN_READY) {       // mel_env_round's plan sink wrote the masks of this call
             if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "MEL_FWD_PLAN_READY needs the agent-set entry points");
         } else {
-            hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
+            MEL_LAUNCH(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
             if (mel_status st = check_launch("plan_masks")) return st;
         }
         const int inline_scan = bs <= 8192;           // beyond that the per-wave re-scan (O(bs^2 / 64) loads) loses
         if (!inline_scan) {
-            hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
+            MEL_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
             if (mel_status st = check_launch("plan_scan")) return st;
         }
-        hipLaunchKernelGGL(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out,
+        MEL_LAUNCH(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out,
                            tconv ? 0 : 1, inline_scan);
         if (mel_status st = check_launch("plan_lists")) return st;
     }
@@ -946,7 +946,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         StageScope t(MEL_STAGE_PLAN, s);
         // hl_dgn.py:108 pools over the whole graph: the controlling index is read (and clamped) but unused
         if (!((w->flags & MEL_FWD_PLAN_READY) && !index_col)) {      // (else: written by mel_env_round's plan sink)
-            hipLaunchKernelGGL(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
+            MEL_LAUNCH(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
                                (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
             if (mel_status st = check_launch("plan_masks")) return st;
         }
@@ -1030,7 +1030,7 @@ mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n, int32_t obs
         obs_stride < n * (in_dim + 3))
         return fail(MEL_ERR_INVALID_ARG, "mel_radius_graph: bad arguments");
     clear_stale_error();
-    hipLaunchKernelGGL(radius_graph_kernel, dim3((bs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), obs, (int)bs, n,
+    MEL_LAUNCH(radius_graph_kernel, dim3((bs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), obs, (int)bs, n,
                        obs_stride, in_dim + 3, adj);
     return check_launch("mel_radius_graph");
 }
@@ -1054,7 +1054,7 @@ mel_status mel_convert_bf16(const float* src, void* dst, int64_t count, void* st
     CvtBatch b{};
     b.n = 1, b.src[0] = src, b.dst[0] = static_cast<uint16_t*>(dst), b.count[0] = (int)count, b.start[0] = 0;
     b.start[1] = (int)((count / 8 + 255) / 256);
-    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(b.start[1]), dim3(256), 0, static_cast<hipStream_t>(stream), b);
+    MEL_LAUNCH(cvt_bf16_kernel, dim3(b.start[1]), dim3(256), 0, static_cast<hipStream_t>(stream), b);
     return check_launch("mel_convert_bf16");
 }
 
@@ -1138,10 +1138,10 @@ mel_status mel_select_action(const float* logits, const uint8_t* mask, int64_t b
     clear_stale_error();
     StageScope t(MEL_STAGE_SELECT, s);
     if (mask) {
-        hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, s, logits, (long)bs * na, static_cast<float*>(scratch));
+        MEL_LAUNCH(minmax_kernel, dim3(1), dim3(1024), 0, s, logits, (long)bs * na, static_cast<float*>(scratch));
         if (mel_status st = check_launch("minmax")) return st;
     }
-    hipLaunchKernelGGL(select_action_kernel, dim3((bs + 255) / 256), dim3(256), 0, s, logits, mask, (long)bs, na, eps,
+    MEL_LAUNCH(select_action_kernel, dim3((bs + 255) / 256), dim3(256), 0, s, logits, mask, (long)bs, na, eps,
                        rand_u, rand_q, static_cast<const float*>(scratch), act);
     return check_launch("select_action");
 }
@@ -1153,7 +1153,7 @@ mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     clear_stale_error();
     StageScope t(MEL_STAGE_SELECT, s);
-    hipLaunchKernelGGL(select_envs_kernel, dim3((bs * n + 255) / 256), dim3(256), 0, s, logits, live, (long)bs, n, na, eps,
+    MEL_LAUNCH(select_envs_kernel, dim3((bs * n + 255) / 256), dim3(256), 0, s, logits, live, (long)bs, n, na, eps,
                        seed, step_dev, act);
     return check_launch("select_action_envs");
 }
@@ -1165,7 +1165,7 @@ mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row,
     hipStream_t s = static_cast<hipStream_t>(stream);
     clear_stale_error();
     StageScope t(MEL_STAGE_SELECT, s);
-    hipLaunchKernelGGL(select_rows_kernel, dim3((rows_cap + 255) / 256), dim3(256), 0, s, logits, logit_row, (long)rows_cap,
+    MEL_LAUNCH(select_rows_kernel, dim3((rows_cap + 255) / 256), dim3(256), 0, s, logits, logit_row, (long)rows_cap,
                        rows_dev, na, eps, seed, step, step_dev, act);
     return check_launch("select_action_rows");
 }

@@ -280,14 +280,14 @@ static mel_status check_gat(const float* xl, const float* xr, const uint64_t* ad
 
 #define MEL_GRAD_DISPATCH(KERNEL, grid)                                                                      \
     switch (hc / 64) {                                                                                        \
-        case 2: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<2, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
-                else hipLaunchKernelGGL((KERNEL<2, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
-        case 4: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<4, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
-                else hipLaunchKernelGGL((KERNEL<4, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
-        case 8: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<8, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
-                else hipLaunchKernelGGL((KERNEL<8, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
-        default: if (kind == MEL_CONV_GATV2) hipLaunchKernelGGL((KERNEL<16, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a); \
-                 else hipLaunchKernelGGL((KERNEL<16, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;          \
+        case 2: if (kind == MEL_CONV_GATV2) MEL_LAUNCH((KERNEL<2, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
+                else MEL_LAUNCH((KERNEL<2, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
+        case 4: if (kind == MEL_CONV_GATV2) MEL_LAUNCH((KERNEL<4, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
+                else MEL_LAUNCH((KERNEL<4, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
+        case 8: if (kind == MEL_CONV_GATV2) MEL_LAUNCH((KERNEL<8, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a);   \
+                else MEL_LAUNCH((KERNEL<8, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;            \
+        default: if (kind == MEL_CONV_GATV2) MEL_LAUNCH((KERNEL<16, MEL_CONV_GATV2>), dim3(grid), dim3(256), 0, s, a); \
+                 else MEL_LAUNCH((KERNEL<16, MEL_CONV_TRANSFORMER>), dim3(grid), dim3(256), 0, s, a); break;          \
     }
 
 }  // namespace mel
@@ -342,7 +342,7 @@ mel_status mel_pool_forward(const float* x, const float* dm, int64_t bs, int32_t
     if (aggregator == MEL_AGG_MAX && !arg) return fail(MEL_ERR_INVALID_ARG, "pool: max needs the arg buffer");
     clear_stale_error();
     const long total = (long)bs * hc;
-    hipLaunchKernelGGL(pool_forward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, dm,
+    MEL_LAUNCH(pool_forward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, dm,
                        (int)bs, n, hc, aggregator, pooled, arg);
     return check_launch("mel_pool_forward");
 }
@@ -355,7 +355,7 @@ mel_status mel_pool_backward(const float* grad_pooled, const float* dm, const in
     if (aggregator == MEL_AGG_MAX && !arg) return fail(MEL_ERR_INVALID_ARG, "pool backward: max needs the arg buffer");
     clear_stale_error();
     const long total = (long)bs * n * hc;
-    hipLaunchKernelGGL(pool_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+    MEL_LAUNCH(pool_backward_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                        grad_pooled, dm, arg, (int)bs, n, hc, aggregator, dx);
     return check_launch("mel_pool_backward");
 }
