@@ -195,6 +195,13 @@ mel_status mel_gemm_bf16(const void* A, int32_t lda, const void* W, const float*
                          int64_t M, int32_t N, int32_t K, int32_t relu, int32_t y_f32, int32_t tile, void* stream);
 mel_status mel_convert_bf16(const float* src, void* dst, int64_t count, void* stream);
 
+/* dst[c, r] = src[r, c] (device fp32; src [rows, ld_src >= cols], dst [cols, ld_dst >= rows]; columns r >= rows of dst are
+ * left untouched, so a zero-filled dst with ld_dst = rows rounded up to 32 is a zero-padded transpose).  The learn path's
+ * dense backward (policies/dgn.py:49-67, [3P] DQNPolicy.learn) runs on mel_gemm_f32, which wants both operands contiguous
+ * along the contraction index:  dX = dY W = gemm(dY, W^T),  dW = dY^T X = gemm(dY^T, X^T). */
+mel_status mel_transpose_f32(const float* src, int32_t ld_src, int64_t rows, int32_t cols, float* dst, int32_t ld_dst,
+                             void* stream);
+
 /* ---- learn path: attention and pool with hand-written backward ---------------------------
  * Wrapped by torch.autograd.Function in melissa_amd/networks/autograd_ops.py; all buffers device fp32, row-major,
  * rows = bs * n_nodes (row b*n + i = node i of graph b), HC = heads * channels in {128, 256, 512, 1024}.

@@ -294,7 +294,40 @@ static mel_status check_gat(const float* xl, const float* xr, const uint64_t* ad
 
 using namespace mel;
 
+namespace mel {
+// dst[c, r] = src[r, c] through a 32 x 33 LDS tile (both sides coalesced).  The learn path's dense backward needs both
+// operands of a product contiguous along the contraction index: dX = dY W wants W^T, dW = dY^T X wants dY^T and X^T.
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int ld_src, int rows, int cols,
+                                                            float* __restrict__ dst, int ld_dst) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][ty + 8 * k];
+    }
+}
+}  // namespace mel
+
 extern "C" {
+
+mel_status mel_transpose_f32(const float* src, int32_t ld_src, int64_t rows, int32_t cols, float* dst, int32_t ld_dst,
+                             void* stream) {
+    if (!src || !dst || rows < 0 || cols < 1 || ld_src < cols || ld_dst < rows || rows > (1ll << 30))
+        return fail(MEL_ERR_INVALID_ARG, "mel_transpose_f32: bad arguments");
+    if (rows == 0) return MEL_OK;
+    clear_stale_error();
+    MEL_LAUNCH(transpose_f32_kernel, dim3((cols + 31) / 32, (unsigned)((rows + 31) / 32)), dim3(256), 0,
+               static_cast<hipStream_t>(stream), src, ld_src, (int)rows, cols, dst, ld_dst);
+    return check_launch("mel_transpose_f32");
+}
 
 mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, const float* att, const float* bias,
                            const uint64_t* adj, int64_t bs, int32_t n, int32_t heads, int32_t channels, int32_t kind,

@@ -5,9 +5,15 @@
 ``graph_pool``     (x * dm) -> global max / mean / add pool with its backward (hl_dgn.py:105-108);
 ``radius_graph``   the fp32 radius adjacency as uint64 source masks (networks/common.py:47-48), no gradient.
 
-The projections (lin_l / lin_r / key / query / value, encoder, heads) stay ``nn.Linear`` under torch autograd -
-plain library GEMMs.  These ops need a ROCm device and fail loudly without the library: no CPU fallback (the
-CPU autograd formulation is ``gatv2_dense`` / ``transformer_dense`` in common.py).
+``hip_linear``     every dense projection of the learn path (lin_l / lin_r / key / query / value, the encoder's second
+                   layer, the heads' hidden layers) on the library's own fp32-MFMA GEMM (``mel_gemm_f32``), forward and
+                   backward: y = x W^T + b, dX = dY W, dW = dY^T X as three launches of the same kernel (the operands that
+                   are not contiguous along the contraction index go through ``mel_transpose_f32`` first), db = column
+                   sums.  Layers the kernel's tiling does not take (K % 32 or N % 64: the 5-wide encoder input, the 2- /
+                   1-wide last head layers - 0.1 % of the FLOPs) stay ``F.linear``.
+
+These ops need a ROCm device and fail loudly without the library: no CPU fallback (the CPU autograd formulation is
+``gatv2_dense`` / ``transformer_dense`` + ``nn.Linear`` in common.py).
 """
 from __future__ import annotations
 
@@ -106,3 +112,62 @@ class _GraphPool(torch.autograd.Function):
 def graph_pool(x: torch.Tensor, dm: torch.Tensor, n_nodes: int, aggregator: str) -> torch.Tensor:
     """x [bs*n, HC], dm [bs*n] decision-maker flags (no gradient) -> [bs, HC]."""
     return _GraphPool.apply(x, dm.reshape(-1), n_nodes, _lib.AGG[aggregator])
+
+
+def _gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, relu: bool = False):
+    """out[m, n] = sum_k a[m, k] * w[n, k] (+ bias[n]); a [M, lda >= K], w [N, K] contiguous, out [M, N] contiguous."""
+    m, k = a.shape[0], w.shape[1]
+    _lib.check(_lib.load().mel_gemm_f32(a.data_ptr(), a.stride(0), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        out.data_ptr(), out.stride(0), m, w.shape[0], k, int(relu), 0, _stream(a)),
+               "mel_gemm_f32")
+    return out
+
+
+def _transpose(src: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
+    """[R, C] -> [C, Rp] with Rp = R rounded up to ``pad_to`` and zeros in the padding."""
+    r, c = src.shape
+    rp = (r + pad_to - 1) // pad_to * pad_to
+    dst = (torch.zeros if rp != r else torch.empty)(c, rp, dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().mel_transpose_f32(src.data_ptr(), src.stride(0), r, c, dst.data_ptr(), rp, _stream(src)),
+               "mel_transpose_f32")
+    return dst
+
+
+def hip_linear_supported(in_features: int, out_features: int) -> bool:
+    """mel_gemm_f32 tiles 64 output columns by 32 contraction steps; forward needs K % 32 == 0 and N % 64 == 0, the two
+    backward products additionally K % 64 == 0 (dX has K columns, dW too)."""
+    return in_features % 64 == 0 and out_features % 64 == 0
+
+
+class _HipLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w = weight.contiguous()
+        y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+        if x.shape[0]:
+            _gemm(x, w, bias, y)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        m = x.shape[0]
+        dx = dw = db = None
+        if m == 0:
+            return (torch.zeros_like(x), torch.zeros_like(w), torch.zeros(w.shape[0], device=w.device) if ctx.has_bias else None)
+        if ctx.needs_input_grad[0]:                       # dX [M, K] = dY [M, N] . W [N, K]: contraction over N
+            dx = _gemm(dy, _transpose(w), None, torch.empty_like(x))
+        if ctx.needs_input_grad[1]:                       # dW [N, K] = dY^T [N, M] . X [M, K]: contraction over M (padded to 32)
+            dw = _gemm(_transpose(dy, 32), _transpose(x, 32), None, torch.empty_like(w))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=0)
+        return dx, dw, db
+
+
+def hip_linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """``F.linear(x, weight, bias)`` on the library's fp32-MFMA GEMM with its own backward (x: CUDA fp32 [M, K])."""
+    return _HipLinear.apply(x, weight, bias)

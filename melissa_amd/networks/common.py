@@ -385,14 +385,33 @@ def learn_adjacency(obs: torch.Tensor, pos: torch.Tensor, n: int, input_dim: int
     return radius_adjacency(pos)
 
 
+def linear(lin: nn.Linear, x: torch.Tensor, hip: bool) -> torch.Tensor:
+    """``lin(x)`` - on the learn path of a ROCm device through the library's own fp32-MFMA GEMM, forward and backward
+    (autograd_ops.hip_linear), for every layer its tiling takes; ``F.linear`` otherwise (CPU tensors, ``learn_kernels =
+    "dense"``, the 5-wide encoder input and the 2- / 1-wide last head layers)."""
+    if hip and x.dim() == 2 and x.dtype == torch.float32:
+        from .autograd_ops import hip_linear, hip_linear_supported
+        if hip_linear_supported(lin.in_features, lin.out_features):
+            return hip_linear(x, lin.weight, lin.bias)
+    return lin(x)
+
+
+def mlp(module: "MLP", x: torch.Tensor, hip: bool) -> torch.Tensor:
+    """``module.model(x)`` with its Linear layers routed through :func:`linear`."""
+    for layer in module.model:
+        x = linear(layer, x, hip) if isinstance(layer, nn.Linear) else layer(x)
+    return x
+
+
 def conv_relu(conv, x: torch.Tensor, adj, n: int, hip: bool) -> torch.Tensor:
     """relu(conv(x)) for a GATv2Conv / TransformerConv over full graphs (adj: uint64 masks when hip, else dense)."""
     if hip:
         from .autograd_ops import gat_attention, transformer_attention
         if isinstance(conv, TransformerConv):
-            return transformer_attention(conv.lin_key(x), conv.lin_value(x), conv.lin_query(x), adj, n, conv.heads,
-                                         conv.out_channels)
-        return gat_attention(conv.lin_l(x), conv.lin_r(x), conv.att, conv.bias, adj, n, conv.heads, conv.out_channels)
+            return transformer_attention(linear(conv.lin_key, x, hip), linear(conv.lin_value, x, hip),
+                                         linear(conv.lin_query, x, hip), adj, n, conv.heads, conv.out_channels)
+        return gat_attention(linear(conv.lin_l, x, hip), linear(conv.lin_r, x, hip), conv.att, conv.bias, adj, n, conv.heads,
+                             conv.out_channels)
     dense = transformer_dense if isinstance(conv, TransformerConv) else gatv2_dense
     return F.relu(dense(conv, x, adj))
 
@@ -433,11 +452,11 @@ class GraphQNetwork(HipForwardMixin, nn.Module):
         self.Q, self.V = MLP(**q_kwargs), MLP(**v_kwargs)
         self.output_dim = q_out
 
-    def _head(self, latent: torch.Tensor) -> torch.Tensor:
+    def _head(self, latent: torch.Tensor, hip: bool = False) -> torch.Tensor:
         if self.use_dueling:
-            q, v = self.Q.model(latent), self.V.model(latent)
+            q, v = mlp(self.Q, latent, hip), mlp(self.V, latent, hip)
             return q - q.mean(dim=1, keepdim=True) + v
-        return self.out_linear(latent)
+        return linear(self.out_linear, latent, hip)
 
     def forward(self, obs, state=None, info={}):
         logits = self._dispatch(self._prepare_obs(obs))
@@ -452,10 +471,10 @@ class GraphQNetwork(HipForwardMixin, nn.Module):
         bs, n = pos.shape[:2]
         hip = use_hip_autograd(self, obs)
         adj = learn_adjacency(obs, pos, n, self.input_dim, hip)
-        x = F.relu(self.encoder.model(feats.reshape(bs * n, -1)))
+        x = F.relu(mlp(self.encoder, feats.reshape(bs * n, -1), hip))
         gi = torch.arange(bs, device=x.device) * n + g
         x_1 = x[gi]
         x = conv_relu(self.conv1, x, adj, n, hip)
         x_2 = x[gi]
         x = conv_relu(self.conv2, x * dm.reshape(bs * n, 1), adj, n, hip)
-        return self._head(torch.cat([x_1, x_2, x[gi]], dim=1))
+        return self._head(torch.cat([x_1, x_2, x[gi]], dim=1), hip)

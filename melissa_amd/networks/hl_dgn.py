@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib
-from .common import GATv2Conv, GraphQNetwork, conv_relu, learn_adjacency, unpack, use_hip_autograd
+from .common import GATv2Conv, GraphQNetwork, conv_relu, learn_adjacency, mlp, unpack, use_hip_autograd
 
 
 class HLDGNNetwork(GraphQNetwork):
@@ -30,11 +30,11 @@ class HLDGNNetwork(GraphQNetwork):
         pos, feats, dm, _g = unpack(obs, self.input_dim, self.agents_num)
         bs, n = pos.shape[:2]
         hip = use_hip_autograd(self, obs)
-        x = F.relu(self.encoder.model(feats.reshape(bs * n, -1)))
+        x = F.relu(mlp(self.encoder, feats.reshape(bs * n, -1), hip))
         x = conv_relu(self.conv1, x, learn_adjacency(obs, pos, n, self.input_dim, hip), n, hip)
         if hip:
             from .autograd_ops import graph_pool
-            return self._head(graph_pool(x, dm, n, self.aggregator_name))
+            return self._head(graph_pool(x, dm, n, self.aggregator_name), hip)
         x = (x * dm.reshape(bs * n, 1)).view(bs, n, -1)
         pooled = {"max": lambda t: t.max(dim=1).values, "mean": lambda t: t.mean(dim=1), "add": lambda t: t.sum(dim=1)}
         return self._head(pooled[self.aggregator_name](x))

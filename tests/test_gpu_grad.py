@@ -85,7 +85,7 @@ def test_hip_autograd_matches_oracle_autograd(model, agg, n, bs):
     loss = (logits[torch.arange(bs), torch.from_numpy(act_np).cuda()] - torch.from_numpy(target_np).cuda()).pow(2).mean()
     loss.backward()
     torch.testing.assert_close(logits.detach().cpu(), want_logits, atol=1e-4, rtol=0)
-    assert abs(float(loss) - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    assert abs(float(loss.detach()) - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
     checked = 0
     for k, p in net.named_parameters():
         gd = want[k]
@@ -137,3 +137,41 @@ def test_learn_step_uses_hip_kernels_by_default():
     out = pol.learn(dict(obs=torch.from_numpy(random_obs(n, bs, 1)).cuda(), act=np.zeros(bs, dtype=np.int64),
                          returns=np.ones(bs, dtype=np.float32)))
     assert np.isfinite(out["loss"]) and not torch.equal(before, net.conv1.att.detach())
+
+
+@pytest.mark.parametrize("m,k,n", [(37, 128, 512), (1600, 512, 512), (1, 1152, 128), (250, 128, 128), (64, 640, 256)])
+def test_hip_linear_matches_torch_linear(m, k, n):
+    """The learn path's dense layers on the library's own GEMM (autograd_ops.hip_linear: y = x W^T + b, dX = dY W,
+    dW = dY^T X through mel_gemm_f32 + mel_transpose_f32) against float64 torch on the CPU."""
+    from melissa_amd.networks.autograd_ops import hip_linear
+    g = torch.Generator().manual_seed(m + k + n)
+    x64 = torch.randn(m, k, generator=g, dtype=torch.float64)
+    w64 = torch.randn(n, k, generator=g, dtype=torch.float64) / k ** 0.5
+    b64 = torch.randn(n, generator=g, dtype=torch.float64)
+    dy64 = torch.randn(m, n, generator=g, dtype=torch.float64)
+    leaves64 = [t.clone().requires_grad_(True) for t in (x64, w64, b64)]
+    torch.nn.functional.linear(*leaves64).backward(dy64)
+    leaves = [t.float().cuda().requires_grad_(True) for t in (x64, w64, b64)]
+    y = hip_linear(*leaves)
+    y.backward(dy64.float().cuda())
+    want_y = torch.nn.functional.linear(x64, w64, b64)
+    assert float((y.detach().cpu().double() - want_y).abs().max()) <= 2e-5 * max(1.0, float(want_y.abs().max()))
+    for got, want in zip(leaves, leaves64):
+        scale = float(want.grad.abs().max())
+        assert float((got.grad.cpu().double() - want.grad).abs().max()) <= 1e-5 * scale + 1e-7
+
+
+def test_learn_path_dense_layers_run_on_the_library_gemm(monkeypatch):
+    """torch_forward on a ROCm device: every projection the GEMM's tiling takes goes through mel_gemm_f32 (no library
+    GEMM); only the 5-wide encoder input and the 2- / 1-wide last head layers are left to F.linear."""
+    import torch.nn.functional as F
+    seen = []
+    real = F.linear
+    monkeypatch.setattr(F, "linear", lambda x, w, b=None: (seen.append(tuple(w.shape)), real(x, w, b))[1])
+    for model in ("l_dgn", "dgn_r", "hl_dgn"):
+        seen.clear()
+        net = make(model, 20)
+        obs = torch.from_numpy(random_obs(20, 8, 3)).cuda()
+        net.torch_forward(obs).sum().backward()
+        assert seen and all(s[1] == 5 or s[0] <= 2 for s in seen), (model, seen)
+        assert all(p.grad is not None for n_, p in net.named_parameters() if "lin_skip" not in n_)

@@ -272,8 +272,9 @@ def test_bench_cpu_baseline_variants_run():
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    one = bench.cpu_baseline(12, budget_s=1.0, envs=4)
+    one = bench.cpu_baseline(12, envs=4, warm=1, reps=3, rep_seconds=0.2)
     assert one["kind"] == "port" and one["value"] > 0 and one["value_bs1"] > 0 and one["cores"] >= 1
+    assert one["min"] <= one["median"] <= one["max"] and one["repetitions"] == 3 and one["cpu_model"]
     sub = bench.cpu_baseline_subproc(12, budget_s=1.0, workers=2, envs_per_worker=2)
     assert sub["value"] > 0 and sub["envs"] == 4
     fl = bench.stage_flops((10.0, 20.0, 5.0))
