@@ -43,6 +43,14 @@ class StaticSupply:
     kind = "static table"
 
     def __init__(self, venv, packed: dict, table: np.ndarray, reset_snapshots: bool, check_wrap: bool = True):
+        if venv.fixed_graph and venv.dynamic_graph:
+            # GraphEnv(graph=...) with dynamic_graph mutates its ONE graph across episodes (core.py:130,303-314: no reload
+            # at reset), so an episode starts from wherever the previous one left the nodes.  The on-device resets of the
+            # loops load every episode's positions from the pool (keep_graph = 0) and would restart from the original
+            # graph: refuse instead of silently diverging.  The host path (HipGraphVectorEnv.reset / step) handles it.
+            raise ValueError("a fixed graph that moves carries its positions over between episodes (core.py:303-314); the "
+                             "device-resident loops reset from the episode pool - drive this configuration through "
+                             "HipGraphVectorEnv.reset()/step(), or use a graph pool")
         self.venv = venv
         self.pool = venv.load_pool(packed, reset_snapshots=reset_snapshots)
         self.table = torch.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).to(venv.device)

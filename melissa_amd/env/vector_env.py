@@ -160,6 +160,7 @@ class HipGraphVectorEnv:
         drive), ``False`` for none.  ``is_testing``: the
         reference's evaluation schedule (GraphEnv(is_testing=True, num_test_episodes=...), core.py:182-187,348-370);
         ``graph_pool`` then stands for the sorted ``graph_topologies/testing_N/*`` files."""
+        _lib.check_n_nodes(number_of_agents, "HipGraphVectorEnv")
         if is_testing and graph is not None:
             raise ValueError("testing mode draws its graph from graph_pool (core.py:355-359)")
         # core.py:143-148: the same argument checks, same messages

@@ -431,6 +431,7 @@ class GraphQNetwork(HipForwardMixin, nn.Module):
     _RETURNS_STATE = True          # forward returns (logits, state); L-DGN returns (logits, None) (l_dgn.py:151)
 
     def _setup(self, input_dim, hidden_dim, output_dim, num_heads, agents_num, device, edge_attributes, backend):
+        _lib.check_n_nodes(agents_num, type(self).__name__)
         self.device, self.backend = device, backend                     # backend: "auto" | "hip" | "torch"
         self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
         self.num_heads, self.agents_num = num_heads, agents_num

@@ -279,3 +279,16 @@ def test_bench_cpu_baseline_variants_run():
     assert sub["value"] > 0 and sub["envs"] == 4
     fl = bench.stage_flops((10.0, 20.0, 5.0))
     assert fl["conv2_lin"] == 2.0 * 15 * 512 * 512 and fl["conv1_lin"] == 2.0 * 30 * 512 * 128
+
+
+def test_graphs_beyond_64_nodes_are_refused_up_front():
+    """The reference CLI offers --n-agents 100 (common.py:49); the kernels hold one node per wavefront lane, so that size is
+    refused by the constructors with a clear message instead of failing at the first launch."""
+    with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
+        LDGNNetwork(5, 128, 2, 4, 100, dueling_param=DUEL(), backend="torch")
+    with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
+        HLDGNNetwork(5, 128, 2, 4, 65, aggregator="max", dueling_param=DUEL(), backend="torch")
+    from melissa_amd.env import HipGraphVectorEnv
+    with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
+        HipGraphVectorEnv(2, 100, graph_pool=synthetic_graph_pool(12, 1, 0), device="cpu")
+    LDGNNetwork(5, 128, 2, 4, 64, dueling_param=DUEL(), backend="torch")
