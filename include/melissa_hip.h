@@ -102,6 +102,9 @@ typedef struct mel_weights {
     mel_mlp   v_head;      /* latent -> ... -> 1                                     */
     int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4), MEL_PREC_BF16 or MEL_PREC_F32_SPLIT */
     int32_t flags;         /* MEL_FWD_PLAN_READY: the plan masks of this call were written by mel_env_round (plan_* sink) */
+    const void* prepared;  /* optional (MEL_PREC_BF16 / MEL_PREC_F32_SPLIT): device buffer filled by mel_prepare_weights for THESE
+                            * weights - the forward then reads the converted projection weights from it and launches no
+                            * conversion.  NULL: every call converts the fp32 parameters into its workspace (stateless). */
 } mel_weights;
 #define MEL_FWD_PLAN_READY 1
 
@@ -118,6 +121,13 @@ typedef struct mel_weights {
  * fp32, accumulated in fp32).  As close to the exact dot product as a native fp32 GEMM (csrc/gemm_split.hpp); the
  * reference's parity bar (logits <= 1e-4) holds with the same margin as MEL_PREC_F32. */
 #define MEL_PREC_F32_SPLIT 2
+
+/* Convert the projection weights once per weight VERSION instead of once per call (bf16 feature path: bf16 copies; split
+ * path: three bf16 planes per weight).  The caller owns the buffer (mel_prepared_weights_bytes; 0 for MEL_PREC_F32), calls
+ * mel_prepare_weights after every change of the parameters (optimizer step, load_state_dict) and points
+ * mel_weights.prepared at it; the library keeps no state. */
+size_t mel_prepared_weights_bytes(const mel_weights* w);
+mel_status mel_prepare_weights(const mel_weights* w, void* prepared, size_t bytes, void* stream);
 
 /* Bytes of scratch the forward needs for `bs` observation rows of `n_nodes`-node graphs. */
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes);
@@ -181,10 +191,9 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 
 /* The dense projection used by every layer above, exposed for tests and tuning:
  *   Y[m, n] = act(sum_k A[m, k] * W[n, k] + bias[n]),  A [M, lda], W [N, K] (nn.Linear layout), Y [M, ldy],
- * all device fp32; K % 32 == 0, N % 64 == 0.  tile: 0 = automatic, 1 = 64x64, 2 = 128x128 workgroup tile;
- * tuning values (csrc/fwd.hip launch_gemm): 3-6 other one-role tiles, 11 / 12 persistent 64x64 / 128x128,
- * 21 / 22 LDS-DMA one-role, 31 / 32 / 33 specialised-wavefront kernel at K step 32 / K step 16 (three workgroups
- * per CU) / 128x64 tiles with eight consumer waves. */
+ * all device fp32; K % 32 == 0, N % 64 == 0.  tile: 0 = automatic, 1 = 64x64, 2 = 128x128 workgroup tile, 11 = the
+ * persistent 64x64 kernel the ragged launches of the round step use, 31 = the specialised-wavefront (loader / MFMA waves)
+ * kernel the heads' long-K first layer uses. */
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
 

@@ -86,23 +86,6 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
     // (conv2 84 vs 85 us, conv1 46 vs 53 us), see DESIGN.md.
     bool long_k = true;
     for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024 && gs[i].ldy % 4 == 0;
-#ifdef MEL_RING_ALL
-    long_k = true;                              // tuning builds: every ragged launch through the ring kernel
-#endif
-#ifdef MEL_RING_WIDE
-    {
-        bool ok = true;
-        for (int i = 0; i < count; ++i) ok = ok && gs[i].ldy % 4 == 0 && gs[i].K >= 64 && gs[i].ksplit <= 1;
-        if (ok && tag >= 1 && tag <= 3 && ((MEL_RING_WIDE >> (tag - 1)) & 1)) {
-            switch (tag) {
-                case 1: gemm_launch_ring_t<1, 16, 4>(gs, count, s); break;
-                case 2: gemm_launch_ring_t<2, 16, 4>(gs, count, s); break;
-                default: gemm_launch_ring_t<3, 16, 4>(gs, count, s); break;
-            }
-            return;
-        }
-    }
-#endif
     if (long_k) {
         switch (tag) {
             case 1: gemm_launch_ring_t<1>(gs, count, s); break;
@@ -118,22 +101,6 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
         case 3: gemm_launch_persistent<2, 2, 1, 1, 3>(gs, count, GEMM_MODE_PLAIN, s); break;
         default: gemm_launch_persistent<2, 2, 1, 1, 0>(gs, count, GEMM_MODE_PLAIN, s); break;
     }
-}
-
-template <int WM, int WN, int TM, int TN>
-static void gemm_launch_glds(const GemmArgs* gs, int count, hipStream_t s) {
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    GemmBatch batch{};
-    batch.count = count;
-    int total = 0;
-    for (int i = 0; i < count; ++i) {
-        batch.p[i] = gs[i];
-        batch.start[i] = total;
-        const int tiles = ((gs[i].M + BM - 1) / BM) * (gs[i].N / BN);
-        total += (tiles + 7) & ~7;
-    }
-    batch.start[count] = total;
-    MEL_LAUNCH((gemm_f32_glds_kernel<WM, WN, TM, TN>), dim3(total), dim3(64 * WM * WN), 0, s, batch);
 }
 
 // bf16 feature path: one persistent launch for every case (ragged or not)
@@ -217,14 +184,6 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
         gemm_launch_persistent<2, 2, 1, 2>(&g, 1, mode, stream);
         return check_launch(what);
     }
-    if (force_tile == 33 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 32) {      // ring kernel, 128 x 64, K step 16
-        gemm_launch_ring_t<0, 16, 4>(&g, 1, stream);
-        return check_launch(what);
-    }
-    if (force_tile == 32 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 32) {      // ring kernel, K step 16, 3 per CU
-        gemm_launch_ring_t<0, 16>(&g, 1, stream);
-        return check_launch(what);
-    }
     if (force_tile == 31 && mode == GEMM_MODE_PLAIN && g.ldy % 4 == 0 && g.K >= 64) {      // specialised-wavefront kernel, 64 x 64
         gemm_launch_ring_t<0>(&g, 1, stream);
         return check_launch(what);
@@ -233,14 +192,7 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
         switch (force_tile) {
             case 1: gemm_launch_t<2, 2, 1, 1>(&g, 1, mode, stream); break;     //  64 x  64, 4 waves
             case 2: gemm_launch_t<2, 2, 2, 2>(&g, 1, mode, stream); break;     // 128 x 128, 4 waves
-            case 3: gemm_launch_t<2, 4, 2, 1>(&g, 1, mode, stream); break;     // 128 x 128, 8 waves (64x32 each)
-            case 4: gemm_launch_t<4, 2, 1, 2>(&g, 1, mode, stream); break;     // 128 x 128, 8 waves (32x64 each)
-            case 5: gemm_launch_t<2, 2, 2, 1>(&g, 1, mode, stream); break;     // 128 x  64, 4 waves
-            case 6: gemm_launch_t<2, 2, 1, 2>(&g, 1, mode, stream); break;     //  64 x 128, 4 waves
-            case 21: gemm_launch_glds<2, 2, 1, 1>(&g, 1, stream); break;               // LDS-DMA  64 x  64
-            case 22: gemm_launch_glds<2, 2, 2, 2>(&g, 1, stream); break;               // LDS-DMA 128 x 128
             case 11: gemm_launch_persistent<2, 2, 1, 1>(&g, 1, mode, stream); break;   // persistent  64 x  64
-            case 12: gemm_launch_persistent<2, 2, 2, 2>(&g, 1, mode, stream); break;   // persistent 128 x 128
             default: return fail(MEL_ERR_INVALID_ARG, "unknown tile %d", force_tile);
         }
         return check_launch(what);
@@ -487,6 +439,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.minmax = c.take<float>(64);
     L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
                  : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
+    if (w->prepared) L.wb_elems = 0;             // the caller holds the converted weights (mel_prepare_weights)
     L.wb = c.take<uint16_t>(L.wb_elems ? L.wb_elems : 8);
     L.bytes = c.off;
     L.rows_cap = R;
@@ -554,8 +507,11 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
     return MEL_OK;
 }
 
-// fp32: alias the parameters.  bf16: convert all projection weights into L.wb with one launch.
-static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, hipStream_t s) {
+// The projection weights as the GEMMs of this precision read them.  fp32: the nn.Parameter storages themselves.  bf16 /
+// split: bf16 copies (planes) - taken from the caller's PREPARED buffer (mel_prepare_weights: converted once per weight
+// version, nothing launched here) or, when mel_weights.prepared is null, converted into `dst` (the workspace) by one launch
+// on every call, which keeps a caller that never prepares correct.  convert = false only lays the pointers out.
+static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjWeights& pw, hipStream_t s, bool convert) {
     pw = ProjWeights{};
     if (w->precision == MEL_PREC_F32_SPLIT) {        // [rows][3][K] bf16 planes of every projection weight
         SplitBatch b{};
@@ -565,13 +521,14 @@ static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, 
         for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) {
             const size_t cnt = lin_elems(l);
             if (b.n >= CVT_MAX_SEG || cnt % 8 != 0 || l.in_dim % 32 != 0 || !l.weight) { bad = true; return; }
-            b.src[b.n] = l.weight, b.dst[b.n] = L.wb + off, b.count[b.n] = (int)cnt, b.K[b.n] = l.in_dim, b.start[b.n] = blocks;
-            *slot = reinterpret_cast<const float*>(L.wb + off);
+            b.src[b.n] = l.weight, b.dst[b.n] = dst + off, b.count[b.n] = (int)cnt, b.K[b.n] = l.in_dim, b.start[b.n] = blocks;
+            *slot = reinterpret_cast<const float*>(dst + off);
             blocks += (int)((cnt / 4 + 255) / 256);
             off += 3 * ((cnt + 7) & ~(size_t)7);
             ++b.n;
         });
         if (bad) return fail(MEL_ERR_UNSUPPORTED, "split path: a projection weight is null or its shape is unsupported");
+        if (!convert) return MEL_OK;
         b.start[b.n] = blocks;
         MEL_LAUNCH(split_weights_kernel, dim3(blocks), dim3(256), 0, s, b);
         return check_launch("weights -> bf16 planes");
@@ -587,16 +544,25 @@ static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, 
     for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) {
         const size_t cnt = lin_elems(l);
         if (b.n >= CVT_MAX_SEG || cnt % 8 != 0 || !l.weight) { bad = true; return; }
-        b.src[b.n] = l.weight, b.dst[b.n] = L.wb + off, b.count[b.n] = (int)cnt, b.start[b.n] = blocks;
-        *slot = reinterpret_cast<const float*>(L.wb + off);
+        b.src[b.n] = l.weight, b.dst[b.n] = dst + off, b.count[b.n] = (int)cnt, b.start[b.n] = blocks;
+        *slot = reinterpret_cast<const float*>(dst + off);
         blocks += (int)((cnt / 8 + 255) / 256);
         off += (cnt + 7) & ~(size_t)7;
         ++b.n;
     });
     if (bad) return fail(MEL_ERR_UNSUPPORTED, "bf16 path: a projection weight is null or its size is not a multiple of 8");
+    if (!convert) return MEL_OK;
     b.start[b.n] = blocks;
     MEL_LAUNCH(cvt_bf16_kernel, dim3(blocks), dim3(256), 0, s, b);
     return check_launch("weights -> bf16");
+}
+static size_t prepared_elems(const mel_weights* w) {
+    return w->precision == MEL_PREC_BF16 ? projection_elems(w) : w->precision == MEL_PREC_F32_SPLIT ? 3 * projection_elems(w) : 0;
+}
+static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, hipStream_t s) {
+    if (w->prepared && w->precision != MEL_PREC_F32)
+        return resolve_projections(w, static_cast<uint16_t*>(const_cast<void*>(w->prepared)), pw, s, false);
+    return resolve_projections(w, L.wb, pw, s, true);
 }
 
 // dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail.
@@ -874,6 +840,22 @@ size_t mel_abi_sizeof(int32_t which) {
     }
 }
 const char* mel_version(void) { return "melissa_hip 0.4 (gfx950)"; }
+
+size_t mel_prepared_weights_bytes(const mel_weights* w) {
+    if (!w || w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_SPLIT) return 0;
+    return prepared_elems(w) * sizeof(uint16_t);
+}
+
+mel_status mel_prepare_weights(const mel_weights* w, void* prepared, size_t bytes, void* stream) {
+    if (!w) return fail(MEL_ERR_INVALID_ARG, "weights pointer is null");
+    if (w->precision == MEL_PREC_F32) return MEL_OK;                 // the fp32 path reads the parameters themselves
+    if (w->precision != MEL_PREC_BF16 && w->precision != MEL_PREC_F32_SPLIT) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
+    const size_t need = prepared_elems(w) * sizeof(uint16_t);
+    if (!prepared || bytes < need) return fail(MEL_ERR_WORKSPACE, "prepared-weights buffer %zu < %zu bytes", bytes, need);
+    clear_stale_error();
+    ProjWeights pw;
+    return resolve_projections(w, static_cast<uint16_t*>(prepared), pw, static_cast<hipStream_t>(stream), true);
+}
 
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {
     if (!w || bs <= 0 || n_nodes < 1 || n_nodes > MEL_MAX_NODES) return 0;

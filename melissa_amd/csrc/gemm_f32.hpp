@@ -563,141 +563,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA variant (PLAIN problems): operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR
-// staging, no ds_write pass), three LDS stages, counted vmcnt + raw s_barrier so two K steps stay in flight
-// under the MFMAs.  LDS rows are 128 B unpadded (the DMA writes 1 KiB linearly per wave-instruction); bank
-// conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte chunk index
-// with (row >> 1) & 7, applied on the SOURCE address of the DMA and on the read (never on the LDS dest).
-// ------------------------------------------------------------------------------------------------
-// hipcc also parses kernel bodies in its host pass; the LDS address-space cast and the counted waits only
-// exist for the device pass, so they live behind the pass macro (the host pass needs just the launch stub).
-__device__ __forceinline__ void dma_16B_to_lds(const float* src, float* lds_dst_uniform) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
-#endif
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_le() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_glds_kernel(GemmBatch batch) {
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN, NW = WM * WN;
-    constexpr int ROWS = BM + BN;
-    constexpr int PIECES = ROWS / 8;                   // 1 KiB DMA pieces (8 rows x 128 B) per stage
-    constexpr int PPW = PIECES / NW;                   // pieces each wave issues per stage
-    constexpr int STAGE = ROWS * GEMM_BK;              // floats per stage
-    static_assert(PIECES % NW == 0, "pieces must divide over the waves");
-    __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
-
-    int pi = 0;
-#pragma unroll
-    for (int k = 1; k < GEMM_MAX_GROUP; ++k)
-        if (k < batch.count && (int)blockIdx.x >= batch.start[k]) pi = k;
-    const GemmArgs& g = batch.p[pi];
-    const int nbn = g.N / BN;
-    const int M = g.M_dev ? min(*g.M_dev, g.M) : g.M;
-    const int active = ((M + BM - 1) / BM) * nbn;
-    int wg = blockIdx.x - batch.start[pi];
-    if (wg >= active) return;
-    {
-        const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
-        wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
-    }
-    const int m0 = (wg / nbn) * BM;
-    const int n0 = (wg % nbn) * BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid / WN, wn = wid % WN;
-    const int r = lane & 31, h = lane >> 5;
-
-    // DMA sources: this lane's 16-byte chunk of each piece this wave issues
-    const float* src[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int piece = wid * PPW + i;
-        const int row = piece * 8 + (lane >> 3);                       // tile-local row: A rows then W rows
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);               // un-swizzled source chunk of this slot
-        if (row < BM) {
-            const int gr = min(m0 + row, M - 1);
-            const int ar = g.arow ? g.arow[gr] : gr;
-            src[i] = g.A + (size_t)ar * g.lda + chunk * 4;
-        } else {
-            const int n = n0 + (row - BM);
-            const float* base = (g.W_hi && n >= g.split_n) ? g.W_hi + (size_t)(n - g.split_n) * g.K
-                                                            : g.W + (size_t)n * g.K;
-            src[i] = base + chunk * 4;
-        }
-    }
-    auto issue = [&](int stage, int k0) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            float* dst = lds + stage * STAGE + (wid * PPW + i) * 8 * GEMM_BK;   // wave-uniform base
-            dma_16B_to_lds(src[i] + k0, dst);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // fragment read addresses (floats): row * 32 + ((2q + h) ^ x) * 4
-    int a_row[TM], a_x[TM], w_row[TN], w_x[TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int row = wm * 32 * TM + t * 32 + r;
-        a_row[t] = row * GEMM_BK, a_x[t] = (row >> 1) & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int row = BM + wn * 32 * TN + t * 32 + r;
-        w_row[t] = row * GEMM_BK, w_x[t] = (row >> 1) & 7;
-    }
-
-    const int KT = g.K / GEMM_BK;
-    issue(0, 0);
-    if (KT > 1) issue(1, GEMM_BK);
-    for (int kt = 0; kt < KT; ++kt) {
-        // the PPW most recent DMAs (K step kt+1) may stay in flight; everything older has landed
-        if (kt + 1 < KT) wait_vmcnt_le<PPW>();
-        else wait_vmcnt_le<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < KT) issue((kt + 2) % 3, (kt + 2) * GEMM_BK);
-        const float* cur = lds + (kt % 3) * STAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = *reinterpret_cast<const f32x4*>(cur + a_row[t] + (((2 * q + h) ^ a_x[t]) << 2));
-#pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = *reinterpret_cast<const f32x4*>(cur + w_row[t] + (((2 * q + h) ^ w_x[t]) << 2));
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            store_block_f32(g, acc[i][j], m0 + wm * 32 * TM + i * 32 + 4 * h, n0 + wn * 32 * TN + j * 32 + r, M);
-}
-
 // Host-side dispatch: picks the tile so that the launch keeps the 256 CUs busy.  `m_hint` is the row
 // count the caller expects (ragged lists are sized on the device; the grid still covers g.M rows).
 mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const char* what, long m_hint = -1,

@@ -55,6 +55,19 @@ constexpr int RING_OUT_STRIDE = 64;                // floats per row of the accu
 __device__ __forceinline__ int ring_out_index(int row, int col) {
     return row * RING_OUT_STRIDE + ((((col >> 2) ^ ((row & 3) << 1))) << 2) + (col & 3);
 }
+// hipcc also parses kernel bodies in its host pass; the LDS address-space cast and the counted waits only exist for the
+// device pass, so they live behind the pass macro (the host pass needs just the launch stub).
+__device__ __forceinline__ void dma_16B_to_lds(const float* src, float* lds_dst_uniform) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
 __device__ __forceinline__ void wait_lds_done() {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -62,7 +75,7 @@ __device__ __forceinline__ void wait_lds_done() {
 }
 
 #ifdef MEL_RING_PROF
-// Tuning builds (-DMEL_RING_PROF=<TAG> [-DMEL_RING_ALL]): cycles a consumer wave 0 of the launches tagged TAG spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
+// Tuning builds (-DMEL_RING_PROF=<TAG>): cycles a consumer wave 0 of the launches tagged TAG spends in [0] MFMA sections, [1] step barriers, [2] epilogues, [3] whole kernel,
 // [4] workgroups counted; loader wave 4: [5] issue (+ epilogue of a finished tile), [6] wait_landed, [7] barrier
 __device__ unsigned long long g_ring_prof[8];
 #define RING_T() __builtin_readcyclecounter()

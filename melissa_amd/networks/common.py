@@ -151,6 +151,29 @@ class HipForwardMixin:
     def _param_key(self):
         return (self.feature_dtype,) + tuple((p.data_ptr(), p.dtype, p.is_contiguous()) for p in self.parameters())
 
+    def _refresh_prepared(self, w, device):
+        """bf16 / split precision: the converted projection weights live in a buffer this module owns and are converted
+        once per weight VERSION (every in-place change of a parameter - optimizer step, load_state_dict - bumps its torch
+        version counter), not once per forward.  Called outside HIP-graph capture first (the loops warm up eagerly), so a
+        captured step carries no conversion launch."""
+        if self.feature_dtype == "f32":
+            w.prepared = None
+            return
+        lib = _lib.load()
+        version = tuple(p._version for p in self.parameters())
+        cached = getattr(self, "_prepared", None)
+        if cached is not None and cached[0] == (self._param_key(), version) and cached[1].device == device:
+            w.prepared = cached[1].data_ptr()
+            return
+        need = int(lib.mel_prepared_weights_bytes(C.byref(w)))
+        buf = cached[1] if cached is not None and cached[1].numel() >= need and cached[1].device == device else \
+            torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+        w.prepared = None
+        _lib.check(lib.mel_prepare_weights(C.byref(w), buf.data_ptr(), buf.numel(), _lib.current_stream_ptr(device)),
+                   "mel_prepare_weights")
+        w.prepared = buf.data_ptr()
+        self._prepared = ((self._param_key(), version), buf)
+
     def _weights(self) -> _lib.MelWeights:
         key = self._param_key()
         cached = getattr(self, "_w_cache", None)
@@ -202,6 +225,7 @@ class HipForwardMixin:
         if bs == 0:             # an empty batch has empty logits (nothing to launch), as the torch ops of the reference give
             return out if out is not None else torch.empty(0, self.output_dim, dtype=torch.float32, device=obs.device)
         w = self._weights()
+        self._refresh_prepared(w, obs.device)
         ws = self._workspace(w, bs, obs.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs.device)
@@ -254,6 +278,7 @@ class HipForwardMixin:
         assert obs_matrix.is_cuda and obs_matrix.dtype == torch.float32 and obs_matrix.stride(-1) == 1
         bs = obs_matrix.shape[0]
         w = self._weights()
+        self._refresh_prepared(w, obs_matrix.device)
         ws = workspace if workspace is not None else self._workspace(w, bs, obs_matrix.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
@@ -290,6 +315,7 @@ class HipForwardMixin:
         assert obs_matrix.is_cuda and obs_matrix.dtype == torch.float32 and obs_matrix.stride(-1) == 1
         bs = obs_matrix.shape[0]
         w = self._weights()
+        self._refresh_prepared(w, obs_matrix.device)
         need = int(lib.mel_workspace_bytes_agents(C.byref(w), bs, self.agents_num, rows_cap))
         if workspace is not None:                  # caller-owned scratch (one per concurrent stream)
             ws = workspace

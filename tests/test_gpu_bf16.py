@@ -153,3 +153,38 @@ def test_bf16_round_forward_matches_fp32_round_forward():
         got = got[:rows].cpu().numpy()
     assert torch.equal(off, off2)
     check_against_fp32(got, want, f"round forward, {rows} agent rows")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32s"])
+def test_prepared_weights_follow_weight_versions(dtype):
+    """The converted projection weights are prepared once per weight VERSION (mel_prepare_weights into a caller-owned
+    buffer), not per call: a forward after an in-place parameter change (optimizer step, load_state_dict) must see the new
+    weights, and the prepared path must give exactly what the stateless per-call conversion gives."""
+    import ctypes as C
+    from melissa_amd import _lib
+    n, bs = 20, 64
+    obs = torch.from_numpy(random_obs(n, bs, 11)).cuda()
+    net, _ = make_net("l_dgn", n, seed=5)
+    net.set_feature_dtype(dtype)
+    with torch.no_grad():
+        first = net(obs)[0].clone()
+        assert net._weights().prepared and net._prepared[1].numel() >= int(_lib.load().mel_prepared_weights_bytes(C.byref(net._weights())))
+        buf_id = net._prepared[1].data_ptr()
+        again = net(obs)[0].clone()
+        assert torch.equal(first, again) and net._prepared[1].data_ptr() == buf_id          # no re-conversion, same buffer
+        # stateless path (prepared = NULL): the library converts into the workspace on every call
+        w = net._weights()
+        keep, w.prepared = w.prepared, None
+        out = torch.empty(bs, 2, device="cuda")
+        ws = torch.empty(int(_lib.load().mel_workspace_bytes(C.byref(w), bs, n)), dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.load().mel_ldgn_forward(C.byref(w), obs.data_ptr(), bs, n, obs.shape[1], out.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), _lib.current_stream_ptr()))
+        w.prepared = keep
+        assert torch.equal(out, first)
+        # a new weight version
+        net.conv2.lin_l.weight.mul_(1.5)
+        changed = net(obs)[0].clone()
+        fresh, _ = make_net("l_dgn", n, seed=5)
+        fresh.set_feature_dtype(dtype)
+        fresh.conv2.lin_l.weight.mul_(1.5)
+        assert not torch.equal(changed, first) and torch.equal(changed, fresh(obs)[0])

@@ -1,5 +1,5 @@
 """Tuning aid: in-kernel cycle breakdown of gemm_f32_ring_kernel over a few round steps.
-Build with MEL_HIPCC_FLAGS="-DMEL_RING_PROF=<tag> -DMEL_RING_ALL" (tag 1 = conv1, 2 = conv2, 3 = heads)."""
+Build with MEL_HIPCC_FLAGS="-DMEL_RING_PROF=3" (the heads' first layer, the one launch the ring kernel serves)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
