@@ -383,16 +383,17 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
 
 def extra_leg(args, device, rank, parallel, note, **over):
     """Another configuration timed exactly like the headline (same barriers, same counters, same steps / warm-up)."""
-    kw = dict(envs=args.envs, nodes=args.nodes, model=args.model, mode=args.mode, dtype=args.dtype)
+    kw = dict(envs=args.envs, nodes=args.nodes, model=args.model, mode=args.mode, dtype=args.dtype, streams=1)
     kw.update(over)
     import torch
     net, venv, lp = build_workload(device, rank, kw["envs"], kw["nodes"], kw["model"], kw["mode"],
-                                   kw["mode"] == "round" and not args.no_graph, 1, dtype=kw["dtype"])
+                                   kw["mode"] == "round" and not args.no_graph, kw["streams"], dtype=kw["dtype"])
     t = timed_run(lp, args.steps, args.warmup, device, parallel)
     out = {"value": t["decisions"] / t["dt"], "unit": "agent-decisions/s", "ms_per_step": t["dt"] / args.steps * 1e3,
            "decisions_per_step": t["decisions"] / args.steps, "env_error_flags": t["errors"],
            "workload": f"{kw['model'].upper().replace('_', '-')} {kw['nodes']}-node, {kw['envs']} envs per GPU, {kw['dtype']}, "
-                       f"{'round-batched' if kw['mode'] == 'round' else 'AEC-order'} loop", "note": note}
+                       f"{'round-batched' if kw['mode'] == 'round' else 'AEC-order'} loop"
+                       + (f", {kw['streams']} HIP streams" if kw["streams"] > 1 else ""), "note": note}
     del lp, venv, net
     torch.cuda.empty_cache()
     return out
@@ -552,6 +553,12 @@ def main():
                                                        "per GPU (collect path; its collective is in learner_leg)", model="hl_dgn", envs=512),
             "aec_order_loop": dict(note="the reference collector's granularity (multi_agent_collector.py:150-308): one agent decision "
                                         "per env per step", mode="aec"),
+            "two_streams": dict(note="the headline workload as two half-batches of 512 envs on two HIP streams, each replaying its own "
+                                     "HIP graph (the latency-bound launches of one half fill the gaps of the other); not the headline "
+                                     "because overlapping launches cannot be priced per kernel", streams=2),
+            "f32_via_split_bf16_mfma": dict(note="fp32-accurate projections on the bf16 matrix cores (every operand split exactly into three "
+                                                 "bf16 pieces, six partial products; logits 3-7e-8 from the oracle like the native path)",
+                                            dtype="f32s"),
         }
         legs = {}
         for name, spec in specs.items():
