@@ -84,16 +84,18 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
     return net, venv, loop
 
 
-def stage_flops(totals, model="l_dgn"):
+def stage_flops(totals, model="l_dgn", table_rows=0):
     """ALGORITHMIC FLOPs (2*MAC) per launch of each GEMM stage, from the row counts the launch actually
     processed: U1 = conv1 targets, U2 = conv1 sources, R = agent rows (pruned / shared work
     is priced at the pruned / shared count).  DGN-R: key | value projections on the source rows (2 HC wide), query on
-    the target rows."""
+    the target rows.  ``table_rows`` > 0: the node-feature table was used - encoder and conv1 projections ran on that
+    many tuple rows instead of the U2 / U1 row lists, and are priced at that count."""
     u1, u2, r = totals[0], totals[1], totals[2]
     src = 2 if model == "dgn_r" else 1
+    e_rows, l_rows, r_rows = (table_rows,) * 3 if table_rows else (u2, u2, u1)
     return {
-        "encoder": u2 * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
-        "conv1_lin": 2.0 * (src * u2 + u1) * HC * HIDDEN,  # lin_l on U2 rows + lin_r on U1 rows, one grouped launch
+        "encoder": e_rows * (2 * 5 * HIDDEN + 2 * HIDDEN * HIDDEN),
+        "conv1_lin": 2.0 * (src * l_rows + r_rows) * HC * HIDDEN,  # lin_l + lin_r, one grouped launch
         "conv2_lin": 2.0 * (src * u1 + r) * HC * HC,       # lin_l on U1 rows + lin_r on the agent rows
         "head_hidden": 2.0 * r * ((HIDDEN + 2 * HC) * 256 + 2 * 128 * 128),
     }
@@ -317,11 +319,13 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
     stages = {name: (ms[i] / steps * 1e3 if cnt[i] else 0.0) for i, name in enumerate(_lib.STAGE_NAMES)}
     mean_tot = (totals.double().mean(dim=0).cpu().numpy() if args.model != "hl_dgn"
                 else (0.0, float(args.envs * args.nodes), float(args.envs)))
+    ft = ploop.feature_table() if hasattr(ploop, "feature_table") else {"table_rows": 0, "bad_envs": 0}
     if args.model == "hl_dgn":
-        fl = {"encoder": args.envs * args.nodes * 34048.0, "conv1_lin": 2.0 * args.envs * args.nodes * 2 * HC * HIDDEN,
+        rows_enc = ft["table_rows"] or args.envs * args.nodes
+        fl = {"encoder": rows_enc * 34048.0, "conv1_lin": 2.0 * rows_enc * 2 * HC * HIDDEN,
               "head_hidden": 2.0 * args.envs * (HC * 256 + 2 * 128 * 128)}
     else:
-        fl = stage_flops(mean_tot, args.model)
+        fl = stage_flops(mean_tot, args.model, ft["table_rows"])
     dom = max(fl, key=lambda k: stages.get(k, 0.0))
     pmc, pmc_source = pmc_traffic()
     same = (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
@@ -342,7 +346,8 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": pmc_source if same else "none: PMC passes exist for the default workload only",
                 "avg_launch_us": round(stages[dom], 2), "algorithmic_flops_per_launch": fl[dom],
-                "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]), "agent_rows": float(mean_tot[2])},
+                "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]), "agent_rows": float(mean_tot[2]),
+                                    "feature_table_rows": ft["table_rows"], "envs_with_foreign_features": ft["bad_envs"]},
                 "whole_step": {"algorithmic_flops": whole_flops, "stage_sum_us": round(step_us, 2),
                                "achieved": round(whole_flops / (step_us * 1e-6) / 1e12, 3) if step_us > 0 else None,
                                "frac": round(whole_flops / (step_us * 1e-6) / 1e12 / peak, 4) if step_us > 0 else None}}

@@ -101,12 +101,21 @@ typedef struct mel_weights {
     mel_mlp   q_head;      /* latent -> ... -> n_actions                             */
     mel_mlp   v_head;      /* latent -> ... -> 1                                     */
     int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4), MEL_PREC_BF16 or MEL_PREC_F32_SPLIT */
-    int32_t flags;         /* MEL_FWD_PLAN_READY: the plan masks of this call were written by mel_env_round (plan_* sink) */
+    int32_t flags;         /* MEL_FWD_PLAN_READY: the plan masks of this call were written by mel_env_round (plan_* sink);
+                            * MEL_FWD_INTEGER_FEATURES: see below */
     const void* prepared;  /* optional (MEL_PREC_BF16 / MEL_PREC_F32_SPLIT): device buffer filled by mel_prepare_weights for THESE
                             * weights - the forward then reads the converted projection weights from it and launches no
                             * conversion.  NULL: every call converts the fp32 parameters into its workspace (stateless). */
 } mel_weights;
 #define MEL_FWD_PLAN_READY 1
+/* MEL_FWD_INTEGER_FEATURES: the caller guarantees that the five node features of every observation row are the integers
+ * GraphEnv writes (graph.py:261-269: degree in [0, N), messages transmitted in [0, 8), last action / interested / has
+ * message in {0, 1}) - true for everything mel_env_* produces.  The encoder and the conv1 projections are then functions of
+ * one of N * 64 feature TUPLES: when the receptive-field row lists are at least twice that long, the forward evaluates them
+ * once per tuple (table rows, on every call - nothing is kept between calls) and the conv1 attention gathers rows by tuple
+ * id.  Same arithmetic per row, bit-identical logits.  A feature outside the ranges is clamped into the table and flagged
+ * (mel_forward_tap kind 3).  Without the flag the general row-list path runs (arbitrary float features). */
+#define MEL_FWD_INTEGER_FEATURES 2
 
 /* Feature precision of the L-DGN / DGN-R forward (BASELINE config "bf16 feature path").  MEL_PREC_BF16: the
  * node-feature rows between layers (encoder output, lin_l / lin_r projections, conv outputs, head input and
@@ -254,7 +263,9 @@ mel_status mel_hldgn_forward_envs(const mel_weights* w, int32_t aggregator, cons
  * kind: 0 = adjacency masks uint64 [bs, n_nodes] (bit j of row i set <=> edge j -> i, radius rule),
  *       1 = head input [bs, latent], fp32 (bf16 when w->precision is MEL_PREC_BF16) (L-DGN: x_1|x_2|x_3,
  *           l_dgn.py:139; HL-DGN: pooled, hl_dgn.py:108),
- *       2 = int32 [3]: rows the L-DGN GEMMs processed (sum |U1|, sum |U2|, agent rows).
+ *       2 = int32 [3]: rows the L-DGN GEMMs processed (sum |U1|, sum |U2|, agent rows),
+ *       3 = int32 [1 + bs]: [0] rows of the node-feature table the last forward used (0 = row-list path),
+ *           [1 + b] = 1 if env b had a node feature outside the integer ranges of MEL_FWD_INTEGER_FEATURES.
  * rows_cap: 0 for a workspace used by mel_ldgn_forward / mel_hldgn_forward, else the rows_cap given to
  * mel_ldgn_forward_agents.  `out` is a device pointer with room for the requested tensor. */
 mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32_t n_nodes, int64_t rows_cap,

@@ -38,7 +38,7 @@ EXPORTS = ("mel_prepared_weights_bytes", "mel_prepare_weights", "mel_transpose_f
            "mel_prof_read", "mel_last_error", "mel_version")
 PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
 FWD_PLAN_READY = 1          # mel_weights.flags: the plan masks of this call were written by mel_env_round
-FWD_PLAN_READY = 1
+FWD_INTEGER_FEATURES = 2    # mel_weights.flags: node features are the env's integers -> node-feature table (melissa_hip.h)
 HEURISTICS = {None: 0, "simple_broadcast": 1, "broadcast_if_any_interested": 2, "silent": 3}
 LOGGER_KEYS = ("total_messages_transmitted", "coverage", "messages_sent", "messages_received", "n_neighbours",
                "interested_agents", "coverage_interested_fraction", "coverage_interested_count",

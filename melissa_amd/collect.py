@@ -61,7 +61,7 @@ class DecisionLoop:
         """One collector iteration for every env (one agent decision per env)."""
         self.supply.before_step(self.iterations)
         net = self.policy.model
-        net.hip_forward(self.obs, out=self.logits)
+        net.hip_forward(self.obs, out=self.logits, integer_features=True)      # observations written by the env kernels
         if self.eps > 0.0:
             rand_u = torch.rand(self.venv.env_num, device=self.obs.device, generator=self.gen)
             rand_q = torch.rand(self.venv.env_num, self.n_actions, device=self.obs.device, generator=self.gen)
@@ -103,6 +103,9 @@ class RoundLoop:
         ``episodes`` = (packed, table) or ``episode_stream=False`` give a fixed table of ``episodes_per_env`` episodes."""
         self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
         self.use_graph, self.graph = use_graph, None
+        # the observations are the env kernels' own, so their node features are integers in known ranges and the forward may
+        # evaluate encoder / conv1 projections once per feature TUPLE (MEL_FWD_INTEGER_FEATURES); False forces row lists
+        self.integer_features = True
         self.stream = stream                       # None: torch's current stream
         self.replay = replay                       # optional melissa_amd.replay.RoundReplay
         dev = venv.device
@@ -157,14 +160,16 @@ class RoundLoop:
             # forward + per-(env, agent) argmax / eps-greedy in the launch that writes the logits (same stream of draws as
             # mel_select_action_envs)
             net.hip_forward_envs(self._obs_matrix, out=self.logits, workspace=self.workspace, select=self._select,
-                                 plan_ready=True)
+                                 plan_ready=True, integer_features=self.integer_features)
             self._bind_plan()
             self.venv.round_device(self.pool, self.act, None, self.live, self.table, round_counter=self.rounds,
                                    replay=self.replay)
             return
         # forward + fused argmax / eps-greedy (the dueling tail writes the action next to the logits)
+        # (integer_features: the obs rows are the env kernel's own -> encoder / conv1 projections per feature tuple)
         net.hip_forward_agents(self._obs_matrix, self.live, self.rows_cap, out=self.logits, row_offsets=self.offsets,
-                               select=self._select, workspace=self.workspace, plan_ready=True)
+                               select=self._select, workspace=self.workspace, plan_ready=True,
+                               integer_features=self.integer_features)
         self._bind_plan()
         self.venv.round_device(self.pool, self.act, self.offsets, self.live, self.table, round_counter=self.rounds,
                                replay=self.replay)
@@ -200,6 +205,13 @@ class RoundLoop:
         sc = self.venv.scalars().cpu().numpy()
         return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
                     errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)
+
+    def feature_table(self) -> dict:
+        """What the last forward did with the node-feature table: rows used (0 = row-list path) and how many envs had a
+        node feature outside the integer ranges the table assumes (must be 0 for env-produced observations)."""
+        t = self.policy.model.hip_tap(3, self.venv.env_num, 0 if self.per_env_logits else self.rows_cap,
+                                      workspace=self.workspace).cpu().numpy()
+        return dict(table_rows=int(t[0]), bad_envs=int(t[1:].sum()))
 
 
 class MultiStreamRoundLoop:

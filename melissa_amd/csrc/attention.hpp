@@ -47,6 +47,9 @@ struct AttArgs {
     long rows_hint;             // expected rows (grid sizing only)
     int rows_cap, cat_off;
     int bf16;                   // bf16 feature path: xl / xr / out / xcat / h0 hold bf16 rows (att / bias stay fp32)
+    // node-feature table mode (plan_masks.hpp): xl / xr / h0 are TABLES indexed by a node's tuple id fid[b*N + i] instead of
+    // row lists indexed by packed position (null = row lists)
+    const int32_t* fid;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -156,10 +159,13 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 //   m' = max(m, s_0..s_3); l = l e^(m-m') + sum_k e^(s_k-m'); acc = acc e^(m-m') + sum_k e^(s_k-m') row_k
 // KIND = MEL_CONV_GATV2:       e = att . leaky_relu(x_r[i] + x_l[j]),          out = sum alpha x_l[j]
 // KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
+// my_fid: table mode - this lane's node's tuple id (lane = node of the target's env); a source row is then the table row
+// of the source's tuple (one v_readlane) instead of its packed position in the row list.
 template <int VPL, int KIND, bool BF>
 __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_row, uint64_t sources,
                                                   uint64_t smask, int soff, const Vec<VPL>& att,
-                                                  const Vec<VPL>& bias, int lane) {
+                                                  const Vec<VPL>& bias, int lane, int my_fid = 0) {
+    const bool table = a.fid != nullptr;
     constexpr int HC = 64 * VPL;
 #ifndef MEL_ATT_G
 #define MEL_ATT_G 4      // measured 2 / 3 / 4 / 8 sources per step: 24.9 / 25.9 / 25.7 / 29.9 us (conv1, round loop)
@@ -178,7 +184,8 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
             on[k] = sources != 0;
             const int j = on[k] ? lowest_bit(sources) : 0;
             sources &= sources - 1;              // 0 stays 0
-            row[k] = (size_t)(soff + (on[k] ? rank_below(smask, j) : 0)) * a.ld_l + lane * VPL;    // off slots re-read a valid row
+            const int srow = table ? lane_i32(my_fid, j) : soff + (on[k] ? rank_below(smask, j) : 0);
+            row[k] = (size_t)srow * a.ld_l + lane * VPL;                     // off slots re-read a valid row
         }
         Vec<VPL> xl[G], xv[G];
 #pragma unroll
@@ -307,7 +314,13 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
         asm volatile("s_nop 0" ::"s"(d.sources), "s"(d.soff));
         const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
-        const Vec<VPL> o = attend_target<VPL, KIND, BF>(a, (size_t)r, d.sources, d.smask, d.soff, att, bias, lane);
+        int my_fid = 0;
+        size_t xr_row = (size_t)r;
+        if (MODE == ATT_ROWS && a.fid) {             // table mode: tuple ids of the target's env (one dependent load)
+            my_fid = lane < a.n ? a.fid[(size_t)d.env * a.n + lane] : 0;
+            xr_row = (size_t)lane_i32(my_fid, d.node);
+        }
+        const Vec<VPL> o = attend_target<VPL, KIND, BF>(a, xr_row, d.sources, d.smask, d.soff, att, bias, lane, my_fid);
 #ifdef MEL_ATT_PROF
         asm volatile("s_nop 0" ::"v"(o.v[0]));
         const unsigned long long q2 = __builtin_readcyclecounter();
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
                 // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
                 store_row<VPL, BF>(a.xcat, cat + a.hidden + lane * VPL, o);
                 // x_1: its encoder row (l_dgn.py:122)
-                const size_t h0 = (size_t)(d.soff + rank_below(d.smask, d.node)) * a.hidden;
+                const size_t h0 = (size_t)(a.fid ? lane_i32(my_fid, d.node) : d.soff + rank_below(d.smask, d.node)) * a.hidden;
                 if constexpr (BF) {
                     uint16_t* dst = reinterpret_cast<uint16_t*>(a.xcat) + cat;
                     const uint16_t* src = reinterpret_cast<const uint16_t*>(a.h0) + h0;
@@ -362,10 +375,11 @@ __global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     Vec<VPL> pool;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
+    const int my_fid = (a.fid && lane < a.n) ? a.fid[(size_t)b * a.n + lane] : 0;      // table mode (null: rows b*N + i)
     for (int t = wave; t < a.n; t += NW) {
         const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
-        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF>(a, (size_t)(b * a.n + t), sources, full, b * a.n,
-                                                                  att, bias, lane);
+        const size_t xr_row = a.fid ? (size_t)lane_i32(my_fid, t) : (size_t)(b * a.n + t);
+        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
         // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
         const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll

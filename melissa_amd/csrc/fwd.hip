@@ -404,6 +404,10 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.plan.adj = c.take<uint64_t>(M);
     L.plan.live = c.take<uint64_t>(d.bs);
     const int latent = w->q_head.layer[0].in_dim;
+    // node-feature table mode: the encoder / conv1-projection buffers must also hold the N * 64 table rows
+    const size_t T = (size_t)d.n * FEATURE_TUPLES_PER_DEGREE;
+    const size_t rows2 = (size_t)d.u2_cap > T ? (size_t)d.u2_cap : T, rows1 = (size_t)d.u1_cap > T ? (size_t)d.u1_cap : T;
+    const size_t rowsM = M > T ? M : T;
     if (w->model != MEL_MODEL_HLDGN) {
         L.plan.u1 = c.take<uint64_t>(d.bs);
         L.plan.u2 = c.take<uint64_t>(d.bs);
@@ -420,17 +424,20 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         L.plan.row_agent = c.take<int32_t>(R);
         L.plan.arow_g = c.take<int32_t>(R);
         L.plan.dm_g = c.take<float>(R);
-        L.h0 = c.take<float>((size_t)d.u2_cap * hidden);
+        L.h0 = c.take<float>(rows2 * hidden);
         const int srcw = (w->conv1.kind == MEL_CONV_TRANSFORMER) ? 2 * hc : hc;     // key | value side by side
-        L.xl1 = c.take<float>((size_t)d.u2_cap * srcw);
-        L.xr1 = c.take<float>((size_t)d.u1_cap * hc);
+        L.xl1 = c.take<float>(rows2 * srcw);
+        L.xr1 = c.take<float>(rows1 * hc);
         L.h1 = c.take<float>((size_t)d.u1_cap * hc);
         L.xl2 = c.take<float>((size_t)d.u1_cap * srcw);
         L.xr2 = c.take<float>(R * hc);
     } else {
-        L.h0 = c.take<float>(M * hidden);
-        L.xl1 = c.take<float>(M * 2 * hc);
+        L.h0 = c.take<float>(rowsM * hidden);
+        L.xl1 = c.take<float>(rowsM * 2 * hc);
     }
+    L.plan.fid = c.take<int32_t>(M);
+    L.plan.fbad = c.take<int32_t>(d.bs);
+    L.plan.fmeta = c.take<int32_t>(4);
     L.xcat = c.take<float>(R * latent);
     const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
@@ -695,6 +702,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const long hintL = single ? bs : (n < 10 ? bs : bs * (long)(36 + n) / 18);
     const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : (n < 10 ? bs * (long)n : bs * 2L * (18 + n) / 13);
     const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : (n < 10 ? bs * (long)n : bs * 3L * (8 + n) / 11);
+    // Node-feature table (plan_masks.hpp): worth it when the row lists are much longer than the N * 64 tuples
+    const int T = n * FEATURE_TUPLES_PER_DEGREE;
+    const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && hint1 + hint2 >= 2L * T;
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -710,7 +720,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
             if (mel_status st = check_launch("plan_scan")) return st;
         }
         MEL_LAUNCH(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out,
-                           tconv ? 0 : 1, inline_scan);
+                           tconv ? 0 : 1, inline_scan, table ? T : 0);
         if (mel_status st = check_launch("plan_lists")) return st;
     }
     {   // encoder on the U2 rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
@@ -720,8 +730,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
         g.Y = L.h0, g.ldy = hidden, g.M = U2, g.M_dev = n2, g.N = hidden;
         g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        if (table) g.feat_domain = 1, g.nid = nullptr, g.M = T, g.M_dev = nullptr;      // one row per feature tuple
         StageScope t(MEL_STAGE_ENCODER, s);
-        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", hint2)) return st;
+        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", table ? T : hint2)) return st;
     }
     {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
         GemmArgs g[2];
@@ -733,7 +744,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g[1].A = L.h0, g[1].lda = hidden, g[1].arow = L.plan.arow1;
         g[1].W = pw.c1r, g[1].bias = w->conv1.lin_r.bias;
         g[1].Y = L.xr1, g[1].ldy = hc, g[1].M = U1, g[1].M_dev = n1, g[1].N = hc, g[1].K = hidden;
-        const long hints[2] = {hint2, hint1};
+        if (table)                                  // both projections of every tuple's encoder row
+            g[0].M = g[1].M = T, g[0].M_dev = g[1].M_dev = nullptr, g[1].arow = nullptr;
+        const long hints[2] = {table ? T : hint2, table ? T : hint1};
         StageScope t(MEL_STAGE_CONV1_LIN, s);
         if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r", 1)) return st;
     }
@@ -746,6 +759,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
+        a.fid = table ? L.plan.fid : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
     }
@@ -923,6 +937,8 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     const int sp = w->precision == MEL_PREC_F32_SPLIT;
     ProjWeights pw;
     if (mel_status st = resolve_projections(w, L, pw, s)) return st;
+    const int T = n * FEATURE_TUPLES_PER_DEGREE;      // node-feature table (plan_masks.hpp): every node is a row here
+    const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && M >= 2L * T;
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -932,6 +948,9 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
                                (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
             if (mel_status st = check_launch("plan_masks")) return st;
         }
+        MEL_LAUNCH(feature_ids_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan,
+                   table ? T : 0);
+        if (mel_status st = check_launch("feature_ids")) return st;
     }
     {
         GemmArgs g;
@@ -939,6 +958,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
         g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        if (table) g.feat_domain = 1, g.M = T;
         StageScope t(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
     }
@@ -947,7 +967,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         g.A = L.h0, g.lda = hidden;
         g.W = pw.c1l, g.W_hi = pw.c1r, g.bf16 = bf, g.split = sp;
         g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
-        g.Y = L.xl1, g.ldy = 2 * hc, g.M = M, g.N = 2 * hc, g.K = hidden;
+        g.Y = L.xl1, g.ldy = 2 * hc, g.M = table ? T : M, g.N = 2 * hc, g.K = hidden;
         StageScope t(MEL_STAGE_CONV1_LIN, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l|lin_r")) return st;
     }
@@ -958,7 +978,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj, a.kind = MEL_CONV_GATV2;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.obs = obs, a.obs_stride = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;
-        a.pooled = L.xcat;
+        a.pooled = L.xcat, a.fid = table ? L.plan.fid : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_POOL>(a, hc, s, "conv1 attention + pool")) return st;
     }
@@ -1058,6 +1078,10 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
         e = hipMemcpyAsync(o, L.plan.off1 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(o + 1, L.plan.off2 + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(o + 2, L.plan.offL + bs, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    } else if (kind == 3) {
+        int32_t* o = static_cast<int32_t*>(out);
+        e = hipMemcpyAsync(o, L.plan.fmeta, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(o + 1, L.plan.fbad, (size_t)bs * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
     } else
         return fail(MEL_ERR_INVALID_ARG, "unknown tap kind %d", kind);
     if (e != hipSuccess) return fail(MEL_ERR_LAUNCH, "tap copy: %s", hipGetErrorString(e));

@@ -152,12 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmBatch ba
                 const int ar = g.arow ? g.arow[row] : row;
                 c.ac[i].src = reinterpret_cast<const u32x4*>(A16 + (size_t)ar * g.lda + kc);
             } else {
-                const int id = g.nid ? g.nid[row] : row;
-                const int b = id / g.n_nodes, node = id - b * g.n_nodes;
-                const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
-#pragma unroll
-                for (int f = 0; f < 8; ++f)
-                    if (f < g.in_dim) c.ac[i].x[f] = x[f];
+                enc_features(g, row, c.ac[i].x);
             }
         }
 #pragma unroll

@@ -43,6 +43,7 @@ struct GemmArgs {
     const float* obs = nullptr;     // [bs, obs_width]
     int obs_width = 0, n_nodes = 0, in_dim = 0, node_cols = 0;
     const int32_t* nid = nullptr;   // optional: global node id (b*N + i) of row m (identity when null)
+    int feat_domain = 0;            // 1: row m IS a node-feature tuple (feature_tuple_of, plan_masks.hpp): no obs is read
     const float* enc_w = nullptr;   // [K, in_dim]
     const float* enc_b = nullptr;   // [K]
     // W operand, rows [0, split_n) from W / bias, rows [split_n, N) from W_hi / bias_hi
@@ -92,6 +93,26 @@ struct AChunk {
 // Rows beyond M are clamped to row M-1 instead of being predicated: a predicated load turns into a branch
 // plus a merge, and the merge makes the compiler wait for the load right where it was issued (no prefetch
 // overlap).  The clamped rows only feed accumulator rows that the epilogue never stores.
+
+// The 5 node features of output row `row` for the ENC producer: read from the observation (optionally through the row ->
+// node list), or - feat_domain - decoded from the row index itself: the features are small integers (degree, messages
+// sent, last action, interested, has message; graph.py:261-269), so the encoder and conv1 projections can be evaluated
+// once per distinct TUPLE instead of once per node row (node-feature table, plan_masks.hpp).
+__device__ __forceinline__ void enc_features(const GemmArgs& g, int row, float x[8]) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) x[f] = 0.f;
+    if (g.feat_domain) {
+        x[0] = (float)(row >> 6), x[1] = (float)((row >> 3) & 7), x[2] = (float)((row >> 2) & 1);
+        x[3] = (float)((row >> 1) & 1), x[4] = (float)(row & 1);
+        return;
+    }
+    const int id = g.nid ? g.nid[row] : row;
+    const int b = id / g.n_nodes, node = id - b * g.n_nodes;
+    const float* src = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+        if (f < g.in_dim) x[f] = src[f];
+}
 
 // enc: layer-0 weights of the encoder staged in LDS as [K][9] = {w[k][0..7], b[k]} (ENC mode only)
 template <int MODE>
@@ -213,12 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
             const int ar = g.arow ? g.arow[row] : row;
             ac[i].src = g.A + (size_t)ar * g.lda + kc;
         } else {
-            const int id = g.nid ? g.nid[row] : row;
-            const int b = id / g.n_nodes, node = id - b * g.n_nodes;
-            const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
-#pragma unroll
-            for (int f = 0; f < 8; ++f)
-                if (f < g.in_dim) ac[i].x[f] = x[f];
+            enc_features(g, row, ac[i].x);
         }
     }
     const float* w_src[W_CHUNKS];
@@ -402,12 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f32_persistent_kernel(Ge
                 const int ar = g.arow ? g.arow[row] : row;
                 c.ac[i].src = g.A + (size_t)ar * g.lda + kc;
             } else {
-                const int id = g.nid ? g.nid[row] : row;
-                const int b = id / g.n_nodes, node = id - b * g.n_nodes;
-                const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
-#pragma unroll
-                for (int f = 0; f < 8; ++f)
-                    if (f < g.in_dim) c.ac[i].x[f] = x[f];
+                enc_features(g, row, c.ac[i].x);
             }
         }
 #pragma unroll

@@ -117,12 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
                 const int ar = g.arow ? g.arow[row] : row;
                 c.ac[i].src = g.A + (size_t)ar * g.lda + kc;
             } else {
-                const int id = g.nid ? g.nid[row] : row;
-                const int b = id / g.n_nodes, node = id - b * g.n_nodes;
-                const float* x = g.obs + (size_t)b * g.obs_width + node * g.node_cols + 2;
-#pragma unroll
-                for (int f = 0; f < 8; ++f)
-                    if (f < g.in_dim) c.ac[i].x[f] = x[f];
+                enc_features(g, row, c.ac[i].x);
             }
         }
         {   // weights: [N][3][K] bf16 planes (split_weights_kernel); W / W_hi point at plane 0 of row 0

@@ -45,6 +45,11 @@ struct PlanBuffers {
     int32_t* row_agent; // [R] agent (node id) of agent row r
     int32_t* arow_g;    // [R] row of the U1 list holding the agent
     float* dm_g;        // [R]
+    // node-feature table mode (plan_masks.hpp): tuple id of every node, per-env "a feature was not an integer in range"
+    // flags, and [0] = table rows the forward used (0 = row-list path)
+    int32_t* fid;       // [bs*N]
+    int32_t* fbad;      // [bs]
+    int32_t* fmeta;     // [4]
 };
 
 // standalone adjacency for the learn path (one wave per observation row)
@@ -127,10 +132,18 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) 
 __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
                                                          int obs_stride, int node_cols, PlanBuffers p,
                                                          int32_t* __restrict__ row_offsets_out, int self_loops,
-                                                         int inline_scan) {
+                                                         int inline_scan, int table_rows) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
+    if (b == 0 && lane == 0) p.fmeta[0] = table_rows;
+    if (table_rows > 0) {                           // tuple ids for the node-feature table path
+        int bad = 0, id = 0;
+        if (lane < n) id = node_feature_id(obs + (size_t)b * obs_stride + lane * node_cols + 2, n, &bad);
+        if (lane < n) p.fid[(size_t)b * n + lane] = id;
+        const int any_bad = __ballot(bad != 0) != 0ull;
+        if (lane == 0) p.fbad[b] = any_bad;
+    }
     const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
     int oL, o1, o2;
     if (inline_scan) {
@@ -176,6 +189,21 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict
         row_offsets_out[b] = oL;
         if (b == bs - 1) row_offsets_out[bs] = oL + p.cnt[b];
     }
+}
+
+// HL-DGN has no row lists: the tuple ids alone (one wave per env)
+__global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
+                                                          int node_cols, PlanBuffers p, int table_rows) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= bs) return;
+    const int lane = lane_id();
+    if (b == 0 && lane == 0) p.fmeta[0] = table_rows;
+    if (table_rows <= 0) return;
+    int bad = 0, id = 0;
+    if (lane < n) id = node_feature_id(obs + (size_t)b * obs_stride + lane * node_cols + 2, n, &bad);
+    if (lane < n) p.fid[(size_t)b * n + lane] = id;
+    const int any_bad = __ballot(bad != 0) != 0ull;
+    if (lane == 0) p.fbad[b] = any_bad;
 }
 
 }  // namespace mel

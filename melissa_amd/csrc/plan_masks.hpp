@@ -27,6 +27,27 @@ __device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, i
     return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
 }
 
+// ---- node-feature table (MEL_FWD_INTEGER_FEATURES) ---------------------------------------------------------------------
+// The five node features the encoder reads are small integers in the env's observations (graph.py:261-269: degree < N,
+// messages transmitted <= 4, last action, interested, has message as 0 / 1), so a node's encoder row and its conv1
+// projections are functions of one of N * 64 TUPLES.  With the flag set the forward evaluates the encoder and the conv1
+// projections once per tuple (table rows, every call - nothing is kept between calls) and the attention kernels fetch rows
+// by tuple id instead of by packed receptive-field row.  Per row it is the same arithmetic in the same order, so logits are
+// bit-identical to the row-list path.  tuple id = (((degree * 8 + messages) * 2 + action) * 2 + interested) * 2 + has_message
+constexpr int FEATURE_TUPLES_PER_DEGREE = 64;
+__device__ __forceinline__ int node_feature_id(const float* f, int n, int* bad) {
+    const float deg = f[0], msg = f[1], act = f[2], itr = f[3], has = f[4];
+    int d = (int)deg, m = (int)msg, a = (int)act, i = (int)itr, h = (int)has;
+    const bool ok = (float)d == deg && (float)m == msg && (float)a == act && (float)i == itr && (float)h == has &&
+                    d >= 0 && d < n && m >= 0 && m < 8 && a >= 0 && a < 2 && i >= 0 && i < 2 && h >= 0 && h < 2;
+    if (!ok) {                                   // not an observation of this env family: flagged, clamped into the table
+        *bad = 1;
+        d = d < 0 ? 0 : (d >= n ? n - 1 : d), m = m < 0 ? 0 : (m > 7 ? 7 : m);
+        a = a != 0, i = i != 0, h = h != 0;
+    }
+    return (((d * 8 + m) * 2 + a) * 2 + i) * 2 + h;
+}
+
 // the plan masks of one env from its fp32 node positions (lane = node) and its agent set; want_receptive < 0: adjacency
 // only (HL-DGN), 0: adjacency + agent set, 1: + one- / two-hop sets and sizes.  Shared by plan_masks_kernel and the env
 // round kernel's plan sink (mel_env_batch.plan_*), which therefore write bit-identical buffers.

@@ -212,8 +212,10 @@ class HipForwardMixin:
             self._ws = ws
         return ws
 
-    def hip_forward(self, obs: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """Inference through libmelissa_hip.so on the current HIP stream.  obs: CUDA float32 [bs, 8N+1]."""
+    def hip_forward(self, obs: torch.Tensor, out: torch.Tensor | None = None, integer_features: bool = False) -> torch.Tensor:
+        """Inference through libmelissa_hip.so on the current HIP stream.  obs: CUDA float32 [bs, 8N+1].
+        ``integer_features``: the caller guarantees the observations come from the env (node features are the integers
+        GraphEnv writes), which lets large batches go through the node-feature table (MEL_FWD_INTEGER_FEATURES)."""
         lib = _lib.load()
         if not obs.is_cuda:
             raise RuntimeError("the HIP forward needs the observation on a ROCm device; there is no CPU "
@@ -230,6 +232,7 @@ class HipForwardMixin:
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs.device)
         stream = _lib.current_stream_ptr(obs.device)
+        w.flags = _lib.FWD_INTEGER_FEATURES if integer_features else 0
         if self._MODEL in (_lib.MODEL_LDGN, _lib.MODEL_DGNR):
             fn = lib.mel_ldgn_forward if self._MODEL == _lib.MODEL_LDGN else lib.mel_dgnr_forward
             st = fn(C.byref(w), obs.data_ptr(), bs, self.agents_num, obs.shape[1], out.data_ptr(), ws.data_ptr(),
@@ -238,21 +241,24 @@ class HipForwardMixin:
             st = lib.mel_hldgn_forward(C.byref(w), _lib.AGG[self.aggregator_name], obs.data_ptr(), bs,
                                        self.agents_num, obs.shape[1], out.data_ptr(), ws.data_ptr(),
                                        ws.numel(), stream)
+        w.flags = 0
         _lib.check(st, type(self).__name__ + ".forward")
         return out
 
-    def hip_tap(self, kind: int, bs: int, rows_cap: int = 0) -> torch.Tensor:
+    def hip_tap(self, kind: int, bs: int, rows_cap: int = 0, workspace: torch.Tensor | None = None) -> torch.Tensor:
         """Parity tap after a HIP forward: 0 = adjacency masks [bs, N] int64 bit patterns, 1 = head input
         [rows, latent], 2 = int32 [3] rows processed (sum|U1|, sum|U2|, agent rows).  ``rows_cap`` = 0 after
         ``hip_forward``, else the cap given to ``hip_forward_agents``."""
         lib = _lib.load()
         w = self._weights()
-        ws = self._ws_agents if rows_cap else self._ws
+        ws = workspace if workspace is not None else (self._ws_agents if rows_cap else self._ws)
         if kind == 0:
             out = torch.empty(bs, self.agents_num, dtype=torch.int64, device=ws.device)
         elif kind == 1:
             out = torch.empty(rows_cap or bs, w.q_head.layer[0].in_dim, device=ws.device,
                               dtype=torch.bfloat16 if self.feature_dtype == "bf16" else torch.float32)
+        elif kind == 3:           # [0] node-feature table rows the last forward used, [1 + b] out-of-range feature flags
+            out = torch.zeros(1 + bs, dtype=torch.int32, device=ws.device)
         else:
             out = torch.zeros(3, dtype=torch.int32, device=ws.device)
         _lib.check(lib.mel_forward_tap(C.byref(w), kind, bs, self.agents_num, rows_cap, ws.data_ptr(), out.data_ptr(),
@@ -269,7 +275,7 @@ class HipForwardMixin:
 
     def hip_forward_envs(self, obs_matrix: torch.Tensor, out: torch.Tensor | None = None,
                          workspace: torch.Tensor | None = None, select: "_lib.MelSelect | None" = None,
-                         plan_ready: bool = False) -> torch.Tensor:
+                         plan_ready: bool = False, integer_features: bool = False) -> torch.Tensor:
         """HL-DGN on env rows without an index column (round-batched loop): one logits row per env.  ``select`` (with
         ``live`` / ``n_nodes`` set): the per-(env, agent) argmax / eps-greedy fused into the launch that writes the logits."""
         if self._MODEL != _lib.MODEL_HLDGN:
@@ -282,7 +288,8 @@ class HipForwardMixin:
         ws = workspace if workspace is not None else self._workspace(w, bs, obs_matrix.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
-        w.flags = _lib.FWD_PLAN_READY if plan_ready else 0        # (the struct is cached: always set, never left behind)
+        # (the struct is cached: always set, never left behind)
+        w.flags = (_lib.FWD_PLAN_READY if plan_ready else 0) | (_lib.FWD_INTEGER_FEATURES if integer_features else 0)
         if select is not None:
             st = lib.mel_hldgn_forward_envs_select(C.byref(w), _lib.AGG[self.aggregator_name], obs_matrix.data_ptr(), bs,
                                                    self.agents_num, obs_matrix.stride(0), out.data_ptr(), C.byref(select),
@@ -305,7 +312,7 @@ class HipForwardMixin:
     def hip_forward_agents(self, obs_matrix: torch.Tensor, agent_mask: torch.Tensor, rows_cap: int,
                            out: torch.Tensor | None = None, row_offsets: torch.Tensor | None = None,
                            select: "_lib.MelSelect | None" = None, workspace: torch.Tensor | None = None,
-                           plan_ready: bool = False):
+                           plan_ready: bool = False, integer_features: bool = False):
         """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
         [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
         patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
@@ -331,7 +338,8 @@ class HipForwardMixin:
         if row_offsets is None:
             row_offsets = torch.empty(bs + 1, dtype=torch.int32, device=obs_matrix.device)
         fn = lib.mel_ldgn_forward_agents if self._MODEL == _lib.MODEL_LDGN else lib.mel_dgnr_forward_agents
-        w.flags = _lib.FWD_PLAN_READY if plan_ready else 0        # mel_env_round's plan sink wrote this call's masks
+        # plan_ready: mel_env_round's plan sink wrote this call's masks; integer_features: obs rows come from the env
+        w.flags = (_lib.FWD_PLAN_READY if plan_ready else 0) | (_lib.FWD_INTEGER_FEATURES if integer_features else 0)
         st = fn(C.byref(w), obs_matrix.data_ptr(), bs, self.agents_num, obs_matrix.stride(0), agent_mask.data_ptr(),
                 rows_cap, out.data_ptr(), row_offsets.data_ptr(), C.byref(select) if select is not None else None,
                 ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(obs_matrix.device))
