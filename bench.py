@@ -45,7 +45,8 @@ def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
 
 
-def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9, dtype="f32", supply="stream"):
+def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9, dtype="f32", supply="stream",
+                   prepared_tables=False):
     import torch
     from melissa_amd.collect import DecisionLoop, MultiStreamRoundLoop, RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
@@ -61,6 +62,7 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
                            device=device, backend="hip")
     net.eval()
     net.set_feature_dtype(dtype)
+    net.prepared_tables = bool(prepared_tables)       # legs only: the headline evaluates the node-feature table every call
     # the first 1024 accepted seeds of nx.random_geometric_graph(n, 0.2, seed=s), connected ones only
     graphs = synthetic_graph_pool(n_nodes, N_GRAPHS, first_seed=0)
     make_venv = lambda count, seed: HipGraphVectorEnv(count, n_nodes, graph_pool=graphs, dynamic_graph=True,
@@ -388,11 +390,13 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
 
 def extra_leg(args, device, rank, parallel, note, **over):
     """Another configuration timed exactly like the headline (same barriers, same counters, same steps / warm-up)."""
-    kw = dict(envs=args.envs, nodes=args.nodes, model=args.model, mode=args.mode, dtype=args.dtype, streams=1)
+    kw = dict(envs=args.envs, nodes=args.nodes, model=args.model, mode=args.mode, dtype=args.dtype, streams=1,
+              prepared_tables=False)
     kw.update(over)
     import torch
     net, venv, lp = build_workload(device, rank, kw["envs"], kw["nodes"], kw["model"], kw["mode"],
-                                   kw["mode"] == "round" and not args.no_graph, kw["streams"], dtype=kw["dtype"])
+                                   kw["mode"] == "round" and not args.no_graph, kw["streams"], dtype=kw["dtype"],
+                                   prepared_tables=kw["prepared_tables"])
     t = timed_run(lp, args.steps, args.warmup, device, parallel)
     out = {"value": t["decisions"] / t["dt"], "unit": "agent-decisions/s", "ms_per_step": t["dt"] / args.steps * 1e3,
            "decisions_per_step": t["decisions"] / args.steps, "env_error_flags": t["errors"],
@@ -561,6 +565,10 @@ def main():
             "two_streams": dict(note="the headline workload as two half-batches of 512 envs on two HIP streams, each replaying its own "
                                      "HIP graph (the latency-bound launches of one half fill the gaps of the other); not the headline "
                                      "because overlapping launches cannot be priced per kernel", streams=2),
+            "prepared_feature_tables": dict(note="the headline workload with the node-feature table (encoder + conv1 projections of the "
+                                                 "3 200 feature tuples: a function of the weights only) prepared ONCE per weight "
+                                                 "version (mel_prepare_feature_tables) instead of evaluated inside every step as the "
+                                                 "headline does; bit-identical logits", prepared_tables=True),
             "f32_via_split_bf16_mfma": dict(note="fp32-accurate projections on the bf16 matrix cores (every operand split exactly into three "
                                                  "bf16 pieces, six partial products; logits 3-7e-8 from the oracle like the native path)",
                                             dtype="f32s"),

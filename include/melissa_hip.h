@@ -106,6 +106,13 @@ typedef struct mel_weights {
     const void* prepared;  /* optional (MEL_PREC_BF16 / MEL_PREC_F32_SPLIT): device buffer filled by mel_prepare_weights for THESE
                             * weights - the forward then reads the converted projection weights from it and launches no
                             * conversion.  NULL: every call converts the fp32 parameters into its workspace (stateless). */
+    const void* tables;    /* optional: device buffer filled by mel_prepare_feature_tables for THESE weights and tables_nodes
+                            * nodes per graph - a forward that takes the node-feature table (MEL_FWD_INTEGER_FEATURES) then reads
+                            * the encoder / conv1-projection rows of every feature tuple from it instead of evaluating them
+                            * (they depend on the weights only).  NULL (the default everywhere, bench.py's headline included):
+                            * the table rows are evaluated by every call. */
+    int32_t tables_nodes;
+    int32_t reserved;
 } mel_weights;
 #define MEL_FWD_PLAN_READY 1
 /* MEL_FWD_INTEGER_FEATURES: the caller guarantees that the five node features of every observation row are the integers
@@ -137,6 +144,13 @@ typedef struct mel_weights {
  * mel_weights.prepared at it; the library keeps no state. */
 size_t mel_prepared_weights_bytes(const mel_weights* w);
 mel_status mel_prepare_weights(const mel_weights* w, void* prepared, size_t bytes, void* stream);
+
+/* The node-feature table of MEL_FWD_INTEGER_FEATURES (encoder row and conv1 projections of each of the n_nodes * 64 feature
+ * tuples) evaluated ONCE per weight version into a caller-owned buffer, like the prepared weights above: same kernels, same
+ * rows, same bits as the per-call evaluation.  Opt-in (mel_weights.tables); precision follows mel_weights.precision and,
+ * for bf16 / split, needs mel_weights.prepared. */
+size_t mel_feature_tables_bytes(const mel_weights* w, int32_t n_nodes);
+mel_status mel_prepare_feature_tables(const mel_weights* w, int32_t n_nodes, void* tables, size_t bytes, void* stream);
 
 /* Bytes of scratch the forward needs for `bs` observation rows of `n_nodes`-node graphs. */
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes);

@@ -30,7 +30,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
     SET_AGENTS = range(8)
 
 # every symbol include/melissa_hip.h declares
-EXPORTS = ("mel_prepared_weights_bytes", "mel_prepare_weights", "mel_transpose_f32", "mel_episode_refill", "mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
+EXPORTS = ("mel_feature_tables_bytes", "mel_prepare_feature_tables", "mel_prepared_weights_bytes", "mel_prepare_weights", "mel_transpose_f32", "mel_episode_refill", "mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
            "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
@@ -65,7 +65,8 @@ class MelMlp(C.Structure):
 class MelWeights(C.Structure):
     _fields_ = [("model", C.c_int32), ("in_dim", C.c_int32), ("n_actions", C.c_int32), ("dueling", C.c_int32),
                 ("encoder", MelMlp), ("conv1", MelGatv2), ("conv2", MelGatv2), ("q_head", MelMlp),
-                ("v_head", MelMlp), ("precision", C.c_int32), ("flags", C.c_int32), ("prepared", C.c_void_p)]
+                ("v_head", MelMlp), ("precision", C.c_int32), ("flags", C.c_int32), ("prepared", C.c_void_p),
+                ("tables", C.c_void_p), ("tables_nodes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MelSelect(C.Structure):
@@ -213,6 +214,10 @@ def load(build_if_missing: bool = True):
     lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MelRoundReplay), vp]
     lib.mel_env_observe.restype = i32
     lib.mel_env_observe.argtypes = [E, vp, i64, O, vp]
+    lib.mel_feature_tables_bytes.restype = sz
+    lib.mel_feature_tables_bytes.argtypes = [W, i32]
+    lib.mel_prepare_feature_tables.restype = i32
+    lib.mel_prepare_feature_tables.argtypes = [W, i32, vp, sz, vp]
     lib.mel_prepared_weights_bytes.restype = sz
     lib.mel_prepared_weights_bytes.argtypes = [W]
     lib.mel_prepare_weights.restype = i32

@@ -670,6 +670,60 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
     return check_launch("dueling tail");
 }
 
+// The node-feature table (plan_masks.hpp): encoder row of every feature tuple, then its conv1 projections - two launches
+// into t_h0 [T, hidden], t_xl [T, srcw (HL-DGN: 2 hc, lin_l | lin_r)], t_xr [T, hc] (unused for HL-DGN).
+struct FeatureTables {
+    float* h0;
+    float* xl;
+    float* xr;
+};
+static size_t table_elem_bytes(const mel_weights* w) { return w->precision == MEL_PREC_BF16 ? 2 : 4; }
+static FeatureTables carve_tables(const mel_weights* w, int n, void* buf, size_t* bytes) {
+    const size_t T = (size_t)n * FEATURE_TUPLES_PER_DEGREE, es = table_elem_bytes(w);
+    const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
+    const bool hl = w->model == MEL_MODEL_HLDGN;
+    const int srcw = hl ? 2 * hc : (w->conv1.kind == MEL_CONV_TRANSFORMER ? 2 * hc : hc);
+    Carver c(buf);
+    FeatureTables t;
+    t.h0 = reinterpret_cast<float*>(c.take<char>(T * hidden * es));
+    t.xl = reinterpret_cast<float*>(c.take<char>(T * srcw * es));
+    t.xr = hl ? nullptr : reinterpret_cast<float*>(c.take<char>(T * hc * es));
+    if (bytes) *bytes = c.off;
+    return t;
+}
+static mel_status run_feature_tables(const mel_weights* w, const ProjWeights& pw, int n, const FeatureTables& t, hipStream_t s) {
+    const int T = n * FEATURE_TUPLES_PER_DEGREE;
+    const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
+    const int bf = w->precision == MEL_PREC_BF16, sp = w->precision == MEL_PREC_F32_SPLIT;
+    const bool tconv = w->conv1.kind == MEL_CONV_TRANSFORMER, hl = w->model == MEL_MODEL_HLDGN;
+    {
+        GemmArgs g;
+        g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
+        g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
+        g.Y = t.h0, g.ldy = hidden, g.M = T, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+        StageScope sc(MEL_STAGE_ENCODER, s);
+        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder (feature tuples)", T)) return st;
+    }
+    StageScope sc(MEL_STAGE_CONV1_LIN, s);
+    if (hl) {
+        GemmArgs g;
+        g.A = t.h0, g.lda = hidden, g.W = pw.c1l, g.W_hi = pw.c1r, g.bf16 = bf, g.split = sp;
+        g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
+        g.Y = t.xl, g.ldy = 2 * hc, g.M = T, g.N = 2 * hc, g.K = hidden;
+        return launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l|lin_r (feature tuples)");
+    }
+    const int srcw = tconv ? 2 * hc : hc;
+    GemmArgs g[2];
+    g[0].bf16 = g[1].bf16 = bf, g[0].split = g[1].split = sp;
+    g[0].A = t.h0, g[0].lda = hidden, g[0].W = pw.c1l, g[0].bias = w->conv1.lin_l.bias;
+    g[0].Y = t.xl, g[0].ldy = srcw, g[0].M = T, g[0].N = srcw, g[0].K = hidden;
+    if (tconv) g[0].W_hi = pw.c1v, g[0].bias_hi = w->conv1.lin_v.bias, g[0].split_n = hc;
+    g[1].A = t.h0, g[1].lda = hidden, g[1].W = pw.c1r, g[1].bias = w->conv1.lin_r.bias;
+    g[1].Y = t.xr, g[1].ldy = hc, g[1].M = T, g[1].N = hc, g[1].K = hidden;
+    const long hints[2] = {T, T};
+    return launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r (feature tuples)", 1);
+}
+
 // L-DGN for a set of controlling agents per env (agent_mask == null: the index column names one)
 static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, const Dims& d, int obs_stride,
                                     const uint64_t* agent_mask, float* logits, int32_t* row_offsets_out,
@@ -730,9 +784,15 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
         g.Y = L.h0, g.ldy = hidden, g.M = U2, g.M_dev = n2, g.N = hidden;
         g.K = w->encoder.layer[0].out_dim, g.relu = 1;
-        if (table) g.feat_domain = 1, g.nid = nullptr, g.M = T, g.M_dev = nullptr;      // one row per feature tuple
         StageScope t(MEL_STAGE_ENCODER, s);
-        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", table ? T : hint2)) return st;
+        if (!table)
+            if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder", hint2)) return st;
+    }
+    // table mode: one row per feature tuple, evaluated here (every call) unless the caller prepared them for these weights
+    FeatureTables ft{L.h0, L.xl1, L.xr1};
+    if (table) {
+        if (w->tables && w->tables_nodes == n) ft = carve_tables(w, n, const_cast<void*>(w->tables), nullptr);
+        else if (mel_status st = run_feature_tables(w, pw, n, ft, s)) return st;
     }
     {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
         GemmArgs g[2];
@@ -744,21 +804,20 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g[1].A = L.h0, g[1].lda = hidden, g[1].arow = L.plan.arow1;
         g[1].W = pw.c1r, g[1].bias = w->conv1.lin_r.bias;
         g[1].Y = L.xr1, g[1].ldy = hc, g[1].M = U1, g[1].M_dev = n1, g[1].N = hc, g[1].K = hidden;
-        if (table)                                  // both projections of every tuple's encoder row
-            g[0].M = g[1].M = T, g[0].M_dev = g[1].M_dev = nullptr, g[1].arow = nullptr;
-        const long hints[2] = {table ? T : hint2, table ? T : hint1};
+        const long hints[2] = {hint2, hint1};
         StageScope t(MEL_STAGE_CONV1_LIN, s);
-        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r", 1)) return st;
+        if (!table)
+            if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv1.lin_l + lin_r", 1)) return st;
     }
     {   // conv1 attention for the U1 targets; also drops x_1 and x_2 of every agent into the head input
         AttArgs a{};
-        a.xl = L.xl1, a.ld_l = srcw, a.xr = L.xr1, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
+        a.xl = ft.xl, a.ld_l = srcw, a.xr = ft.xr, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
         a.kind = w->conv1.kind, a.score_scale = 1.0f / sqrtf((float)w->conv1.channels), a.bf16 = bf;
         a.adj = L.plan.adj, a.live = L.plan.live, a.smask = L.plan.u2;
         a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
-        a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = L.h0;
+        a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = ft.h0;
         a.fid = table ? L.plan.fid : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
@@ -860,6 +919,28 @@ size_t mel_prepared_weights_bytes(const mel_weights* w) {
     return prepared_elems(w) * sizeof(uint16_t);
 }
 
+size_t mel_feature_tables_bytes(const mel_weights* w, int32_t n_nodes) {
+    if (!w || n_nodes < 1 || n_nodes > MEL_MAX_NODES || w->in_dim != 5 || w->encoder.n_layers != 2) return 0;
+    size_t bytes = 0;
+    (void)carve_tables(w, n_nodes, nullptr, &bytes);
+    return bytes;
+}
+
+mel_status mel_prepare_feature_tables(const mel_weights* w, int32_t n_nodes, void* tables, size_t bytes, void* stream) {
+    if (mel_status st = validate(w, w ? w->model : 0, 1, n_nodes, n_nodes * ((w ? w->in_dim : 5) + 3), false)) return st;
+    if (w->in_dim != 5) return fail(MEL_ERR_UNSUPPORTED, "the node-feature table is defined for the 5 GraphEnv features");
+    const size_t need = mel_feature_tables_bytes(w, n_nodes);
+    if (!tables || bytes < need) return fail(MEL_ERR_WORKSPACE, "feature-table buffer %zu < %zu bytes", bytes, need);
+    if (w->precision != MEL_PREC_F32 && !w->prepared)
+        return fail(MEL_ERR_INVALID_ARG, "bf16 / split precision: prepare the weights first (mel_prepare_weights)");
+    clear_stale_error();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ProjWeights pw;
+    FwdLayout none{};
+    if (mel_status st = resolve_projections(w, none, pw, s)) return st;
+    return run_feature_tables(w, pw, n_nodes, carve_tables(w, n_nodes, tables, nullptr), s);
+}
+
 mel_status mel_prepare_weights(const mel_weights* w, void* prepared, size_t bytes, void* stream) {
     if (!w) return fail(MEL_ERR_INVALID_ARG, "weights pointer is null");
     if (w->precision == MEL_PREC_F32) return MEL_OK;                 // the fp32 path reads the parameters themselves
@@ -958,23 +1039,29 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
         g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
         g.Y = L.h0, g.ldy = hidden, g.M = M, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
-        if (table) g.feat_domain = 1, g.M = T;
         StageScope t(MEL_STAGE_ENCODER, s);
-        if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
+        if (!table)
+            if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder")) return st;
     }
     {   // x_l | x_r for every node in one GEMM (weights split along n)
         GemmArgs g;
         g.A = L.h0, g.lda = hidden;
         g.W = pw.c1l, g.W_hi = pw.c1r, g.bf16 = bf, g.split = sp;
         g.bias = w->conv1.lin_l.bias, g.bias_hi = w->conv1.lin_r.bias, g.split_n = hc;
-        g.Y = L.xl1, g.ldy = 2 * hc, g.M = table ? T : M, g.N = 2 * hc, g.K = hidden;
+        g.Y = L.xl1, g.ldy = 2 * hc, g.M = M, g.N = 2 * hc, g.K = hidden;
         StageScope t(MEL_STAGE_CONV1_LIN, s);
-        if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l|lin_r")) return st;
+        if (!table)
+            if (mel_status st = launch_gemm(g, GEMM_MODE_PLAIN, s, "conv1.lin_l|lin_r")) return st;
+    }
+    FeatureTables ft{L.h0, L.xl1, nullptr};
+    if (table) {
+        if (w->tables && w->tables_nodes == n) ft = carve_tables(w, n, const_cast<void*>(w->tables), nullptr);
+        else if (mel_status st = run_feature_tables(w, pw, n, ft, s)) return st;
     }
     {
         AttArgs a{};
-        a.xl = L.xl1, a.ld_l = 2 * hc, a.ld_r = 2 * hc, a.bf16 = bf;
-        a.xr = bf ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(L.xl1) + hc) : L.xl1 + hc;
+        a.xl = ft.xl, a.ld_l = 2 * hc, a.ld_r = 2 * hc, a.bf16 = bf;
+        a.xr = bf ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(ft.xl) + hc) : ft.xl + hc;
         a.att = w->conv1.att, a.bias = w->conv1.bias, a.adj = L.plan.adj, a.kind = MEL_CONV_GATV2;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.obs = obs, a.obs_stride = obs_width, a.node_cols = node_cols, a.aggregator = aggregator;

@@ -151,6 +151,26 @@ class HipForwardMixin:
     def _param_key(self):
         return (self.feature_dtype,) + tuple((p.data_ptr(), p.dtype, p.is_contiguous()) for p in self.parameters())
 
+    # Opt-in: the node-feature table (MEL_FWD_INTEGER_FEATURES) prepared once per weight version instead of evaluated by
+    # every forward (it depends on the weights only).  Off by default: a forward then does all of its own arithmetic.
+    prepared_tables = False
+
+    def _refresh_tables(self, w, device):
+        if not self.prepared_tables or self.input_dim != 5:
+            w.tables, w.tables_nodes = None, 0
+            return
+        lib = _lib.load()
+        key = (self._param_key(), tuple(p._version for p in self.parameters()), self.agents_num)
+        cached = getattr(self, "_tables", None)
+        if cached is None or cached[0] != key or cached[1].device != device:
+            need = int(lib.mel_feature_tables_bytes(C.byref(w), self.agents_num))
+            buf = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+            w.tables, w.tables_nodes = None, 0
+            _lib.check(lib.mel_prepare_feature_tables(C.byref(w), self.agents_num, buf.data_ptr(), buf.numel(),
+                                                      _lib.current_stream_ptr(device)), "mel_prepare_feature_tables")
+            self._tables = cached = (key, buf)
+        w.tables, w.tables_nodes = cached[1].data_ptr(), self.agents_num
+
     def _refresh_prepared(self, w, device):
         """bf16 / split precision: the converted projection weights live in a buffer this module owns and are converted
         once per weight VERSION (every in-place change of a parameter - optimizer step, load_state_dict - bumps its torch
@@ -228,6 +248,7 @@ class HipForwardMixin:
             return out if out is not None else torch.empty(0, self.output_dim, dtype=torch.float32, device=obs.device)
         w = self._weights()
         self._refresh_prepared(w, obs.device)
+        self._refresh_tables(w, obs.device)
         ws = self._workspace(w, bs, obs.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs.device)
@@ -285,6 +306,7 @@ class HipForwardMixin:
         bs = obs_matrix.shape[0]
         w = self._weights()
         self._refresh_prepared(w, obs_matrix.device)
+        self._refresh_tables(w, obs_matrix.device)
         ws = workspace if workspace is not None else self._workspace(w, bs, obs_matrix.device)
         if out is None:
             out = torch.empty(bs, self.output_dim, dtype=torch.float32, device=obs_matrix.device)
@@ -323,6 +345,7 @@ class HipForwardMixin:
         bs = obs_matrix.shape[0]
         w = self._weights()
         self._refresh_prepared(w, obs_matrix.device)
+        self._refresh_tables(w, obs_matrix.device)
         need = int(lib.mel_workspace_bytes_agents(C.byref(w), bs, self.agents_num, rows_cap))
         if workspace is not None:                  # caller-owned scratch (one per concurrent stream)
             ws = workspace

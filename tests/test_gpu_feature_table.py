@@ -107,3 +107,23 @@ def test_round_loop_with_and_without_table_walks_the_same_trajectory(model):
     for a, b in zip(finals[0][:4], finals[1][:4]):
         np.testing.assert_array_equal(a, b)
     assert finals[0][4] == finals[1][4] and finals[0][4]["errors"] == 0 and finals[0][4]["episodes"] > 100
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("model", ["l_dgn", "dgn_r", "hl_dgn"])
+def test_prepared_tables_equal_per_call_tables(model, dtype):
+    """Opt-in: the table prepared once per weight version (mel_prepare_feature_tables) gives the same bits as the table every
+    call evaluates, and follows a weight change."""
+    n, bs = 20, 512
+    obs = torch.from_numpy(env_like_obs(n, bs, 3)).cuda()
+    net, _ = make(model, n)
+    net.set_feature_dtype(dtype)
+    with torch.no_grad():
+        per_call = net.hip_forward(obs, integer_features=True).clone()
+        net.prepared_tables = True
+        prepared = net.hip_forward(obs, integer_features=True).clone()
+        assert net._weights().tables and torch.equal(per_call, prepared)
+        net.conv1.lin_l.weight.mul_(0.5) if model != "dgn_r" else net.conv1.lin_key.weight.mul_(0.5)
+        changed = net.hip_forward(obs, integer_features=True).clone()
+        net.prepared_tables = False
+        assert not torch.equal(changed, per_call) and torch.equal(changed, net.hip_forward(obs, integer_features=True))
