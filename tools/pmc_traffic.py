@@ -16,10 +16,11 @@ from melissa_amd import build  # noqa: E402  (source hash of the library the pas
                                 #              from a file whose hash matches the library it is timing)
 
 # launches of the round step by kernel name (the call site is part of it: TAG 1 = conv1, 2 = conv2, 3 = heads)
-LAUNCHES = {"conv1 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 1>", "conv2 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
+LAUNCHES = {"conv1 (lin_l+lin_r, feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 0>", "conv2 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
          "head0 (Q|V, split-K)": "gemm_f32_ring_kernel<3,", "head finish": "head_finish_kernel",
          "conv1 attention": "gat_attend_rows_kernel<8, 0,", "conv2 attention": "gat_attend_rows_kernel<8, 2,",
-         "env round": "env_round_kernel", "encoder": "gemm_f32_persistent_kernel<2, 2, 1, 1, 1,"}
+         "env round": "env_round_kernel", "encoder (feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 1>",
+         "plan lists": "plan_lists_kernel"}
 
 
 def mean_counter(directory, counter, needle):
@@ -38,6 +39,8 @@ def main():
            "workload": "L-DGN 50-node, 1024 envs, round loop, fp32", "source_hash": build.source_hash(), "per_launch": {}}
     for name, needle in LAUNCHES.items():
         f, w = mean_counter(sys.argv[1], "FETCH_SIZE", needle), mean_counter(sys.argv[2], "WRITE_SIZE", needle)
+        if f == 0 and w == 0:
+            continue                                 # this build does not launch that kernel
         out["per_launch"][name] = {"FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                                    "hbm_bytes_corrected": int((2 * f + w) * 1024)}
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -1,21 +1,29 @@
 #!/bin/bash
-# Round-end profile refresh (run on the GPU box through gpurun): kernel-trace stats of the bench command, the two
-# PMC passes behind roofline.traffic, and the bench line itself.  Usage: bash tools/refresh_profiles.sh r01k
+# Profile refresh (run on the GPU box through gpurun): rocprofv3 kernel-trace stats of the bench command, the two PMC
+# passes behind roofline.traffic (tied to the library's source hash), the bench lines, the soak-parity log.
+# Usage: bash tools/refresh_profiles.sh r02b        (outputs land in gpurun_out/<tag>/ and are copied into profiles/)
 set -e
-TAG=${1:-r01k}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extra-legs --no-graph > $OUT/bench_line_nograph.json 2> $OUT/stats.log
+# same command as the default bench (HIP-graph replay, episode stream), minus the legs and the CPU baseline
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-extra-legs > $OUT/bench_line_under_rocprof.json 2> $OUT/stats.log
+echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-profile --no-graph > /dev/null 2> $OUT/pmc_fetch.log
+echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-legs --no-profile --no-graph > /dev/null 2> $OUT/pmc_write.log
+echo "pmc write done"
 cd $ROOT
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
-cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_round_kernel_stats.csv
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-extra-legs   (MI355X, round 2, round-batched loop, fp32, HIP-graph replay, device episode stream)";
+  echo "# 430 launches per forward kernel = 30 warm-up + 200 timed + 200 stage-timer steps (the stage timer's eager pass launches the same kernels); episode_* = the episode stream's refill on its side stream";
+  cat $(find $OUT/stats -name '*kernel_stats.csv' | head -1); } > $OUT/${TAG}_round_kernel_stats.csv
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
-cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json       # bench.py reads roofline.traffic from profiles/
-python3 bench.py > $OUT/${TAG}_bench_line_round.json 2> $OUT/bench.log
-python3 bench.py --dtype bf16 --no-cpu-baseline > $OUT/${TAG}_bench_line_round_bf16.json 2>> $OUT/bench.log
-python3 bench.py --dtype f32s --no-cpu-baseline > $OUT/${TAG}_bench_line_round_f32s.json 2>> $OUT/bench.log
-tail -c 600 $OUT/${TAG}_bench_line_round.json
+cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json       # bench.py reads roofline.traffic from profiles/ (hash-checked)
+python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.log
+echo "bench line done"
+python3 tools/soak_parity.py > $OUT/${TAG}_soak_parity.log 2>&1 || echo "SOAK FAILED"
+tail -2 $OUT/${TAG}_soak_parity.log
+tail -c 400 $OUT/${TAG}_bench_line.json

@@ -1,12 +1,18 @@
-"""Soak: the round-loop-vs-oracle parity test (tests/test_gpu_round.py) at more sizes than the suite runs."""
+"""Soak: the round-loop-vs-oracle parity tests (tests/test_gpu_round.py) at more sizes than the suite runs, with both episode
+supplies (host-drawn table / device episode stream).  Prints one line per case; run it on the GPU box and keep the output
+under profiles/ (python tools/soak_parity.py | tee gpurun_out/soak_parity.log)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gpu_round as t
-for n, dyn in ((50, True), (33, True), (64, True), (7, False), (20, False), (12, True), (50, False), (41, True), (64, False)):
+for n, dyn, supply in ((50, True, "table"), (33, True, "stream"), (64, True, "stream"), (7, False, "table"), (20, False, "stream"),
+                       (12, True, "table"), (50, False, "stream"), (41, True, "stream"), (64, False, "table"), (50, True, "stream")):
     t0 = time.time()
-    t.test_round_loop_matches_oracle(n, dyn)
-    print(f"n={n} dynamic={dyn}: ok ({time.time() - t0:.1f} s)", flush=True)
-for scripted in (None, (0.3, "simple_broadcast"), (0.4, "broadcast_if_any_interested"), (0.5, "silent"), (0.2, "simple_broadcast")):
-    t0 = time.time()
-    t.test_hldgn_round_loop_matches_oracle(scripted)
-    print(f"hl_dgn scripted={scripted}: ok ({time.time() - t0:.1f} s)", flush=True)
+    t.test_round_loop_matches_oracle(n, dyn, supply)
+    print(f"l_dgn round loop n={n} dynamic={dyn} episodes={supply}: bit-exact env state + logits within 1e-4 of the oracle "
+          f"({time.time() - t0:.1f} s)", flush=True)
+for n in (20, 50, 37):
+    for scripted in (None, (0.3, "simple_broadcast"), (0.4, "broadcast_if_any_interested"), (0.5, "silent"), (0.2, "simple_broadcast")):
+        t0 = time.time()
+        t.test_hldgn_round_loop_matches_oracle(scripted, n)
+        print(f"hl_dgn round loop n={n} scripted={scripted}: ok ({time.time() - t0:.1f} s)", flush=True)
+print("soak ok")
