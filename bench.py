@@ -362,7 +362,9 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
         esz = 2 if args.dtype == "bf16" else 4
         u1, u2, r = (float(x) for x in mean_tot)
         row = HC * esz
-        att1 = (u2 + u1) * row + u1 * row + r * (HIDDEN + HC) * esz        # x_l rows + x_r rows read, h1 + x_1|x_2 written
+        # x_l rows + x_r rows read (with the node-feature table: at most its rows), h1 + x_1|x_2 written
+        tr = ft["table_rows"]
+        att1 = ((min(u2, tr) + min(u1, tr)) if tr else (u2 + u1)) * row + u1 * row + r * (HIDDEN + HC) * esz
         att2 = (u1 + r) * row + r * row                                      # x_l2 rows + x_r2 rows read, x_3 written
         env_b = 2.0 * float(lib.mel_env_state_bytes(args.envs, args.nodes))  # every env's state read + written once
         hbm_rooflines = []

@@ -117,10 +117,10 @@ def test_round_loop_matches_oracle(n, dynamic, supply):
     from melissa_amd.replay import RoundReplay
     replay = RoundReplay(B, n, 8, "cuda")
     if supply == "stream":
-        # (N = 50: the greedy random-weight policy plays ~12-round episodes, so a 3-slot ring refilled EVERY round)
-        ring = 5 if n < 50 else 3
+        # (beyond 20 nodes the greedy random-weight policy plays ~12-round episodes, so a 3-slot ring refilled EVERY round)
+        ring = 5 if n <= 20 else 3
         loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed, replay=replay, ring=ring, discard=1)
-        K = 70
+        K = 70 if n <= 50 else 110
     else:
         loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=seed, replay=replay,
                          episodes=({k: v for k, v in packed.items()}, np.ascontiguousarray(table[:, 1:])))
