@@ -474,6 +474,12 @@ typedef struct mel_episode_stream {
  * arrays the library may WRITE, a snapshot batch of B*ring envs, and produced == stream->produced.  ep_cursor is read
  * from env->scalars.  Launches on `stream`; the caller orders it against the env launches (a refill may overlap env
  * rounds on another stream as long as no env can reach an episode >= the produced[] value of the previous refill). */
+/* A pacing gate for `stream`: whatever is enqueued behind it runs once the device counter `counter` (e.g. the round_counter
+ * mel_env_round advances on another stream) has reached `target` (wrap-around compare), or after timeout_us.  It lets the
+ * episode refill follow the main stream's progress without an event on the main stream (events between HIP-graph replays
+ * cost the step several microseconds on this stack); one wavefront polls with agent-scope relaxed loads and s_sleep. */
+mel_status mel_wait_counter(const uint32_t* counter, uint32_t target, uint32_t timeout_us, void* stream);
+
 mel_status mel_episode_refill(const mel_episode_stream* st, const mel_graph_pool* graphs, const mel_episode_pool* pool,
                               const mel_env_batch* env, int32_t max_new, int32_t discard, void* stream);
 

@@ -126,7 +126,8 @@ class RoundLoop:
         self.act = torch.zeros(venv.env_num * venv.n if self.per_env_logits else self.rows_cap, dtype=torch.int32,
                                device=dev)
         self.iterations = 0
-        self.rounds = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side round counter (RNG step)
+        self._rounds_base = 0
+        self.rounds = torch.zeros(1, dtype=torch.int32, device=dev)     # device-side round counter (RNG step, refill pacing)
         self._select = _lib.MelSelect()
         self._select.act, self._select.eps = self.act.data_ptr(), float(eps)
         self._select.seed, self._select.step_dev = seed & 0xFFFFFFFF, self.rounds.data_ptr()
@@ -182,7 +183,8 @@ class RoundLoop:
             self._step()
 
     def _step(self):
-        self.supply.before_step(self.iterations)      # episode stream: refill on a side stream every few rounds
+        # episode stream: refill on a side stream every few rounds, paced by the device-side round counter
+        self.supply.before_step(self.iterations - self._rounds_base, self.rounds)
         if self.use_graph:
             if self.graph is None:
                 self._launch()                        # warm-up outside capture (lazy init)

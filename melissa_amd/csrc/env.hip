@@ -903,6 +903,13 @@ mel_status mel_episode_refill(const mel_episode_stream* st, const mel_graph_pool
     return launch_episode_refill(st, graphs, pool, env, max_new, discard, static_cast<hipStream_t>(stream));
 }
 
+mel_status mel_wait_counter(const uint32_t* counter, uint32_t target, uint32_t timeout_us, void* stream) {
+    if (!counter) return fail(MEL_ERR_INVALID_ARG, "mel_wait_counter: counter is null");
+    clear_stale_error();
+    MEL_LAUNCH(wait_counter_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, target, timeout_us);
+    return check_launch("wait_counter");
+}
+
 // tuning builds only (-DMEL_ENV_PROF): read and reset the round kernel's cycle counters (tools/env_prof.py)
 void mel_debug_world_prof(unsigned long long* out4) {
 #ifdef MEL_ENV_PROF

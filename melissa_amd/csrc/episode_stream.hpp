@@ -281,6 +281,23 @@ __global__ __launch_bounds__(64) void episode_fill_kernel(StreamArgs a) {
     }
 }
 
+// Pacing gate for a side stream: one wavefront polls a device counter that the main stream's kernels advance (the round
+// counter of mel_env_round) until it reaches `target`, so that what follows on the side stream runs when the main stream has
+// got that far - WITHOUT any event on the main stream (an event record / wait between HIP-graph replays costs the replayed
+// step ~8 us on this stack).  Bounded: after timeout_us the gate opens anyway (what follows must be safe at any time; the
+// episode refill is - it only ever writes ring slots no env can be using, judged from the cursors it reads).
+__global__ __launch_bounds__(64) void wait_counter_kernel(const uint32_t* counter, uint32_t target, uint32_t timeout_us) {
+    if (threadIdx.x != 0) return;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();            // 100 MHz
+    const uint64_t limit = (uint64_t)timeout_us * 100ull;
+    for (;;) {
+        const uint32_t c = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(c - target) >= 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 static mel_status launch_episode_refill(const mel_episode_stream* st, const mel_graph_pool* graphs,
                                         const mel_episode_pool* pool, const mel_env_batch* env, int32_t max_new,
                                         int32_t discard, hipStream_t stream) {
@@ -312,7 +329,11 @@ static mel_status launch_episode_refill(const mel_episode_stream* st, const mel_
     MEL_LAUNCH(episode_draw_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
     // the work-item count lives on the device: a fixed grid loops over it (surplus workgroups leave at once)
     const long expect = (long)B * (a.max_new < 4 ? a.max_new : 4);
+#ifdef MEL_FILL_GRID
+    const int grid = MEL_FILL_GRID;                  // tuning: fewer, longer-lived fill waves
+#else
     const int grid = (int)(expect < 256 ? 256 : (expect > 4096 ? 4096 : expect));
+#endif
     MEL_LAUNCH(episode_fill_kernel, dim3(grid), dim3(64), 0, stream, a);
     MEL_LAUNCH(episode_publish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
     return check_launch("episode_refill");

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict
         if (lane < n) p.fid[(size_t)b * n + lane] = id;
         const int any_bad = __ballot(bad != 0) != 0ull;
         if (lane == 0) p.fbad[b] = any_bad;
+    } else if (lane == 0) {
+        p.fbad[b] = 0;
     }
     const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
     int oL, o1, o2;
@@ -198,7 +200,10 @@ __global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restric
     if (b >= bs) return;
     const int lane = lane_id();
     if (b == 0 && lane == 0) p.fmeta[0] = table_rows;
-    if (table_rows <= 0) return;
+    if (table_rows <= 0) {
+        if (lane == 0) p.fbad[b] = 0;
+        return;
+    }
     int bad = 0, id = 0;
     if (lane < n) id = node_feature_id(obs + (size_t)b * obs_stride + lane * node_cols + 2, n, &bad);
     if (lane < n) p.fid[(size_t)b * n + lane] = id;

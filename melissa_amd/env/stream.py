@@ -24,6 +24,7 @@ error flag unless the table is periodic by construction (the evaluation schedule
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -64,7 +65,7 @@ class StaticSupply:
     def first_episode_ids(self) -> torch.Tensor:
         return self.table[:, 0].contiguous()
 
-    def before_step(self, iteration: int):
+    def before_step(self, iteration: int, round_counter=None):
         pass
 
     def describe(self) -> dict:
@@ -129,6 +130,9 @@ class EpisodeStream:
         self._ev_main = torch.cuda.Event()
         self._ev_done = None
         self.refills = 0
+        self._max_new = int(os.environ["MEL_STREAM_MAX_NEW"]) if "MEL_STREAM_MAX_NEW" in os.environ else None   # tuning only
+        if "MEL_STREAM_PERIOD" in os.environ:
+            self.period = int(os.environ["MEL_STREAM_PERIOD"])
         # first fill on the current stream: the loop resets its envs from slot 0 right after
         self.refill(discard=discard)
 
@@ -142,9 +146,29 @@ class EpisodeStream:
     def first_episode_ids(self) -> torch.Tensor:
         return self.table[:, 0].contiguous()
 
-    def before_step(self, iteration: int):
-        """Call before launching iteration number ``iteration`` (0-based) on the current stream."""
+    def before_step(self, iteration: int, round_counter: "torch.Tensor | None" = None):
+        """Call before launching iteration number ``iteration`` (0-based) on the current stream.  Every ``period``
+        iterations one refill is issued on the side stream, ordered after the main stream's progress in one of two ways:
+
+        * ``round_counter`` given (the device counter mel_env_round advances once per round, RoundLoop): a pacing gate
+          (mel_wait_counter) on the SIDE stream polls it until this iteration's env launch has started, i.e. the previous
+          iteration is complete; nothing touches the main stream (an event record / wait between HIP-graph replays costs
+          the replayed step ~8 us on this stack, measured).  Nothing orders the main stream behind the refill either: a
+          refill takes ~0.15 ms and no env can need its episodes before ``ring - period - 3`` more iterations; should that
+          ever fail, the env kernels' produced check raises MEL_ENV_ERR_EPISODE_UNDERRUN (an error, never a stale slot).
+        * no counter (DecisionLoop): events - the side stream waits for an event recorded on the main stream, and the main
+          stream waits for the refill one period later."""
         if iteration % self.period:
+            return
+        # paced mode needs slack: a refill gated at iteration i reads cursors of iteration i-1 or i, finishes within the next
+        # iteration or two, and must cover every episode an env can start until the NEXT refill has finished, i.e. up to
+        # period + 1 more: period <= ring - 3 (one more of margin kept).  Small test rings fall back to events.
+        if (round_counter is not None and self.period <= self.ring - 4
+                and os.environ.get("MEL_STREAM_SYNC", "paced") == "paced"):
+            with torch.cuda.stream(self.side):
+                _lib.check(self.lib.mel_wait_counter(round_counter.data_ptr(), (iteration + 1) & 0xFFFFFFFF, 200000,
+                                                     _lib.current_stream_ptr(self.venv.device)), "mel_wait_counter")
+                self.refill(max_new=self._max_new)
             return
         main = torch.cuda.current_stream(self.venv.device)
         if self._ev_done is not None:
@@ -152,7 +176,7 @@ class EpisodeStream:
         self._ev_main.record(main)
         self.side.wait_event(self._ev_main)           # exact episode cursors: everything issued so far has run
         with torch.cuda.stream(self.side):
-            self.refill()
+            self.refill(max_new=self._max_new)
             if self._ev_done is None:
                 self._ev_done = torch.cuda.Event()
             self._ev_done.record(self.side)

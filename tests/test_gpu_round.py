@@ -382,7 +382,7 @@ def test_training_loop_n50_first_update_matches_oracle_autograd(model):
         q = logits[torch.arange(len(b["act"])), b["act"]]
         loss = (b["returns"] - q).pow(2).mean()
     loss.backward()
-    assert abs(float(loss) - out["loss_first"]) <= 1e-4 * max(1.0, abs(float(loss))), (float(loss), out["loss_first"])
+    assert abs(float(loss.detach()) - out["loss_first"]) <= 1e-4 * max(1.0, abs(float(loss.detach()))), (float(loss.detach()), out["loss_first"])
     # Adam's first step from zero moments: delta = -lr * g / (|g| + eps) -> -lr * sign(g) wherever |g| >> 1e-8
     checked = agree = 0
     for k, g in ((k, v.grad) for k, v in sd.items()):
