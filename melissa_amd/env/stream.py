@@ -166,7 +166,9 @@ class EpisodeStream:
         if (round_counter is not None and self.period <= self.ring - 4
                 and os.environ.get("MEL_STREAM_SYNC", "paced") == "paced"):
             with torch.cuda.stream(self.side):
-                _lib.check(self.lib.mel_wait_counter(round_counter.data_ptr(), (iteration + 1) & 0xFFFFFFFF, 200000,
+                # (the gate is satisfied by the env launch this very step() call issues next; the 2 s bound only guards the
+                #  process exit should that launch never come.  The host can run hundreds of replays ahead of the GPU.)
+                _lib.check(self.lib.mel_wait_counter(round_counter.data_ptr(), (iteration + 1) & 0xFFFFFFFF, 2000000,
                                                      _lib.current_stream_ptr(self.venv.device)), "mel_wait_counter")
                 self.refill(max_new=self._max_new)
             return
