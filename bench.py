@@ -575,6 +575,10 @@ def main():
                                                  "bf16 pieces, six partial products; logits 3-7e-8 from the oracle like the native path)",
                                             dtype="f32s"),
         }
+        if world > 1:
+            # N > 1: only the configuration BASELINE quotes on several GPUs (configs[3]) besides the headline - every leg is a
+            # chain of collectives (barriers, reductions) that all ranks must walk in step, so the fewer the better
+            specs = {k: v for k, v in specs.items() if k == "config3_hldgn_512envs_per_gpu"}
         legs = {}
         for name, spec in specs.items():
             try:

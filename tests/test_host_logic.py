@@ -294,3 +294,23 @@ def test_graphs_beyond_64_nodes_are_refused_up_front():
     with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
         HipGraphVectorEnv(2, 100, graph_pool=synthetic_graph_pool(12, 1, 0), device="cpu")
     LDGNNetwork(5, 128, 2, 4, 64, dueling_param=DUEL(), backend="torch")
+
+
+def test_packed_graph_pool_round_trip(tmp_path):
+    """The on-disk / in-HBM graph dataset (pos f64 [G, N, 2] + adj u64 [G, N]; replaces graph_topologies/*.pickle,
+    core.py:165-175,450-452): same graphs as the list generator, lossless save / load, cached second call."""
+    from melissa_amd.env import cached_graph_pool, load_graph_pool, packed_graph_pool, save_graph_pool
+    pos, hop, seeds = packed_graph_pool(20, 30, first_seed=0)
+    ref = synthetic_graph_pool(20, 30, 0)
+    assert pos.shape == (30, 20, 2) and hop.dtype == np.uint64 and len(seeds) == 30 and seeds[0] >= 0
+    for g in range(30):
+        np.testing.assert_array_equal(pos[g], ref[g].pos)
+        np.testing.assert_array_equal(hop[g], ref[g].one_hop)
+    path = str(tmp_path / "pool.npz")
+    save_graph_pool(path, pos, hop, seeds)
+    back = load_graph_pool(path)
+    assert len(back) == 30 and all(b.is_connected() for b in back)
+    np.testing.assert_array_equal(back[7].pos, ref[7].pos)
+    a = cached_graph_pool(20, 12, 0, cache_dir=str(tmp_path))
+    b = cached_graph_pool(20, 12, 0, cache_dir=str(tmp_path))          # second call reads the .npz
+    assert len(a) == len(b) == 12 and all(np.array_equal(x.one_hop, y.one_hop) for x, y in zip(a, b))
