@@ -568,7 +568,7 @@ def main():
                                      "HIP graph (the latency-bound launches of one half fill the gaps of the other); not the headline "
                                      "because overlapping launches cannot be priced per kernel", streams=2),
             "prepared_feature_tables": dict(note="the headline workload with the node-feature table (encoder + conv1 projections of the "
-                                                 "3 200 feature tuples: a function of the weights only) prepared ONCE per weight "
+                                                 "2 000 feature tuples: a function of the weights only) prepared ONCE per weight "
                                                  "version (mel_prepare_feature_tables) instead of evaluated inside every step as the "
                                                  "headline does; bit-identical logits", prepared_tables=True),
             "f32_via_split_bf16_mfma": dict(note="fp32-accurate projections on the bf16 matrix cores (every operand split exactly into three "

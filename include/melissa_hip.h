@@ -116,9 +116,9 @@ typedef struct mel_weights {
 } mel_weights;
 #define MEL_FWD_PLAN_READY 1
 /* MEL_FWD_INTEGER_FEATURES: the caller guarantees that the five node features of every observation row are the integers
- * GraphEnv writes (graph.py:261-269: degree in [0, N), messages transmitted in [0, 8), last action / interested / has
- * message in {0, 1}) - true for everything mel_env_* produces.  The encoder and the conv1 projections are then functions of
- * one of N * 64 feature TUPLES: when the receptive-field row lists are at least twice that long, the forward evaluates them
+ * GraphEnv writes for policy agents (graph.py:261-269: degree in [0, N), messages transmitted in [0, 4], last action /
+ * interested / has message in {0, 1}) - true for everything mel_env_* produces when no agent is scripted.  The encoder and the conv1 projections are then functions of
+ * one of N * 40 feature TUPLES: when the receptive-field row lists are at least twice that long, the forward evaluates them
  * once per tuple (table rows, on every call - nothing is kept between calls) and the conv1 attention gathers rows by tuple
  * id.  Same arithmetic per row, bit-identical logits.  A feature outside the ranges is clamped into the table and flagged
  * (mel_forward_tap kind 3).  Without the flag the general row-list path runs (arbitrary float features). */
@@ -145,7 +145,7 @@ typedef struct mel_weights {
 size_t mel_prepared_weights_bytes(const mel_weights* w);
 mel_status mel_prepare_weights(const mel_weights* w, void* prepared, size_t bytes, void* stream);
 
-/* The node-feature table of MEL_FWD_INTEGER_FEATURES (encoder row and conv1 projections of each of the n_nodes * 64 feature
+/* The node-feature table of MEL_FWD_INTEGER_FEATURES (encoder row and conv1 projections of each of the n_nodes * 40 feature
  * tuples) evaluated ONCE per weight version into a caller-owned buffer, like the prepared weights above: same kernels, same
  * rows, same bits as the per-call evaluation.  Opt-in (mel_weights.tables); precision follows mel_weights.precision and,
  * for bf16 / split, needs mel_weights.prepared. */

@@ -61,7 +61,9 @@ class DecisionLoop:
         """One collector iteration for every env (one agent decision per env)."""
         self.supply.before_step(self.iterations)
         net = self.policy.model
-        net.hip_forward(self.obs, out=self.logits, integer_features=True)      # observations written by the env kernels
+        # observations written by the env kernels: integer node features (unless scripted agents relay beyond four times)
+        net.hip_forward(self.obs, out=self.logits,
+                        integer_features=self.venv._sampler_kw["scripted_agents_ratio"] == 0.0)
         if self.eps > 0.0:
             rand_u = torch.rand(self.venv.env_num, device=self.obs.device, generator=self.gen)
             rand_q = torch.rand(self.venv.env_num, self.n_actions, device=self.obs.device, generator=self.gen)
@@ -105,7 +107,8 @@ class RoundLoop:
         self.use_graph, self.graph = use_graph, None
         # the observations are the env kernels' own, so their node features are integers in known ranges and the forward may
         # evaluate encoder / conv1 projections once per feature TUPLE (MEL_FWD_INTEGER_FEATURES); False forces row lists
-        self.integer_features = True
+        # (scripted agents relay without a step budget, so their message counts leave the table's range: row lists then)
+        self.integer_features = venv._sampler_kw["scripted_agents_ratio"] == 0.0
         self.stream = stream                       # None: torch's current stream
         self.replay = replay                       # optional melissa_amd.replay.RoundReplay
         dev = venv.device

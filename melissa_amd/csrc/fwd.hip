@@ -319,6 +319,14 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
 
 namespace mel {
 
+// The row lists of a forward and the encoder rows of its node-feature table in ONE launch: the first `gemm_blocks`
+// workgroups are 64 x 64 tiles of the (feature-domain) encoder GEMM, the rest run plan_lists.  The two are independent (the
+// table depends on the weights only) and each is a latency-bound launch of a few hundred workgroups on its own.
+__global__ __launch_bounds__(256, 2) void plan_enc_kernel(PlanListsArgs pa, GemmBatch batch, int gemm_blocks) {
+    if ((int)blockIdx.x < gemm_blocks) gemm_f32_tile<2, 2, 1, 1, GEMM_MODE_ENC>(batch, (int)blockIdx.x);
+    else plan_lists_body(pa, (int)blockIdx.x - gemm_blocks);
+}
+
 // ------------------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------------------
@@ -408,7 +416,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.plan.adj = c.take<uint64_t>(M);
     L.plan.live = c.take<uint64_t>(d.bs);
     const int latent = w->q_head.layer[0].in_dim;
-    // node-feature table mode: the encoder / conv1-projection buffers must also hold the N * 64 table rows
+    // node-feature table mode: the encoder / conv1-projection buffers must also hold the N * 40 table rows
     const size_t T = (size_t)d.n * FEATURE_TUPLES_PER_DEGREE;
     const size_t rows2 = (size_t)d.u2_cap > T ? (size_t)d.u2_cap : T, rows1 = (size_t)d.u1_cap > T ? (size_t)d.u1_cap : T;
     const size_t rowsM = M > T ? M : T;
@@ -695,12 +703,13 @@ static FeatureTables carve_tables(const mel_weights* w, int n, void* buf, size_t
     if (bytes) *bytes = c.off;
     return t;
 }
-static mel_status run_feature_tables(const mel_weights* w, const ProjWeights& pw, int n, const FeatureTables& t, hipStream_t s) {
+static mel_status run_feature_tables(const mel_weights* w, const ProjWeights& pw, int n, const FeatureTables& t, hipStream_t s,
+                                     bool encoder_done = false) {
     const int T = n * FEATURE_TUPLES_PER_DEGREE;
     const int hidden = w->encoder.layer[1].out_dim, hc = w->conv1.heads * w->conv1.channels;
     const int bf = w->precision == MEL_PREC_BF16, sp = w->precision == MEL_PREC_F32_SPLIT;
     const bool tconv = w->conv1.kind == MEL_CONV_TRANSFORMER, hl = w->model == MEL_MODEL_HLDGN;
-    {
+    if (!encoder_done) {
         GemmArgs g;
         g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
         g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
@@ -760,9 +769,10 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const long hintL = single ? bs : (n < 10 ? bs : bs * (long)(36 + n) / 18);
     const long hint1 = single ? bs * (long)(n < 8 ? n : 2 + n / 8) : (n < 10 ? bs * (long)n : bs * 2L * (18 + n) / 13);
     const long hint2 = single ? bs * (long)(n < 8 ? n : 1 + n / 4) : (n < 10 ? bs * (long)n : bs * 3L * (8 + n) / 11);
-    // Node-feature table (plan_masks.hpp): worth it when the row lists are much longer than the N * 64 tuples
+    // Node-feature table (plan_masks.hpp): worth it when the row lists are much longer than the N * 40 tuples
     const int T = n * FEATURE_TUPLES_PER_DEGREE;
     const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && hint1 + hint2 >= 2L * T;
+    bool fused_enc = false;
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -777,8 +787,24 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
             MEL_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, s, (int)bs, L.plan);
             if (mel_status st = check_launch("plan_scan")) return st;
         }
-        MEL_LAUNCH(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out,
-                           tconv ? 0 : 1, inline_scan, table ? T : 0);
+        // fp32 + node-feature table: the row lists and the encoder rows of the feature tuples (which depend on the weights
+        // only) are independent - ONE launch runs both (plan_enc_kernel) instead of two latency-bound ones back to back
+        fused_enc = table && !bf && !sp && !(w->tables && w->tables_nodes == n);
+        const PlanListsArgs pa{obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out, tconv ? 0 : 1, inline_scan, table ? T : 0};
+        if (fused_enc) {
+            GemmArgs g;
+            g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
+            g.W = pw.enc1, g.bias = w->encoder.layer[1].bias;
+            g.Y = L.h0, g.ldy = hidden, g.M = T, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+            if (mel_status st = check_gemm_shape(g, "encoder (feature tuples)")) return st;
+            GemmBatch batch{};
+            batch.count = 1, batch.p[0] = g, batch.start[0] = 0;
+            const int tiles = ((((T + 63) / 64) * (hidden / 64)) + 7) & ~7;
+            batch.start[1] = tiles;
+            MEL_LAUNCH(plan_enc_kernel, dim3(tiles + (int)((bs + 3) / 4)), dim3(256), 0, s, pa, batch, tiles);
+        } else {
+            MEL_LAUNCH(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, pa);
+        }
         if (mel_status st = check_launch("plan_lists")) return st;
     }
     {   // encoder on the U2 rows: relu(W1 relu(W0 x + b0) + b1)      (l_dgn.py:117-118)
@@ -796,7 +822,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     FeatureTables ft{L.h0, L.xl1, L.xr1};
     if (table) {
         if (w->tables && w->tables_nodes == n) ft = carve_tables(w, n, const_cast<void*>(w->tables), nullptr);
-        else if (mel_status st = run_feature_tables(w, pw, n, ft, s)) return st;
+        else if (mel_status st = run_feature_tables(w, pw, n, ft, s, /*encoder_done=*/fused_enc)) return st;
     }
     {   // conv1.lin_l on the U2 rows + conv1.lin_r on the U1 rows, one grouped launch
         GemmArgs g[2];

@@ -102,8 +102,9 @@ __device__ __forceinline__ void enc_features(const GemmArgs& g, int row, float x
 #pragma unroll
     for (int f = 0; f < 8; ++f) x[f] = 0.f;
     if (g.feat_domain) {
-        x[0] = (float)(row >> 6), x[1] = (float)((row >> 3) & 7), x[2] = (float)((row >> 2) & 1);
-        x[3] = (float)((row >> 1) & 1), x[4] = (float)(row & 1);
+        const int deg = row / 40, rem = row - deg * 40;               // tuple id = degree * 40 + messages * 8 + flags
+        x[0] = (float)deg, x[1] = (float)(rem >> 3), x[2] = (float)((rem >> 2) & 1);
+        x[3] = (float)((rem >> 1) & 1), x[4] = (float)(rem & 1);
         return;
     }
     const int id = g.nid ? g.nid[row] : row;
@@ -177,12 +178,14 @@ __device__ __forceinline__ void store_block_f32(const GemmArgs& g, const f32x16&
     store_block_f32(g, acc, m_lane, n, M, fetch_epilogue_operands(g, m_lane, n, M));
 }
 
+// body of gemm_f32_kernel for workgroup `block` of the launch's tile list (a device function so that another kernel can run
+// GEMM tiles and unrelated work in ONE launch: plan_enc_kernel, fwd.hip)
 template <int WM, int WN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32_kernel(GemmBatch batch) {
+__device__ __forceinline__ void gemm_f32_tile(const GemmBatch& batch, const int block) {
     int pi = 0;
 #pragma unroll
     for (int k = 1; k < GEMM_MAX_GROUP; ++k)
-        if (k < batch.count && (int)blockIdx.x >= batch.start[k]) pi = k;
+        if (k < batch.count && block >= batch.start[k]) pi = k;
     const GemmArgs& g = batch.p[pi];
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, T = 64 * WM * WN;
     constexpr int A_CHUNKS = BM * (GEMM_BK / 4) / T;   // float4 chunks per thread per K step
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
     const int nbn = g.N / BN;
     const int M = g.M_dev ? min(*g.M_dev, g.M) : g.M;
     const int active = ((M + BM - 1) / BM) * nbn;
-    int wg = blockIdx.x - batch.start[pi];
+    int wg = block - batch.start[pi];
     if (wg >= active) return;
     {
         const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
@@ -318,6 +321,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
 #pragma unroll
         for (int i = 0; i < TM; ++i)
             store_block_f32(g, acc[i][j], m0 + wm * 32 * TM + i * 32 + 4 * h, n0 + wn * 32 * TN + j * 32 + r, M);
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32_kernel(GemmBatch batch) {
+    gemm_f32_tile<WM, WN, TM, TN, MODE>(batch, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

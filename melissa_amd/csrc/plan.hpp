@@ -129,11 +129,23 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(int bs, PlanBuffers p) 
     if (tid == 1023) p.offL[bs] = part[0][1023], p.off1[bs] = part[1][1023], p.off2[bs] = part[2][1023];
 }
 
-__global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict__ obs, int bs, int n,
-                                                         int obs_stride, int node_cols, PlanBuffers p,
-                                                         int32_t* __restrict__ row_offsets_out, int self_loops,
-                                                         int inline_scan, int table_rows) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+struct PlanListsArgs {
+    const float* obs;
+    int bs, n, obs_stride, node_cols;
+    PlanBuffers p;
+    int32_t* row_offsets_out;
+    int self_loops, inline_scan, table_rows;
+};
+
+// body of plan_lists_kernel for workgroup `block` (four envs): a device function so that plan_enc_kernel (fwd.hip) can run
+// it beside the encoder rows of the node-feature table in one launch
+__device__ __forceinline__ void plan_lists_body(const PlanListsArgs& a, const int block) {
+    const float* __restrict__ obs = a.obs;
+    const int bs = a.bs, n = a.n, obs_stride = a.obs_stride, node_cols = a.node_cols;
+    const PlanBuffers& p = a.p;
+    int32_t* __restrict__ row_offsets_out = a.row_offsets_out;
+    const int self_loops = a.self_loops, inline_scan = a.inline_scan, table_rows = a.table_rows;
+    const int b = block * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
     if (b == 0 && lane == 0) p.fmeta[0] = table_rows;
@@ -192,6 +204,8 @@ __global__ __launch_bounds__(256) void plan_lists_kernel(const float* __restrict
         if (b == bs - 1) row_offsets_out[bs] = oL + p.cnt[b];
     }
 }
+
+__global__ __launch_bounds__(256) void plan_lists_kernel(PlanListsArgs a) { plan_lists_body(a, (int)blockIdx.x); }
 
 // HL-DGN has no row lists: the tuple ids alone (one wave per env)
 __global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,

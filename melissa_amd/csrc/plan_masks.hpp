@@ -29,23 +29,25 @@ __device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, i
 
 // ---- node-feature table (MEL_FWD_INTEGER_FEATURES) ---------------------------------------------------------------------
 // The five node features the encoder reads are small integers in the env's observations (graph.py:261-269: degree < N,
-// messages transmitted <= 4, last action, interested, has message as 0 / 1), so a node's encoder row and its conv1
-// projections are functions of one of N * 64 TUPLES.  With the flag set the forward evaluates the encoder and the conv1
+// messages transmitted <= 4 for a policy agent - at most four acting steps, graph.py:330-334, the source's forced first
+// transmission included -, last action, interested, has message as 0 / 1), so a node's encoder row and its conv1
+// projections are functions of one of N * 40 TUPLES.  With the flag set the forward evaluates the encoder and the conv1
 // projections once per tuple (table rows, every call - nothing is kept between calls) and the attention kernels fetch rows
 // by tuple id instead of by packed receptive-field row.  Per row it is the same arithmetic in the same order, so logits are
-// bit-identical to the row-list path.  tuple id = (((degree * 8 + messages) * 2 + action) * 2 + interested) * 2 + has_message
-constexpr int FEATURE_TUPLES_PER_DEGREE = 64;
+// bit-identical to the row-list path.  tuple id = degree * 40 + messages * 8 + action * 4 + interested * 2 + has_message.
+// (Scripted agents relay without a step budget: the loops leave the flag off for envs that have them.)
+constexpr int FEATURE_TUPLES_PER_DEGREE = 40;      // 5 message counts x 8 flag combinations
 __device__ __forceinline__ int node_feature_id(const float* f, int n, int* bad) {
     const float deg = f[0], msg = f[1], act = f[2], itr = f[3], has = f[4];
     int d = (int)deg, m = (int)msg, a = (int)act, i = (int)itr, h = (int)has;
     const bool ok = (float)d == deg && (float)m == msg && (float)a == act && (float)i == itr && (float)h == has &&
-                    d >= 0 && d < n && m >= 0 && m < 8 && a >= 0 && a < 2 && i >= 0 && i < 2 && h >= 0 && h < 2;
+                    d >= 0 && d < n && m >= 0 && m < 5 && a >= 0 && a < 2 && i >= 0 && i < 2 && h >= 0 && h < 2;
     if (!ok) {                                   // not an observation of this env family: flagged, clamped into the table
         *bad = 1;
-        d = d < 0 ? 0 : (d >= n ? n - 1 : d), m = m < 0 ? 0 : (m > 7 ? 7 : m);
+        d = d < 0 ? 0 : (d >= n ? n - 1 : d), m = m < 0 ? 0 : (m > 4 ? 4 : m);
         a = a != 0, i = i != 0, h = h != 0;
     }
-    return (((d * 8 + m) * 2 + a) * 2 + i) * 2 + h;
+    return d * FEATURE_TUPLES_PER_DEGREE + m * 8 + a * 4 + i * 2 + h;
 }
 
 // the plan masks of one env from its fp32 node positions (lane = node) and its agent set; want_receptive < 0: adjacency
