@@ -97,11 +97,7 @@ static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int
     }
     switch (tag) {
         case 1: gemm_launch_persistent<2, 2, 1, 1, 1>(gs, count, GEMM_MODE_PLAIN, s); break;
-#ifdef MEL_CONV2_TILE128
-        case 2: gemm_launch_persistent<2, 2, 2, 2, 2>(gs, count, GEMM_MODE_PLAIN, s); break;
-#else
         case 2: gemm_launch_persistent<2, 2, 1, 1, 2>(gs, count, GEMM_MODE_PLAIN, s); break;
-#endif
         case 3: gemm_launch_persistent<2, 2, 1, 1, 3>(gs, count, GEMM_MODE_PLAIN, s); break;
         default: gemm_launch_persistent<2, 2, 1, 1, 0>(gs, count, GEMM_MODE_PLAIN, s); break;
     }
