@@ -35,13 +35,20 @@ extern "C" {
 
 typedef int32_t mel_status;
 #define MEL_OK                 0
-#define MEL_ERR_INVALID_ARG   -1   /* null pointer, bad size, N outside [1, 64] ...              */
+#define MEL_ERR_INVALID_ARG   -1   /* null pointer, bad size, N outside [1, 128] ...             */
 #define MEL_ERR_SHAPE         -2   /* obs width != N*(in_dim+3)+1 (networks/common.py:24-29)      */
 #define MEL_ERR_UNSUPPORTED   -3   /* layer sizes the kernels are not built for                  */
 #define MEL_ERR_WORKSPACE     -4   /* ws_bytes < mel_workspace_bytes(...)                        */
 #define MEL_ERR_LAUNCH        -5   /* hipGetLastError() != hipSuccess after a launch             */
 
-#define MEL_MAX_NODES         64   /* node sets are 64-bit masks, one wavefront lane per node    */
+/* Node sets.  A set of nodes of an N-node graph is MEL_SET_WORDS(N) consecutive uint64 words, word k holding nodes
+ * 64 k .. 64 k + 63 (bit i of word k = node 64 k + i).  For N <= 64 (the sizes BASELINE quotes, 20 and 50) that is ONE
+ * 64-bit mask and every layout below is exactly "one uint64 per set"; for 64 < N <= 128 (the reference CLI's third size,
+ * --n-agents 100, common.py:49) every array documented as uint64 [..] of node sets gains a trailing [2]: one_hop is
+ * [B, N, 2], node_sets [B, 8, 2], live [B, 2], adjacency taps [bs, N, 2] and so on.  One wavefront still steps one env;
+ * a lane then holds the two nodes lane and lane + 64. */
+#define MEL_MAX_NODES        128
+#define MEL_SET_WORDS(n)     (((n) + 63) / 64)
 #define MEL_NODE_COLS          8   /* x, y, 5 features, dm flag (graph.py:80)                    */
 #define MEL_MAX_HEAD_LAYERS    6
 

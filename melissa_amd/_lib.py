@@ -8,16 +8,21 @@ import os
 from . import build as _build
 
 MAX_HEAD_LAYERS = 6
-MAX_NODES = 64               # MEL_MAX_NODES: node sets are 64-bit masks, one wavefront lane per node
+MAX_NODES = 128              # MEL_MAX_NODES: one wavefront per graph, one or two nodes per lane, node sets = 1 or 2 uint64 words
+
+
+def set_words(n: int) -> int:
+    """MEL_SET_WORDS: uint64 words per node set (1 up to 64 nodes, 2 beyond)."""
+    return (int(n) + 63) // 64
 
 
 def check_n_nodes(n: int, what: str):
-    """The kernels hold one graph per wavefront (lane = node, node sets = 64-bit masks), so graphs have at most 64 nodes.
-    The reference CLI also offers --n-agents 100 (common.py:49): that size has no path here and is refused up front."""
+    """The kernels hold one graph per wavefront (a lane holds node i and, beyond 64 nodes, node i + 64; node sets are one
+    or two 64-bit words), so graphs have at most 128 nodes: the reference CLI's --n-agents 20 / 50 / 100 (common.py:49) all
+    fit."""
     if not (1 <= int(n) <= MAX_NODES):
-        raise ValueError(f"{what}: {n} nodes per graph is outside [1, {MAX_NODES}] - the MI355X kernels map one node to one "
-                         f"wavefront lane and keep node sets in 64-bit masks (the reference's 20- and 50-node configurations "
-                         f"fit; its --n-agents 100 option does not)")
+        raise ValueError(f"{what}: {n} nodes per graph is outside [1, {MAX_NODES}] - the MI355X kernels hold one graph per "
+                         f"wavefront (at most two nodes per lane, node sets of at most two 64-bit words)")
 MODEL_LDGN, MODEL_HLDGN, MODEL_DGNR = 0, 1, 2
 CONV_GATV2, CONV_TRANSFORMER = 0, 1
 AGG = {"max": 0, "mean": 1, "add": 2}

@@ -123,7 +123,8 @@ class RoundLoop:
         # HL-DGN's logits do not depend on the agent (hl_dgn.py:108): one row per env, dense action layout
         self.per_env_logits = policy.model._MODEL == _lib.MODEL_HLDGN
         self.rows_cap = venv.env_num if self.per_env_logits else int(rows_cap or venv.env_num * venv.n)
-        self.live = torch.zeros(venv.env_num, dtype=torch.int64, device=dev)
+        self.live = torch.zeros(venv.env_num, *(() if venv.n <= 64 else (_lib.set_words(venv.n),)), dtype=torch.int64,
+                                device=dev)         # the round's active sets (node sets: [B], or [B, W] beyond 64 nodes)
         self.offsets = torch.zeros(venv.env_num + 1, dtype=torch.int32, device=dev)
         self.logits = torch.zeros(self.rows_cap, self.n_actions, dtype=torch.float32, device=dev)
         self.act = torch.zeros(venv.env_num * venv.n if self.per_env_logits else self.rows_cap, dtype=torch.int32,
@@ -186,12 +187,15 @@ class RoundLoop:
             self._step()
 
     def _step(self):
-        # episode stream: refill on a side stream every few rounds, paced by the device-side round counter
-        self.supply.before_step(self.iterations - self._rounds_base, self.rounds)
+        # episode stream: refill on a side stream every few rounds, paced by the device-side round counter; the pacing gate
+        # goes into its queue AFTER the launches it waits for (EpisodeStream.after_step)
+        it = self.iterations - self._rounds_base
+        self.supply.before_step(it, self.rounds)
         if self.use_graph:
             if self.graph is None:
                 self._launch()                        # warm-up outside capture (lazy init)
                 self.iterations += 1
+                self.supply.after_step(it, self.rounds)
                 torch.cuda.synchronize(self.venv.device)
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):    # launches land on the capture stream (torch's current one)
@@ -201,6 +205,7 @@ class RoundLoop:
         else:
             self._launch()
         self.iterations += 1
+        self.supply.after_step(it, self.rounds)
 
     def run(self, iterations: int):
         for _ in range(iterations):

@@ -21,6 +21,7 @@ struct AttArgs {
     int ld_r;
     const float* att;       // [heads*C]
     const float* bias;      // [heads*C]
+    // node sets: MEL_SET_WORDS(n) words each
     const uint64_t* adj;    // [bs*N]
     const uint64_t* live;   // [bs] controlling agents (ATT_ROWS: whose x_1 / x_2 go to the head input)
     const uint64_t* tmask;  // [bs] targets, or null = all nodes
@@ -42,7 +43,7 @@ struct AttArgs {
     int obs_stride, node_cols, aggregator;
     float* pooled;          // [bs, heads*C]
     // ATT_ROWS / ATT_SINGLE: one wavefront per target row
-    const TargetDesc* desc;     // [rows] per-target descriptor
+    const void* desc;           // [rows] per-target descriptor (TargetDesc<W>)
     const int32_t* rows_dev;    // device-side row count
     long rows_hint;             // expected rows (grid sizing only)
     int rows_cap, cat_off;
@@ -159,12 +160,12 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 //   m' = max(m, s_0..s_3); l = l e^(m-m') + sum_k e^(s_k-m'); acc = acc e^(m-m') + sum_k e^(s_k-m') row_k
 // KIND = MEL_CONV_GATV2:       e = att . leaky_relu(x_r[i] + x_l[j]),          out = sum alpha x_l[j]
 // KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
-// my_fid: table mode - this lane's node's tuple id (lane = node of the target's env); a source row is then the table row
-// of the source's tuple (one v_readlane) instead of its packed position in the row list.
-template <int VPL, int KIND, bool BF>
-__device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_row, uint64_t sources,
-                                                  uint64_t smask, int soff, const Vec<VPL>& att,
-                                                  const Vec<VPL>& bias, int lane, int my_fid = 0) {
+// my_fid: table mode - the tuple ids of this lane's nodes (node lane + 64 h of the target's env); a source row is then the
+// table row of the source's tuple (one v_readlane) instead of its packed position in the row list.
+template <int VPL, int KIND, bool BF, int W>
+__device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_row, NodeSet<W> sources,
+                                                  const NodeSet<W>& smask, int soff, const Vec<VPL>& att,
+                                                  const Vec<VPL>& bias, int lane, const int (&my_fid)[W]) {
     const bool table = a.fid != nullptr;
     constexpr int HC = 64 * VPL;
 #ifndef MEL_ATT_G
@@ -176,15 +177,15 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
     Vec<VPL> acc;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    while (sources) {                            // TransformerConv adds no self-loop: a target may be isolated
+    while (ns_any(sources)) {                    // TransformerConv adds no self-loop: a target may be isolated
         size_t row[G];                           // element index of this lane's slice of the source row
         bool on[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) {
-            on[k] = sources != 0;
-            const int j = on[k] ? lowest_bit(sources) : 0;
-            sources &= sources - 1;              // 0 stays 0
-            const int srow = table ? lane_i32(my_fid, j) : soff + (on[k] ? rank_below(smask, j) : 0);
+            on[k] = ns_any(sources);
+            const int j = on[k] ? ns_lowest(sources) : 0;
+            ns_clear_lowest(sources);            // empty stays empty
+            const int srow = table ? node_i32<W>(my_fid, j) : soff + (on[k] ? ns_rank_below(smask, j) : 0);
             row[k] = (size_t)srow * a.ld_l + lane * VPL;                     // off slots re-read a valid row
         }
         Vec<VPL> xl[G], xv[G];
@@ -279,7 +280,7 @@ __device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
 __device__ unsigned long long g_att_prof[8];
 #endif
 
-template <int VPL, int MODE, int KIND, bool BF>
+template <int VPL, int MODE, int KIND, bool BF, int W>
 __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
 #ifdef MEL_ATT_PROF
     const unsigned long long p0 = __builtin_readcyclecounter();
@@ -309,18 +310,19 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
 #ifdef MEL_ATT_PROF
         const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
-        const TargetDesc d = a.desc[r];          // one 32-byte record: no chain of dependent index loads
+        const TargetDesc<W> d = static_cast<const TargetDesc<W>*>(a.desc)[r];   // one 32-byte record: no chain of dependent index loads
 #ifdef MEL_ATT_PROF
-        asm volatile("s_nop 0" ::"s"(d.sources), "s"(d.soff));
+        asm volatile("s_nop 0" ::"s"(d.sources.w[0]), "s"(d.soff));
         const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
-        int my_fid = 0;
+        int my_fid[W];
+        MEL_W_FOR(h) my_fid[h] = 0;
         size_t xr_row = (size_t)r;
         if (MODE == ATT_ROWS && a.fid) {             // table mode: tuple ids of the target's env (one dependent load)
-            my_fid = lane < a.n ? a.fid[(size_t)d.env * a.n + lane] : 0;
-            xr_row = (size_t)lane_i32(my_fid, d.node);
+            MEL_W_FOR(h) my_fid[h] = lane + 64 * h < a.n ? a.fid[(size_t)d.env * a.n + lane + 64 * h] : 0;
+            xr_row = (size_t)node_i32<W>(my_fid, d.node);
         }
-        const Vec<VPL> o = attend_target<VPL, KIND, BF>(a, xr_row, d.sources, d.smask, d.soff, att, bias, lane, my_fid);
+        const Vec<VPL> o = attend_target<VPL, KIND, BF, W>(a, xr_row, d.sources, d.smask, d.soff, att, bias, lane, my_fid);
 #ifdef MEL_ATT_PROF
         asm volatile("s_nop 0" ::"v"(o.v[0]));
         const unsigned long long q2 = __builtin_readcyclecounter();
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
                 // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)
                 store_row<VPL, BF>(a.xcat, cat + a.hidden + lane * VPL, o);
                 // x_1: its encoder row (l_dgn.py:122)
-                const size_t h0 = (size_t)(a.fid ? lane_i32(my_fid, d.node) : d.soff + rank_below(d.smask, d.node)) * a.hidden;
+                const size_t h0 = (size_t)(a.fid ? node_i32<W>(my_fid, d.node) : d.soff + ns_rank_below(d.smask, d.node)) * a.hidden;
                 if constexpr (BF) {
                     uint16_t* dst = reinterpret_cast<uint16_t*>(a.xcat) + cat;
                     const uint16_t* src = reinterpret_cast<const uint16_t*>(a.h0) + h0;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
 // conv1 attention for all nodes, decision-maker mask, max / mean / add pool over the graph.
 // NW wavefronts per env: at 512 envs per GPU four waves per workgroup leave a CU with 8 resident waves (two workgroups),
 // too few to hide the source-row latency; sixteen waves (three targets each at N = 50) fill it.
-template <int VPL, bool BF, int NW>
+template <int VPL, bool BF, int NW, int W>
 __global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     constexpr int HC = 64 * VPL;
     __shared__ float part[NW][HC];
@@ -371,15 +373,16 @@ __global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     const int b = blockIdx.x;
     const Vec<VPL> att = load_vec<VPL>(a.att + lane * VPL);
     const Vec<VPL> bias = load_vec<VPL>(a.bias + lane * VPL);
-    const uint64_t full = (a.n == 64) ? ~0ull : ((1ull << a.n) - 1ull);
+    const NodeSet<W> full = ns_full<W>(a.n);
     Vec<VPL> pool;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) pool.v[i] = (a.aggregator == MEL_AGG_MAX) ? -INFINITY : 0.f;
-    const int my_fid = (a.fid && lane < a.n) ? a.fid[(size_t)b * a.n + lane] : 0;      // table mode (null: rows b*N + i)
+    int my_fid[W];                                                                    // table mode (null: rows b*N + i)
+    MEL_W_FOR(h) my_fid[h] = (a.fid && lane + 64 * h < a.n) ? a.fid[(size_t)b * a.n + lane + 64 * h] : 0;
     for (int t = wave; t < a.n; t += NW) {
-        const uint64_t sources = a.adj[(size_t)b * a.n + t] | (1ull << t);
-        const size_t xr_row = a.fid ? (size_t)lane_i32(my_fid, t) : (size_t)(b * a.n + t);
-        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
+        const NodeSet<W> sources = ns_load<W>(a.adj, (size_t)b * a.n + t) | ns_bit<W>(t);
+        const size_t xr_row = a.fid ? (size_t)node_i32<W>(my_fid, t) : (size_t)(b * a.n + t);
+        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF, W>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
         // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
         const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
@@ -411,12 +414,15 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
     if constexpr (MODE == ATT_POOL) {
         switch (hc / 64) {
 #define MEL_POOL_LAUNCH(V)                                                                                         \
-    if (a.bs >= 2048) {                                                                                           \
-        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 4>), dim3(a.bs), dim3(256), 0, s, a);     \
-        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 4>), dim3(a.bs), dim3(256), 0, s, a);           \
+    if (a.n > 64) {             /* graphs of 65 .. 128 nodes: two-word node sets */                               \
+        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 16, 2>), dim3(a.bs), dim3(1024), 0, s, a);        \
+        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 16, 2>), dim3(a.bs), dim3(1024), 0, s, a);              \
+    } else if (a.bs >= 2048) {                                                                                    \
+        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 4, 1>), dim3(a.bs), dim3(256), 0, s, a);  \
+        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 4, 1>), dim3(a.bs), dim3(256), 0, s, a);        \
     } else {                                                                                                      \
-        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 16>), dim3(a.bs), dim3(1024), 0, s, a);   \
-        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 16>), dim3(a.bs), dim3(1024), 0, s, a);         \
+        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 16, 1>), dim3(a.bs), dim3(1024), 0, s, a);        \
+        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 16, 1>), dim3(a.bs), dim3(1024), 0, s, a);              \
     }
             case 2: MEL_POOL_LAUNCH(2) break;
             case 4: MEL_POOL_LAUNCH(4) break;
@@ -430,15 +436,21 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         if (want > (a.rows_cap + 3) / 4) want = (a.rows_cap + 3) / 4;
         if (want < 256) want = 256;
         const int grid = (int)((want + 7) & ~7L);       // multiple of 8: block id % 8 = XCD
-#define MEL_ATT_LAUNCH(V)                                                                                             \
+#define MEL_ATT_LAUNCH_W(V, WW)                                                                                          \
     if (a.kind == MEL_CONV_TRANSFORMER && a.bf16)                                                                     \
-        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, true>), dim3(grid), dim3(256), 0, s, a);  \
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, true, WW>), dim3(grid), dim3(256), 0, s, a);  \
     else if (a.kind == MEL_CONV_TRANSFORMER)                                                                          \
-        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, false>), dim3(grid), dim3(256), 0, s, a); \
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_TRANSFORMER, false, WW>), dim3(grid), dim3(256), 0, s, a); \
     else if (a.bf16)                                                                                                  \
-        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, true>), dim3(grid), dim3(256), 0, s, a);        \
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, true, WW>), dim3(grid), dim3(256), 0, s, a);        \
     else                                                                                                              \
-        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, false>), dim3(grid), dim3(256), 0, s, a);
+        MEL_LAUNCH((gat_attend_rows_kernel<V, MODE, MEL_CONV_GATV2, false, WW>), dim3(grid), dim3(256), 0, s, a);
+#define MEL_ATT_LAUNCH(V)                                                                                             \
+    if (a.n > 64) {                                                                                                   \
+        MEL_ATT_LAUNCH_W(V, 2)                                                                                        \
+    } else {                                                                                                          \
+        MEL_ATT_LAUNCH_W(V, 1)                                                                                        \
+    }
         switch (hc / 64) {
             case 2: MEL_ATT_LAUNCH(2) break;
             case 4: MEL_ATT_LAUNCH(4) break;
@@ -447,6 +459,7 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
             default: return fail(MEL_ERR_UNSUPPORTED, "%s: heads*C = %d not in {128,256,512,1024}", what, hc);
         }
 #undef MEL_ATT_LAUNCH
+#undef MEL_ATT_LAUNCH_W
     }
     return check_launch(what);
 }

@@ -164,4 +164,133 @@ __device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
     return ((uint64_t)wave_or_u32_dpp((uint32_t)(v >> 32)) << 32) | wave_or_u32_dpp((uint32_t)v);
 }
 
+// ---- node sets of up to 64 * W nodes -------------------------------------------------------------------------------
+// Graphs of up to 64 nodes (the sizes BASELINE quotes: 20, 50) hold one node per wavefront lane and a node set in ONE
+// 64-bit mask (W = 1).  The reference CLI's third size, --n-agents 100 (common.py:49), takes W = 2: a lane holds the
+// two nodes lane and lane + 64, a node set is two words (word k = nodes 64 k .. 64 k + 63), a ballot yields one word.
+// Every kernel that touches node sets is a template on W; with W = 1 the wrappers below compile to the plain uint64_t
+// arithmetic the kernels were written with.  In memory a set is W consecutive uint64 (MEL_SET_WORDS(n_nodes)).
+template <int W>
+struct NodeSet {
+    uint64_t w[W];
+};
+#define MEL_W_FOR(k) _Pragma("unroll") for (int k = 0; k < W; ++k)
+
+template <int W> __device__ __forceinline__ NodeSet<W> ns_zero() {
+    NodeSet<W> r;
+    MEL_W_FOR(k) r.w[k] = 0ull;
+    return r;
+}
+template <int W> __device__ __forceinline__ NodeSet<W> ns_bit(int i) {
+    NodeSet<W> r;
+    if constexpr (W == 1) r.w[0] = 1ull << i;
+    else MEL_W_FOR(k) r.w[k] = ((i >> 6) == k) ? (1ull << (i & 63)) : 0ull;
+    return r;
+}
+// nodes 0 .. n-1
+template <int W> __device__ __forceinline__ NodeSet<W> ns_full(int n) {
+    NodeSet<W> r;
+    MEL_W_FOR(k) {
+        const int c = n - 64 * k;
+        r.w[k] = c >= 64 ? ~0ull : (c <= 0 ? 0ull : ((1ull << c) - 1ull));
+    }
+    return r;
+}
+template <int W> __device__ __forceinline__ NodeSet<W> operator|(NodeSet<W> a, const NodeSet<W>& b) {
+    MEL_W_FOR(k) a.w[k] |= b.w[k];
+    return a;
+}
+template <int W> __device__ __forceinline__ NodeSet<W> operator&(NodeSet<W> a, const NodeSet<W>& b) {
+    MEL_W_FOR(k) a.w[k] &= b.w[k];
+    return a;
+}
+template <int W> __device__ __forceinline__ NodeSet<W> operator~(NodeSet<W> a) {
+    MEL_W_FOR(k) a.w[k] = ~a.w[k];
+    return a;
+}
+template <int W> __device__ __forceinline__ NodeSet<W>& operator|=(NodeSet<W>& a, const NodeSet<W>& b) {
+    MEL_W_FOR(k) a.w[k] |= b.w[k];
+    return a;
+}
+template <int W> __device__ __forceinline__ NodeSet<W>& operator&=(NodeSet<W>& a, const NodeSet<W>& b) {
+    MEL_W_FOR(k) a.w[k] &= b.w[k];
+    return a;
+}
+template <int W> __device__ __forceinline__ bool operator==(const NodeSet<W>& a, const NodeSet<W>& b) {
+    bool e = true;
+    MEL_W_FOR(k) e = e && a.w[k] == b.w[k];
+    return e;
+}
+template <int W> __device__ __forceinline__ bool operator!=(const NodeSet<W>& a, const NodeSet<W>& b) { return !(a == b); }
+template <int W> __device__ __forceinline__ bool ns_any(const NodeSet<W>& a) {
+    uint64_t o = 0;
+    MEL_W_FOR(k) o |= a.w[k];
+    return o != 0ull;
+}
+template <int W> __device__ __forceinline__ int ns_count(const NodeSet<W>& a) {
+    int c = 0;
+    MEL_W_FOR(k) c += __popcll(a.w[k]);
+    return c;
+}
+// lowest / highest member (the set must not be empty)
+template <int W> __device__ __forceinline__ int ns_lowest(const NodeSet<W>& a) {
+    if constexpr (W == 1) return lowest_bit(a.w[0]);
+    else return a.w[0] ? lowest_bit(a.w[0]) : 64 + lowest_bit(a.w[1]);
+}
+template <int W> __device__ __forceinline__ int ns_highest(const NodeSet<W>& a) {
+    if constexpr (W == 1) return 63 - __clzll((long long)a.w[0]);
+    else return a.w[1] ? 127 - __clzll((long long)a.w[1]) : 63 - __clzll((long long)a.w[0]);
+}
+template <int W> __device__ __forceinline__ void ns_clear_lowest(NodeSet<W>& a) {      // an empty set stays empty
+    if constexpr (W == 1) a.w[0] &= a.w[0] - 1ull;
+    else {
+        if (a.w[0]) a.w[0] &= a.w[0] - 1ull;
+        else a.w[1] &= a.w[1] - 1ull;
+    }
+}
+template <int W> __device__ __forceinline__ bool ns_test(const NodeSet<W>& a, int i) {
+    if constexpr (W == 1) return (a.w[0] >> i) & 1ull;
+    else return ((i < 64 ? a.w[0] : a.w[1]) >> (i & 63)) & 1ull;
+}
+// is node lane + 64 h a member?
+template <int W> __device__ __forceinline__ bool ns_mine(const NodeSet<W>& a, int lane, int h) { return (a.w[h] >> lane) & 1ull; }
+// number of members below node i: the position of node i in a set-ordered row list
+template <int W> __device__ __forceinline__ int ns_rank_below(const NodeSet<W>& a, int i) {
+    if constexpr (W == 1) return rank_below(a.w[0], i);
+    else return i < 64 ? rank_below(a.w[0], i) : __popcll(a.w[0]) + rank_below(a.w[1], i - 64);
+}
+template <int W> __device__ __forceinline__ NodeSet<W> ns_uniform(NodeSet<W> a) {      // wave-uniform value -> SGPRs
+    MEL_W_FOR(k) a.w[k] = uniform_u64(a.w[k]);
+    return a;
+}
+template <int W> __device__ __forceinline__ NodeSet<W> ns_wave_or(NodeSet<W> a) {
+    MEL_W_FOR(k) a.w[k] = wave_or_u64(a.w[k]);
+    return a;
+}
+// element `idx` of an array of sets
+template <int W> __device__ __forceinline__ NodeSet<W> ns_load(const uint64_t* p, size_t idx) {
+    NodeSet<W> r;
+    MEL_W_FOR(k) r.w[k] = p[idx * W + k];
+    return r;
+}
+template <int W> __device__ __forceinline__ void ns_store(uint64_t* p, size_t idx, const NodeSet<W>& a) {
+    MEL_W_FOR(k) p[idx * W + k] = a.w[k];
+}
+// cross-lane reads of per-node values (v[h] = value of node lane + 64 h) at a WAVE-UNIFORM node i
+template <int W> __device__ __forceinline__ int node_i32(const int (&v)[W], int i) {
+    if constexpr (W == 1) return lane_i32(v[0], i);
+    else return i < 64 ? lane_i32(v[0], i) : lane_i32(v[1], i - 64);
+}
+template <int W> __device__ __forceinline__ double node_f64(const double (&v)[W], int i) {
+    if constexpr (W == 1) return lane_f64(v[0], i);
+    else return i < 64 ? lane_f64(v[0], i) : lane_f64(v[1], i - 64);
+}
+template <int W> __device__ __forceinline__ NodeSet<W> node_set(const NodeSet<W> (&v)[W], int i) {
+    NodeSet<W> r;
+    if constexpr (W == 1) r.w[0] = lane_u64(v[0].w[0], i);
+    else MEL_W_FOR(k) r.w[k] = i < 64 ? lane_u64(v[0].w[k], i) : lane_u64(v[1].w[k], i - 64);
+    return r;
+}
+inline int set_words(int n_nodes) { return (n_nodes + 63) >> 6; }
+
 }  // namespace mel

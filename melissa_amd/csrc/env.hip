@@ -2,7 +2,9 @@
 //
 // One wavefront steps one env; lane i is node/agent i (N <= 64); every node set is one 64-bit mask
 // held wave-uniformly, so the reference's Python list/dict walks become popcounts, ballots and a
-// handful of cross-lane reads.  Integer state is bit-exact with the reference; float64 arithmetic
+// handful of cross-lane reads.  Graphs of 65 .. 128 nodes (--n-agents 100, common.py:49) run the same code with
+// W = 2: a lane holds the nodes lane and lane + 64, a node set is two words (NodeSet<W>, common.hpp).
+// Integer state is bit-exact with the reference; float64 arithmetic
 // (positions, rewards, logger stats) is written operation-for-operation like the Python expressions
 // and the library is built with -ffp-contract=off, so it is bit-exact too.
 //
@@ -22,40 +24,41 @@ constexpr int SKIP_NONE = -2;   // _skip_agent_selection is None
 constexpr int MAX_AGENT_STEPS = 4;          // graph.py:332, selector.py:44
 constexpr double R2_F64 = 0.04000000000000001;   // 0.2 ** 2 (nx.geometric_edges, core.py:311)
 
-// every cross-lane read in this file has a wave-uniform source lane (loop counter / selected agent)
-__device__ __forceinline__ double shfl_f64(double v, int src) { return lane_f64(v, src); }
+// every cross-lane read in this file has a wave-uniform source node (loop counter / selected agent)
 __device__ __forceinline__ int wave_sum_i32(int v) { return wave_sum_i32_dpp(v); }
-__device__ __forceinline__ uint64_t bit(int i) { return 1ull << i; }
 
-// Wave-uniform working copy of one env's masks/scalars + this lane's per-node values.
+// Wave-uniform working copy of one env's masks/scalars + this lane's per-node values ([h]: node lane + 64 h).
+template <int W>
 struct Env {
     // uniform
-    uint64_t has_msg, origin_set, interested, scripted, truncated, alive, terminated, agents;
-    uint64_t sel_active, sel_selected, info_valid, taken_action;
+    NodeSet<W> has_msg, origin_set, interested, scripted, truncated, alive, terminated, agents;
+    NodeSet<W> sel_active, sel_selected, info_valid, taken_action;
     int origin, sel, skip, num_moves, world_msgs, new_round, episode, move_cursor, decisions, done_count,
         episodes_done, error, ep_cursor;
     double episode_rewards;
-    // per lane (node)
-    double px, py, reward, pz_reward;
-    uint64_t one_hop, two_hop;
-    int msgs, received, cover;
-    int act, cur_act, steps, sel_steps;
+    // per lane (node lane + 64 h)
+    double px[W], py[W], reward[W], pz_reward[W];
+    NodeSet<W> one_hop[W], two_hop[W];
+    int msgs[W], received[W], cover[W];
+    int act[W], cur_act[W], steps[W], sel_steps[W];
     // not stored: get_info's ten values (graph.py:166-178), lane k holds value k; they only change in World.step / reset, so
     // the AEC sub-steps of a round reuse them (three wave sums and two float64 divisions once instead of per sub-step)
     double info_val;
     int info_valid_cache;
 };
 
-__device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane, Env& s) {
+template <int W>
+__device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane, Env<W>& s) {
     const int n = e.n_nodes;
     // wave-uniform state: forced into SGPRs so mask arithmetic and branches run on the scalar unit
-    const uint64_t* ns = e.node_sets + (size_t)b * 8;
-    s.has_msg = uniform_u64(ns[0]), s.origin_set = uniform_u64(ns[1]), s.interested = uniform_u64(ns[2]);
-    s.scripted = uniform_u64(ns[3]), s.truncated = uniform_u64(ns[4]), s.alive = uniform_u64(ns[5]);
-    s.terminated = uniform_u64(ns[6]), s.agents = uniform_u64(ns[7]);
-    const uint64_t* ss = e.sel_sets + (size_t)b * 4;
-    s.sel_active = uniform_u64(ss[0]), s.sel_selected = uniform_u64(ss[1]);
-    s.info_valid = uniform_u64(ss[2]), s.taken_action = uniform_u64(ss[3]);
+    const uint64_t* ns = e.node_sets + (size_t)b * 8 * W;
+    s.has_msg = ns_uniform(ns_load<W>(ns, 0)), s.origin_set = ns_uniform(ns_load<W>(ns, 1));
+    s.interested = ns_uniform(ns_load<W>(ns, 2)), s.scripted = ns_uniform(ns_load<W>(ns, 3));
+    s.truncated = ns_uniform(ns_load<W>(ns, 4)), s.alive = ns_uniform(ns_load<W>(ns, 5));
+    s.terminated = ns_uniform(ns_load<W>(ns, 6)), s.agents = ns_uniform(ns_load<W>(ns, 7));
+    const uint64_t* ss = e.sel_sets + (size_t)b * 4 * W;
+    s.sel_active = ns_uniform(ns_load<W>(ss, 0)), s.sel_selected = ns_uniform(ns_load<W>(ss, 1));
+    s.info_valid = ns_uniform(ns_load<W>(ss, 2)), s.taken_action = ns_uniform(ns_load<W>(ss, 3));
     const int32_t* sc = e.scalars + (size_t)b * MEL_ENV_SCALARS;
     s.origin = uniform_i32(sc[MEL_S_ORIGIN]), s.sel = uniform_i32(sc[MEL_S_SELECTION]), s.skip = uniform_i32(sc[MEL_S_SKIP]);
     s.num_moves = uniform_i32(sc[MEL_S_NUM_MOVES]), s.world_msgs = uniform_i32(sc[MEL_S_WORLD_MSGS]);
@@ -64,25 +67,30 @@ __device__ __forceinline__ void env_load(const mel_env_batch& e, int b, int lane
     s.done_count = uniform_i32(sc[MEL_S_DONE_COUNT]), s.episodes_done = uniform_i32(sc[MEL_S_EPISODES_DONE]);
     s.error = uniform_i32(sc[MEL_S_ERROR]), s.ep_cursor = uniform_i32(sc[MEL_S_EP_CURSOR]);
     s.episode_rewards = e.episode_rewards[b];
-    const size_t k = (size_t)b * n + lane;
-    const bool on = lane < n;
-    s.px = on ? e.pos[2 * k] : 0.0, s.py = on ? e.pos[2 * k + 1] : 0.0;
-    s.reward = on ? e.rewards[k] : 0.0, s.pz_reward = on ? e.pz_rewards[k] : 0.0;
-    s.one_hop = on ? e.one_hop[k] : 0ull, s.two_hop = on ? e.two_hop[k] : 0ull;
-    s.msgs = on ? e.agent_msgs[k] : 0, s.received = on ? e.received[k] : 0, s.cover = on ? e.two_hop_cover[k] : 0;
-    s.act = on ? e.agent_action[k] : NONE, s.cur_act = on ? e.current_actions[k] : NONE;
-    s.steps = on ? e.steps_taken[k] : 0, s.sel_steps = on ? e.sel_steps[k] : 0;
+    MEL_W_FOR(h) {
+        const size_t k = (size_t)b * n + lane + 64 * h;
+        const bool on = lane + 64 * h < n;
+        s.px[h] = on ? e.pos[2 * k] : 0.0, s.py[h] = on ? e.pos[2 * k + 1] : 0.0;
+        s.reward[h] = on ? e.rewards[k] : 0.0, s.pz_reward[h] = on ? e.pz_rewards[k] : 0.0;
+        s.one_hop[h] = on ? ns_load<W>(e.one_hop, k) : ns_zero<W>(), s.two_hop[h] = on ? ns_load<W>(e.two_hop, k) : ns_zero<W>();
+        s.msgs[h] = on ? e.agent_msgs[k] : 0, s.received[h] = on ? e.received[k] : 0, s.cover[h] = on ? e.two_hop_cover[k] : 0;
+        s.act[h] = on ? e.agent_action[k] : NONE, s.cur_act[h] = on ? e.current_actions[k] : NONE;
+        s.steps[h] = on ? e.steps_taken[k] : 0, s.sel_steps[h] = on ? e.sel_steps[k] : 0;
+    }
     s.info_val = 0.0, s.info_valid_cache = 0;
 }
 
-__device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lane, const Env& s) {
+template <int W>
+__device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lane, const Env<W>& s) {
     const int n = e.n_nodes;
     if (lane == 0) {
-        uint64_t* ns = e.node_sets + (size_t)b * 8;
-        ns[0] = s.has_msg, ns[1] = s.origin_set, ns[2] = s.interested, ns[3] = s.scripted;
-        ns[4] = s.truncated, ns[5] = s.alive, ns[6] = s.terminated, ns[7] = s.agents;
-        uint64_t* ss = e.sel_sets + (size_t)b * 4;
-        ss[0] = s.sel_active, ss[1] = s.sel_selected, ss[2] = s.info_valid, ss[3] = s.taken_action;
+        uint64_t* ns = e.node_sets + (size_t)b * 8 * W;
+        ns_store<W>(ns, 0, s.has_msg), ns_store<W>(ns, 1, s.origin_set), ns_store<W>(ns, 2, s.interested);
+        ns_store<W>(ns, 3, s.scripted), ns_store<W>(ns, 4, s.truncated), ns_store<W>(ns, 5, s.alive);
+        ns_store<W>(ns, 6, s.terminated), ns_store<W>(ns, 7, s.agents);
+        uint64_t* ss = e.sel_sets + (size_t)b * 4 * W;
+        ns_store<W>(ss, 0, s.sel_active), ns_store<W>(ss, 1, s.sel_selected);
+        ns_store<W>(ss, 2, s.info_valid), ns_store<W>(ss, 3, s.taken_action);
         int32_t* sc = e.scalars + (size_t)b * MEL_ENV_SCALARS;
         sc[MEL_S_ORIGIN] = s.origin, sc[MEL_S_SELECTION] = s.sel, sc[MEL_S_SKIP] = s.skip;
         sc[MEL_S_NUM_MOVES] = s.num_moves, sc[MEL_S_WORLD_MSGS] = s.world_msgs, sc[MEL_S_NEW_ROUND] = s.new_round;
@@ -91,66 +99,84 @@ __device__ __forceinline__ void env_store(const mel_env_batch& e, int b, int lan
         sc[MEL_S_EP_CURSOR] = s.ep_cursor;
         e.episode_rewards[b] = s.episode_rewards;
     }
-    if (lane < n) {
-        const size_t k = (size_t)b * n + lane;
-        e.pos[2 * k] = s.px, e.pos[2 * k + 1] = s.py;
-        e.rewards[k] = s.reward, e.pz_rewards[k] = s.pz_reward;
-        e.one_hop[k] = s.one_hop, e.two_hop[k] = s.two_hop;
-        e.agent_msgs[k] = s.msgs, e.received[k] = s.received, e.two_hop_cover[k] = s.cover;
-        e.agent_action[k] = (int8_t)s.act, e.current_actions[k] = (int8_t)s.cur_act;
-        e.steps_taken[k] = (int8_t)s.steps, e.sel_steps[k] = (int8_t)s.sel_steps;
+    MEL_W_FOR(h) {
+        if (lane + 64 * h < n) {
+            const size_t k = (size_t)b * n + lane + 64 * h;
+            e.pos[2 * k] = s.px[h], e.pos[2 * k + 1] = s.py[h];
+            e.rewards[k] = s.reward[h], e.pz_rewards[k] = s.pz_reward[h];
+            ns_store<W>(e.one_hop, k, s.one_hop[h]), ns_store<W>(e.two_hop, k, s.two_hop[h]);
+            e.agent_msgs[k] = s.msgs[h], e.received[k] = s.received[h], e.two_hop_cover[k] = s.cover[h];
+            e.agent_action[k] = (int8_t)s.act[h], e.current_actions[k] = (int8_t)s.cur_act[h];
+            e.steps_taken[k] = (int8_t)s.steps[h], e.sel_steps[k] = (int8_t)s.sel_steps[h];
+        }
     }
 }
 
 // core.py:334-341: one-hop OR neighbours' one-hop, minus self
-__device__ __forceinline__ uint64_t two_hop_of(uint64_t one_hop, int lane, int n) {
+template <int W>
+__device__ __forceinline__ void two_hop_of(const NodeSet<W> (&one_hop)[W], int lane, int n, NodeSet<W> (&two_hop)[W]) {
     // every lane walks ITS OWN neighbours (a handful, not all n nodes) and ORs their rows in, fetched from LDS by a
     // per-lane gather; the wave iterates max-degree times instead of n times with two v_readlane each
-    __shared__ uint64_t rows[4][64];
+    __shared__ uint64_t rows[4][64 * W][W];
     const int w = (threadIdx.x >> 6) & 3;
     (void)n;
-    rows[w][lane] = one_hop;                    // (lanes >= n hold 0)
-    uint64_t m = one_hop, rest = one_hop;
-    while (__ballot(rest != 0ull)) {
-        if (rest) {
-            const int j = __ffsll((long long)rest) - 1;
-            rest &= rest - 1ull;
-            m |= rows[w][j];
+    MEL_W_FOR(h) MEL_W_FOR(k) rows[w][lane + 64 * h][k] = one_hop[h].w[k];          // (nodes >= n hold 0)
+    MEL_W_FOR(h) {
+        NodeSet<W> m = one_hop[h], rest = one_hop[h];
+        while (__ballot(ns_any(rest))) {
+            if (ns_any(rest)) {
+                const int j = ns_lowest(rest);
+                ns_clear_lowest(rest);
+                MEL_W_FOR(k) m.w[k] |= rows[w][j][k];
+            }
         }
+        two_hop[h] = m & ~ns_bit<W>(lane + 64 * h);
     }
-    return m & ~bit(lane);
 }
 
 // nx.geometric_edges (core.py:311): edge iff dx*dx + dy*dy <= 0.2**2 in float64.
 // Node j's position reaches the lanes as an LDS broadcast (every lane reads the same address) instead of four
 // v_readlane into SGPRs: the loop body is then pure VALU on VGPR operands, without the SGPR write -> VALU read wait
 // states that dominated it with one wavefront per SIMD (workgroups of the env kernels are 4 wavefronts).
-__device__ __forceinline__ uint64_t geometric_one_hop(double px, double py, int lane, int n) {
-    __shared__ double sx[4][64], sy[4][64];
+template <int W>
+__device__ __forceinline__ void geometric_one_hop(const double (&px)[W], const double (&py)[W], int lane, int n,
+                                                  NodeSet<W> (&one_hop)[W]) {
+    __shared__ double sx[4][64 * W], sy[4][64 * W];
     const int w = (threadIdx.x >> 6) & 3;
-    sx[w][lane] = px, sy[w][lane] = py;
-    uint64_t m = 0;
+    MEL_W_FOR(h) sx[w][lane + 64 * h] = px[h], sy[w][lane + 64 * h] = py[h];
+    NodeSet<W> m[W];
+    MEL_W_FOR(h) m[h] = ns_zero<W>();
+    MEL_W_FOR(k) {
+        const int cnt = n - 64 * k < 64 ? n - 64 * k : 64;
 #pragma unroll 5
-    for (int j = 0; j < n; ++j) {
-        const double dx = px - sx[w][j], dy = py - sy[w][j];
-        const double d2 = dx * dx + dy * dy;
-        if (d2 <= R2_F64) m |= bit(j);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const double xj = sx[w][64 * k + jj], yj = sy[w][64 * k + jj];
+            MEL_W_FOR(h) {
+                const double dx = px[h] - xj, dy = py[h] - yj;
+                const double d2 = dx * dx + dy * dy;
+                if (d2 <= R2_F64) m[h].w[k] |= 1ull << jj;
+            }
+        }
     }
-    return (lane < n) ? (m & ~bit(lane)) : 0ull;
+    MEL_W_FOR(h) one_hop[h] = (lane + 64 * h < n) ? (m[h] & ~ns_bit<W>(lane + 64 * h)) : ns_zero<W>();
 }
 
 // selector.py:25-34
-__device__ __forceinline__ int selector_next(Env& s, int lane) {
-    const uint64_t cand = s.sel_active & ~s.sel_selected;
-    if (!cand) return NONE;
-    const int i = lowest_bit(cand);
-    if (lane == i) s.sel_steps += 1;
-    s.sel_selected |= bit(i);
+template <int W>
+__device__ __forceinline__ int selector_next(Env<W>& s, int lane) {
+    const NodeSet<W> cand = s.sel_active & ~s.sel_selected;
+    if (!ns_any(cand)) return NONE;
+    const int i = ns_lowest(cand);
+    MEL_W_FOR(h) if (lane + 64 * h == i) s.sel_steps[h] += 1;
+    s.sel_selected |= ns_bit<W>(i);
     return i;
 }
 // selector.py:43-44
-__device__ __forceinline__ void selector_enable(Env& s, uint64_t agents, int lane) {
-    const uint64_t can = __ballot(s.sel_steps < MAX_AGENT_STEPS);
+template <int W>
+__device__ __forceinline__ void selector_enable(Env<W>& s, const NodeSet<W>& agents, int lane) {
+    (void)lane;
+    NodeSet<W> can;
+    MEL_W_FOR(h) can.w[h] = __ballot(s.sel_steps[h] < MAX_AGENT_STEPS);
     s.sel_active = (s.sel_active & ~agents) | (agents & can);
 }
 
@@ -161,7 +187,8 @@ __device__ unsigned long long g_world_prof[4];
 #endif
 
 // World.step core.py:225-266
-__device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env& s,
+template <int W>
+__device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_episode_pool& pool, Env<W>& s,
                                            int lane) {
     const int n = e.n_nodes;
 #ifdef MEL_ENV_PROF
@@ -171,35 +198,39 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
     // :226-234 scripted agents: action = heuristic(agent) (the heuristics offered return no relay mask, so the
     // relays_for pass :236-243 never fires)
     // (no heuristic: Agent.action_callback stays None, World.scripted_agents is empty, nothing is overridden)
-    const bool scripted_lane = e.heuristic != MEL_HEURISTIC_NONE && lane < n && ((s.scripted >> lane) & 1ull);
-    if (scripted_lane) {
-        if (e.heuristic == MEL_HEURISTIC_SIMPLE_BROADCAST) s.act = ((s.taken_action >> lane) & 1ull) ? 0 : 1;
-        // Agent.number_interested_neighbors: counted at reset (core.py:401) but zeroed again by agent.reset() ->
-        // Agent.__init__ (:412-416, :68); only move_graph recomputes it (:286-287), so it is 0 until the episode's
-        // first move and tracks the current graph afterwards (one_hop changes only in moves)
-        else if (e.heuristic == MEL_HEURISTIC_BROADCAST_IF_INTERESTED)
-            s.act = (e.dynamic_graph && s.move_cursor > 0 && (s.one_hop & s.interested)) ? 1 : 0;
-        else s.act = 0;                                          // silent
+    bool scripted_lane[W];
+    MEL_W_FOR(h) {
+        scripted_lane[h] = e.heuristic != MEL_HEURISTIC_NONE && lane + 64 * h < n && ns_mine(s.scripted, lane, h);
+        if (scripted_lane[h]) {
+            if (e.heuristic == MEL_HEURISTIC_SIMPLE_BROADCAST) s.act[h] = ns_mine(s.taken_action, lane, h) ? 0 : 1;
+            // Agent.number_interested_neighbors: counted at reset (core.py:401) but zeroed again by agent.reset() ->
+            // Agent.__init__ (:412-416, :68); only move_graph recomputes it (:286-287), so it is 0 until the episode's
+            // first move and tracks the current graph afterwards (one_hop changes only in moves)
+            else if (e.heuristic == MEL_HEURISTIC_BROADCAST_IF_INTERESTED)
+                s.act[h] = (e.dynamic_graph && s.move_cursor > 0 && ns_any(s.one_hop[h] & s.interested)) ? 1 : 0;
+            else s.act[h] = 0;                                       // silent
+        }
     }
     // :246 the source always transmits on its first opportunity
-    const int origin_msgs = lane_i32(s.msgs, s.origin);
-    if (lane == s.origin && origin_msgs == 0) s.act = 1;
+    const int origin_msgs = node_i32<W>(s.msgs, s.origin);
+    MEL_W_FOR(h) if (lane + 64 * h == s.origin && origin_msgs == 0) s.act[h] = 1;
     // :249-254 relay in id order; has_message is re-read at each agent's turn
-    uint64_t cand = __ballot(lane < n && s.act != NONE && s.act != 0);
-    while (cand) {
-        const int i = lowest_bit(cand);
-        cand &= cand - 1;
-        if ((s.has_msg >> i) & 1ull) {                       // relay_message core.py:268-279
-            const uint64_t nb = lane_u64(s.one_hop, i);
+    NodeSet<W> cand;
+    MEL_W_FOR(h) cand.w[h] = __ballot(lane + 64 * h < n && s.act[h] != NONE && s.act[h] != 0);
+    while (ns_any(cand)) {
+        const int i = ns_lowest(cand);
+        ns_clear_lowest(cand);
+        if (ns_test(s.has_msg, i)) {                         // relay_message core.py:268-279
+            const NodeSet<W> nb = node_set<W>(s.one_hop, i);
             s.world_msgs += 1;
-            if (lane == i) s.msgs += 1;
-            s.taken_action |= bit(i);
-            s.received += (int)((nb >> lane) & 1ull);
+            MEL_W_FOR(h) if (lane + 64 * h == i) s.msgs[h] += 1;
+            s.taken_action |= ns_bit<W>(i);
+            MEL_W_FOR(h) s.received[h] += (int)ns_mine(nb, lane, h);
             s.has_msg |= nb;
         }
     }
 #ifdef MEL_ENV_PROF
-    asm volatile("s_nop 0" ::"s"(s.has_msg), "v"(s.received));
+    asm volatile("s_nop 0" ::"s"(s.has_msg.w[0]), "v"(s.received[0]));
     const unsigned long long wp1 = __builtin_readcyclecounter();
     unsigned long long wp2 = wp1, wp3 = wp1;
 #endif
@@ -210,20 +241,22 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
             mv = pool.max_moves - 1;
             s.error |= MEL_ENV_ERR_MOVES_EXHAUSTED;
         }
-        if (lane < n) {
-            const double* off = pool.moves + ((size_t)s.episode * pool.max_moves + mv) * 2 * n;
-            s.px = s.px + off[lane];
-            s.py = s.py + off[n + lane];
+        const double* off = pool.moves + ((size_t)s.episode * pool.max_moves + mv) * 2 * n;
+        MEL_W_FOR(h) {
+            if (lane + 64 * h < n) {
+                s.px[h] = s.px[h] + off[lane + 64 * h];
+                s.py[h] = s.py[h] + off[n + lane + 64 * h];
+            }
         }
         s.move_cursor += 1;
-        s.one_hop = geometric_one_hop(s.px, s.py, lane, n);
+        geometric_one_hop<W>(s.px, s.py, lane, n, s.one_hop);
 #ifdef MEL_ENV_PROF
-        asm volatile("s_nop 0" ::"v"(s.one_hop));
+        asm volatile("s_nop 0" ::"v"(s.one_hop[0].w[0]));
         wp2 = __builtin_readcyclecounter();
 #endif
-        s.two_hop = two_hop_of(s.one_hop, lane, n);
+        two_hop_of<W>(s.one_hop, lane, n, s.two_hop);
 #ifdef MEL_ENV_PROF
-        asm volatile("s_nop 0" ::"v"(s.two_hop));
+        asm volatile("s_nop 0" ::"v"(s.two_hop[0].w[0]));
         wp3 = __builtin_readcyclecounter();
 #endif
     }
@@ -234,58 +267,71 @@ __device__ __forceinline__ void world_step(const mel_env_batch& e, const mel_epi
     }
 #endif
     // :260-261 -> Agent.update_two_hop_cover_from_one_hopper (core.py:94-102)
-    s.cover = __popcll(s.two_hop & (s.has_msg | s.origin_set));
-    if (scripted_lane) s.act = 0;                                // :264-266
-}
-
-// graph.py:254-271 (copy: optional second destination, the replay's obs_next slot)
-__device__ __forceinline__ void write_obs_matrix(const mel_env_batch& e, int b, const Env& s, int lane,
-                                                 float* copy = nullptr) {
-    if (lane >= e.n_nodes) return;
-    float4* row = reinterpret_cast<float4*>(e.obs_matrix + ((size_t)b * e.n_nodes + lane) * 8);
-    const float act = (s.act != NONE) ? (float)s.act : 0.f;
-    const float interested = ((s.interested >> lane) & 1ull) ? 1.f : 0.f;
-    const float has = (((s.has_msg | s.origin_set) >> lane) & 1ull) ? 1.f : 0.f;
-    const float dm = ((s.scripted >> lane) & 1ull) ? 0.f : 1.f;
-    row[0] = make_float4((float)s.px, (float)s.py, (float)__popcll(s.one_hop), (float)s.msgs);
-    row[1] = make_float4(act, interested, has, dm);
-    if (copy) {
-        float4* c = reinterpret_cast<float4*>(copy + (size_t)lane * 8);
-        c[0] = row[0];
-        c[1] = row[1];
+    MEL_W_FOR(h) {
+        s.cover[h] = ns_count(s.two_hop[h] & (s.has_msg | s.origin_set));
+        if (scripted_lane[h]) s.act[h] = 0;                          // :264-266
     }
 }
 
-// graph.py:402-463, float64, same operation order
-__device__ __forceinline__ double agent_reward(const Env& s) {
-    const uint64_t covered = s.has_msg | s.origin_set;
-    const int total = __popcll(s.two_hop & s.interested);
-    const int cov = __popcll(s.two_hop & s.interested & covered);
+// graph.py:254-271 (copy: optional second destination, the replay's obs_next slot)
+template <int W>
+__device__ __forceinline__ void write_obs_matrix(const mel_env_batch& e, int b, const Env<W>& s, int lane,
+                                                 float* copy = nullptr) {
+    MEL_W_FOR(h) {
+        const int node = lane + 64 * h;
+        if (node >= e.n_nodes) continue;
+        float4* row = reinterpret_cast<float4*>(e.obs_matrix + ((size_t)b * e.n_nodes + node) * 8);
+        const float act = (s.act[h] != NONE) ? (float)s.act[h] : 0.f;
+        const float interested = ns_mine(s.interested, lane, h) ? 1.f : 0.f;
+        const float has = ns_mine(s.has_msg | s.origin_set, lane, h) ? 1.f : 0.f;
+        const float dm = ns_mine(s.scripted, lane, h) ? 0.f : 1.f;
+        row[0] = make_float4((float)s.px[h], (float)s.py[h], (float)ns_count(s.one_hop[h]), (float)s.msgs[h]);
+        row[1] = make_float4(act, interested, has, dm);
+        if (copy) {
+            float4* c = reinterpret_cast<float4*>(copy + (size_t)node * 8);
+            c[0] = row[0];
+            c[1] = row[1];
+        }
+    }
+}
+
+// graph.py:402-463, float64, same operation order (h: the lane's node lane + 64 h)
+template <int W>
+__device__ __forceinline__ double agent_reward(const Env<W>& s, int h) {
+    const NodeSet<W> covered = s.has_msg | s.origin_set;
+    const int total = ns_count(s.two_hop[h] & s.interested);
+    const int cov = ns_count(s.two_hop[h] & s.interested & covered);
     double reward = total > 0 ? (double)cov / (double)total : 0.0;
-    const int deg = __popcll(s.one_hop);
-    if (s.act != NONE && s.act != 0) {
-        const double pen_unint = deg > 0 ? (double)__popcll(s.one_hop & ~s.interested) / (double)deg : 0.0;
-        const double pen_cov = deg > 0 ? (double)__popcll(s.one_hop & s.has_msg) / (double)deg : 0.0;
+    const int deg = ns_count(s.one_hop[h]);
+    if (s.act[h] != NONE && s.act[h] != 0) {
+        const double pen_unint = deg > 0 ? (double)ns_count(s.one_hop[h] & ~s.interested) / (double)deg : 0.0;
+        const double pen_cov = deg > 0 ? (double)ns_count(s.one_hop[h] & s.has_msg) / (double)deg : 0.0;
         const double penalty = pen_unint + pen_cov;
         reward -= penalty;
     } else {
-        const int one_int = __popcll(s.one_hop & s.interested);
-        const int unc = __popcll(s.one_hop & s.interested & ~s.has_msg & ~s.origin_set);
+        const int one_int = ns_count(s.one_hop[h] & s.interested);
+        const int unc = ns_count(s.one_hop[h] & s.interested & ~s.has_msg & ~s.origin_set);
         if (unc > 0) reward -= (double)unc / (double)one_int;
     }
     return reward;
 }
 
 // graph.py:149-179 -> infos[agent]['logger_stats'] (10 float64 in dict order)
-__device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, int agent, Env& s, int lane) {
+template <int W>
+__device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, int agent, Env<W>& s, int lane) {
     const int n = e.n_nodes;
     if (!s.info_valid_cache) {
-        const int sent = wave_sum_i32(lane < n ? s.msgs : 0);
-        const int recv = wave_sum_i32(lane < n ? s.received : 0);
-        const int nbrs = wave_sum_i32(lane < n ? __popcll(s.one_hop) : 0);
-        const int n_int = __popcll(s.interested);
-        const int cov_int = __popcll(s.has_msg & s.interested);
-        const double st1 = (double)__popcll(s.has_msg) / (double)n;
+        int my_sent = 0, my_recv = 0, my_nbrs = 0;
+        MEL_W_FOR(h) {
+            const bool on = lane + 64 * h < n;
+            my_sent += on ? s.msgs[h] : 0, my_recv += on ? s.received[h] : 0, my_nbrs += on ? ns_count(s.one_hop[h]) : 0;
+        }
+        const int sent = wave_sum_i32(my_sent);
+        const int recv = wave_sum_i32(my_recv);
+        const int nbrs = wave_sum_i32(my_nbrs);
+        const int n_int = ns_count(s.interested);
+        const int cov_int = ns_count(s.has_msg & s.interested);
+        const double st1 = (double)ns_count(s.has_msg) / (double)n;
         const double st6 = n_int > 0 ? (double)cov_int / (double)n_int : 0.0;
         double v = (double)s.world_msgs;                                   // lane 0
         v = lane == 1 ? st1 : v;
@@ -295,7 +341,7 @@ __device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, 
         v = lane == 5 ? (double)n_int : v;
         v = lane == 6 ? st6 : v;
         v = lane == 7 ? (double)cov_int : v;
-        v = lane == 8 ? (double)__popcll(s.has_msg & ~s.interested) : v;
+        v = lane == 8 ? (double)ns_count(s.has_msg & ~s.interested) : v;
         v = lane == 9 ? s.episode_rewards : v;
         s.info_val = v;
         s.info_valid_cache = 1;
@@ -304,7 +350,8 @@ __device__ __forceinline__ void write_info_stats(const mel_env_batch& e, int b, 
 }
 
 // one row of the episode log: the logger_stats of the final observation of the episode that just ended
-__device__ __forceinline__ void log_episode(const mel_env_batch& e, int b, const Env& s, int lane) {
+template <int W>
+__device__ __forceinline__ void log_episode(const mel_env_batch& e, int b, const Env<W>& s, int lane) {
     if (e.log_capacity <= 0) return;
     int slot = 0;
     if (lane == 0) slot = atomicAdd(e.log_cursor, 1);
@@ -315,7 +362,7 @@ __device__ __forceinline__ void log_episode(const mel_env_batch& e, int b, const
     // copy of the selected agent's slot, not a recomputation from the current state
     if (lane < MEL_ENV_LOGGER_STATS) {
         const int a = s.sel >= 0 ? s.sel : 0;
-        const bool valid = s.sel >= 0 && ((s.info_valid >> a) & 1ull);
+        const bool valid = s.sel >= 0 && ns_test(s.info_valid, a);
         e.log_stats[(size_t)slot * MEL_ENV_LOGGER_STATS + lane] =
             valid ? e.info_stats[((size_t)b * e.n_nodes + a) * MEL_ENV_LOGGER_STATS + lane] : 0.0;
     }
@@ -327,7 +374,8 @@ __device__ __forceinline__ void log_episode(const mel_env_batch& e, int b, const
 
 // GraphEnv.step graph.py:303-359 (+ the sticky reward copy of [3P] PettingZooEnv.step)
 // returns true when this step completed the round and ran the world step
-__device__ __forceinline__ bool env_step(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
+template <int W>
+__device__ __forceinline__ bool env_step(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env<W>& s,
                                          int action, int lane, float* obs_next_copy = nullptr) {
     const int n = e.n_nodes;
     const int a = s.sel;
@@ -336,121 +384,142 @@ __device__ __forceinline__ bool env_step(const mel_env_batch& e, const mel_episo
         s.error |= 2;
         return false;
     }
-    if ((s.terminated >> a) & 1ull) {                                   // :304-310 dead step
-        s.sel_active &= ~bit(a);
-        s.alive &= ~bit(a);                                             // _was_dead_step :274-301
-        s.terminated &= ~bit(a);
-        s.info_valid &= ~bit(a);
-        s.agents &= ~bit(a);
-        const uint64_t dead = s.agents & s.terminated;
-        if (dead) {
+    if (ns_test(s.terminated, a)) {                                     // :304-310 dead step
+        const NodeSet<W> not_a = ~ns_bit<W>(a);
+        s.sel_active &= not_a;
+        s.alive &= not_a;                                               // _was_dead_step :274-301
+        s.terminated &= not_a;
+        s.info_valid &= not_a;
+        s.agents &= not_a;
+        const NodeSet<W> dead = s.agents & s.terminated;
+        if (ns_any(dead)) {
             if (s.skip == SKIP_NONE) s.skip = a;
-            s.sel = lowest_bit(dead);
+            s.sel = ns_lowest(dead);
         } else {
             if (s.skip != SKIP_NONE) s.sel = s.skip;
             s.skip = SKIP_NONE;
         }
     } else {
         s.decisions += 1;
-        if (lane == a) {
-            s.cur_act = action;                                         // :314
-            s.steps += 1;                                               // :316-318
+        MEL_W_FOR(h) {
+            if (lane + 64 * h == a) {
+                s.cur_act[h] = action;                                  // :314
+                s.steps[h] += 1;                                        // :316-318
+            }
         }
         s.sel = selector_next(s, lane);                                 // :321
         if (s.sel == NONE) {                                            // :324 round complete
             world = true;
-            if ((s.alive >> lane) & 1ull) s.reward = 0.0;               // _clear_rewards
-            s.act = s.cur_act;                                          // :362-365
+            MEL_W_FOR(h) {
+                if (ns_mine(s.alive, lane, h)) s.reward[h] = 0.0;       // _clear_rewards
+                s.act[h] = s.cur_act[h];                                // :362-365
+            }
             world_step(e, pool, s, lane);
             write_obs_matrix(e, b, s, lane, obs_next_copy);             // :370-371
-            const double r0 = agent_reward(s);
-            double r = r0;
-            if (e.has_local_ratio) r = 0.0 * (1.0 - e.local_ratio) + r0 * e.local_ratio;   // :380-384
-            if ((s.agents >> lane) & 1ull) s.reward = r;                // :386
-            uint64_t rest = s.agents;                                   // :387 summed in id order
-            while (rest) {
-                const int i = lowest_bit(rest);
-                rest &= rest - 1;
-                s.episode_rewards += shfl_f64(r, i);
+            double r[W];
+            MEL_W_FOR(h) {
+                const double r0 = agent_reward(s, h);
+                r[h] = r0;
+                if (e.has_local_ratio) r[h] = 0.0 * (1.0 - e.local_ratio) + r0 * e.local_ratio;   // :380-384
+                if (ns_mine(s.agents, lane, h)) s.reward[h] = r[h];     // :386
+            }
+            NodeSet<W> rest = s.agents;                                 // :387 summed in id order
+            while (ns_any(rest)) {
+                const int i = ns_lowest(rest);
+                ns_clear_lowest(rest);
+                s.episode_rewards += node_f64<W>(r, i);
             }
             s.num_moves += 1;                                           // :328
-            const uint64_t expire = __ballot(lane < n && s.steps >= MAX_AGENT_STEPS) & s.agents & ~s.truncated;
+            NodeSet<W> expire;
+            MEL_W_FOR(h) expire.w[h] = __ballot(lane + 64 * h < n && s.steps[h] >= MAX_AGENT_STEPS);
+            expire = expire & s.agents & ~s.truncated;
             s.truncated |= expire;                                      // :330-334
             s.terminated |= expire;
-            s.agents = s.has_msg & s.alive & (e.is_testing ? ~0ull : ~s.scripted);   // :336-341
+            s.agents = s.has_msg & s.alive;                             // :336-341
+            if (!e.is_testing) s.agents &= ~s.scripted;
             selector_enable(s, s.agents, lane);                         // :342
-            s.sel_selected = 0;                                         // :343
+            s.sel_selected = ns_zero<W>();                              // :343
             s.new_round = 1;                                            // :344
             s.sel = selector_next(s, lane);                             // :345
-            s.cur_act = NONE;                                           // :347
+            MEL_W_FOR(h) s.cur_act[h] = NONE;                           // :347
         }
         if (s.sel != NONE) {                                            // :358
             write_info_stats(e, b, s.sel, s, lane);
-            s.info_valid |= bit(s.sel);
+            s.info_valid |= ns_bit<W>(s.sel);
         }
-        const uint64_t dead = s.agents & s.terminated;                  // :359 _deads_step_first
-        if (dead) {
+        const NodeSet<W> dead = s.agents & s.terminated;                // :359 _deads_step_first
+        if (ns_any(dead)) {
             s.skip = s.sel;
-            s.sel = lowest_bit(dead);
+            s.sel = ns_lowest(dead);
         }
     }
-    if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;               // PettingZooEnv.step (A.6)
+    MEL_W_FOR(h) if (ns_mine(s.alive, lane, h)) s.pz_reward[h] = s.reward[h];   // PettingZooEnv.step (A.6)
     return world;
 }
 
 // GraphEnv.reset + World.reset, graph.py:222-248 / core.py:343-437, from a pre-sampled pool episode
-__device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env& s,
+template <int W>
+__device__ __forceinline__ void env_reset(const mel_env_batch& e, const mel_episode_pool& pool, int b, Env<W>& s,
                                           int episode, int keep_graph, int lane) {
     const int n = e.n_nodes;
-    const uint64_t full = (n == 64) ? ~0ull : (bit(n) - 1ull);
+    const NodeSet<W> full = ns_full<W>(n);
     s.episode = episode;
     s.move_cursor = 0;
     if (!keep_graph) {
-        const size_t k = (size_t)episode * n + lane;
-        s.px = lane < n ? pool.pos[2 * k] : 0.0;
-        s.py = lane < n ? pool.pos[2 * k + 1] : 0.0;
-        s.one_hop = lane < n ? pool.one_hop[k] : 0ull;
+        MEL_W_FOR(h) {
+            const size_t k = (size_t)episode * n + lane + 64 * h;
+            const bool on = lane + 64 * h < n;
+            s.px[h] = on ? pool.pos[2 * k] : 0.0;
+            s.py[h] = on ? pool.pos[2 * k + 1] : 0.0;
+            s.one_hop[h] = on ? ns_load<W>(pool.one_hop, k) : ns_zero<W>();
+        }
     }
-    s.two_hop = two_hop_of(s.one_hop, lane, n);                         // core.py:421
+    two_hop_of<W>(s.one_hop, lane, n, s.two_hop);                       // core.py:421
     s.origin = uniform_i32(pool.origin[episode]);
-    s.interested = uniform_u64(pool.interested[episode]) & full;
-    s.scripted = pool.scripted ? (uniform_u64(pool.scripted[episode]) & full) : 0ull;   // core.py:395,404
+    s.interested = ns_uniform(ns_load<W>(pool.interested, episode)) & full;
+    s.scripted = pool.scripted ? (ns_uniform(ns_load<W>(pool.scripted, episode)) & full) : ns_zero<W>();   // core.py:395,404
     s.world_msgs = 0;
-    s.has_msg = bit(s.origin);                                          // :432-434
-    s.origin_set = bit(s.origin);
-    s.taken_action = 0;
-    s.truncated = 0;
-    s.msgs = 0, s.received = 0, s.cover = 0;
-    s.act = NONE;
-    s.steps = (lane == s.origin) ? 1 : 0;                               // :424,435
+    s.has_msg = ns_bit<W>(s.origin);                                    // :432-434
+    s.origin_set = ns_bit<W>(s.origin);
+    s.taken_action = ns_zero<W>();
+    s.truncated = ns_zero<W>();
+    MEL_W_FOR(h) {
+        s.msgs[h] = 0, s.received[h] = 0, s.cover[h] = 0;
+        s.act[h] = NONE;
+        s.steps[h] = (lane + 64 * h == s.origin) ? 1 : 0;               // :424,435
+    }
     world_step(e, pool, s, lane);                                       // :437
     // GraphEnv.reset
-    s.sel_steps = (lane == s.origin) ? 1 : 0;                           // selector.reinit + enable(on_reset)
-    s.sel_active = 0, s.sel_selected = 0;
-    s.reward = 0.0;
-    s.alive = full, s.terminated = 0, s.info_valid = 0;
+    MEL_W_FOR(h) {
+        s.sel_steps[h] = (lane + 64 * h == s.origin) ? 1 : 0;           // selector.reinit + enable(on_reset)
+        s.reward[h] = 0.0;
+    }
+    s.sel_active = ns_zero<W>(), s.sel_selected = ns_zero<W>();
+    s.alive = full, s.terminated = ns_zero<W>(), s.info_valid = ns_zero<W>();
     s.num_moves = 0;
     s.episode_rewards = 0.0;
     s.done_count = 0;
     write_obs_matrix(e, b, s, lane);
-    s.agents = s.has_msg & (e.is_testing ? ~0ull : ~s.scripted);        // :242-245
+    s.agents = s.has_msg;                                               // :242-245
+    if (!e.is_testing) s.agents &= ~s.scripted;
     selector_enable(s, s.agents, lane);
     s.sel = selector_next(s, lane);                                     // :247
     s.skip = SKIP_NONE;
-    s.cur_act = NONE;                                                   // :248
+    MEL_W_FOR(h) s.cur_act[h] = NONE;                                   // :248
     s.ep_cursor += 1;
 }
 
 // GraphEnv.observe / last() graph.py:181-216 + PettingZooEnv packing; returns bit0 terminated,
 // bit1 explicit_reset, bit2 environment_step
-__device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s, const mel_env_obs& o,
+template <int W>
+__device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env<W>& s, const mel_env_obs& o,
                                            int64_t row, int lane) {
     const int n = e.n_nodes;
     const int a = s.sel;
     const int valid = a >= 0;
-    const int dead = valid ? (int)((s.terminated >> a) & 1ull) : 0;
+    const int dead = valid ? (int)ns_test(s.terminated, a) : 0;
     int explicit_reset = 0, environment_step = 0;
-    if (__popcll(s.agents) == 1 && (s.agents & ~s.terminated) == 0) {   // :205-207
+    if (ns_count(s.agents) == 1 && !ns_any(s.agents & ~s.terminated)) {   // :205-207
         s.new_round = 0;
         explicit_reset = 1;
     }
@@ -464,13 +533,13 @@ __device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s
         for (int c = lane; c < n * 8; c += 64) dst[c] = src[c];
         if (lane == 0) dst[n * 8] = (float)a;
     }
-    if (o.rew && lane < n) o.rew[row * n + lane] = s.pz_reward;
+    if (o.rew) MEL_W_FOR(h) if (lane + 64 * h < n) o.rew[row * n + lane + 64 * h] = s.pz_reward[h];
     if (o.stats && lane < MEL_ENV_LOGGER_STATS) {
-        const int ok = valid && ((s.info_valid >> a) & 1ull);
+        const int ok = valid && ns_test(s.info_valid, a);
         o.stats[row * MEL_ENV_LOGGER_STATS + lane] =
             ok ? e.info_stats[((size_t)b * n + a) * MEL_ENV_LOGGER_STATS + lane] : 0.0;
     }
-    const uint64_t nb = lane_u64(s.one_hop, valid ? a : 0);
+    const NodeSet<W> nb = node_set<W>(s.one_hop, valid ? a : 0);
     if (lane == 0) {
         if (o.agent_id) o.agent_id[row] = a;
         if (o.action_mask) o.action_mask[2 * row] = o.action_mask[2 * row + 1] = dead ? 0 : 1;   // :190-192
@@ -479,9 +548,9 @@ __device__ __forceinline__ int env_observe(const mel_env_batch& e, int b, Env& s
             o.flags[4 * row + 0] = s.num_moves;
             o.flags[4 * row + 1] = environment_step;
             o.flags[4 * row + 2] = explicit_reset;
-            o.flags[4 * row + 3] = valid ? (int)((s.info_valid >> a) & 1ull) : 0;
+            o.flags[4 * row + 3] = valid ? (int)ns_test(s.info_valid, a) : 0;
         }
-        if (o.active_nb) o.active_nb[row] = valid ? (nb & ~(s.truncated & ~s.agents)) : 0ull;   // :198-203
+        if (o.active_nb) ns_store<W>(o.active_nb, row, valid ? (nb & ~(s.truncated & ~s.agents)) : ns_zero<W>());   // :198-203
     }
     return dead | (explicit_reset << 1) | (environment_step << 2);
 }
@@ -495,7 +564,7 @@ struct RoundArgs {
     mel_episode_pool pool;
     const int32_t* actions;        // [rows] one action per (env, active agent), rows ordered by env, agent id
     const int32_t* row_offsets;    // [B+1] first row of each env (as mel_ldgn_forward_agents wrote them)
-    uint64_t* live;                // [B] in: the active set the actions were computed for; out: next round's
+    uint64_t* live;                // [B] node sets; in: the active set the actions were computed for; out: next round's
     const int32_t* episode_table;
     int table_stride;
     int first;                     // 1: only publish the active set (no step) - used right after a reset
@@ -507,13 +576,14 @@ struct RoundArgs {
 
 // GraphEnv.reset from a snapshot: the state env_reset would compute for this episode was computed once when the pool was
 // loaded (same kernel, same settings); what a reset does NOT touch is carried over from the live env.
-__device__ __forceinline__ void env_reset_from_snapshot(const mel_env_batch& e, const mel_env_batch& snap, int b, Env& s,
+template <int W>
+__device__ __forceinline__ void env_reset_from_snapshot(const mel_env_batch& e, const mel_env_batch& snap, int b, Env<W>& s,
                                                         int episode, int lane) {
-    Env t;
+    Env<W> t;
     env_load(snap, episode, lane, t);
     t.new_round = s.new_round, t.decisions = s.decisions, t.episodes_done = s.episodes_done;
     t.error = s.error | t.error, t.ep_cursor = s.ep_cursor + 1;
-    t.pz_reward = s.pz_reward;                 // the sticky Tianshou reward vector survives a reset
+    MEL_W_FOR(h) t.pz_reward[h] = s.pz_reward[h];          // the sticky Tianshou reward vector survives a reset
     s = t;
     write_obs_matrix(e, b, s, lane);
 }
@@ -527,13 +597,14 @@ __device__ unsigned long long g_env_prof[9];
 #define ENV_MARK(x) asm volatile("s_nop 0" ::"s"(x))
 #endif
 
+template <int W>
 __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= a.env.n_envs) return;
     const int lane = lane_id();
     const int n = a.env.n_nodes;
     if (a.round_counter && b == 0 && lane == 0 && !a.first) atomicAdd(a.round_counter, 1u);
-    Env s;
+    Env<W> s;
 #ifdef MEL_ENV_PROF
     unsigned long long pw = 0, ps = 0, po = 0, pr = 0, pit = 0;
     const unsigned long long p0 = ENV_T();
@@ -541,30 +612,33 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     env_load(a.env, b, lane, s);
 #ifdef MEL_ENV_PROF
     ENV_MARK(s.sel);
-    asm volatile("s_nop 0" ::"v"(s.px), "v"(s.steps));
+    asm volatile("s_nop 0" ::"v"(s.px[0]), "v"(s.steps[0]));
     const unsigned long long p1 = ENV_T();
 #endif
     const mel_env_obs none{};
     if (!a.first) {
-        const uint64_t live_in = uniform_u64(a.live[b]);
+        const NodeSet<W> live_in = ns_uniform(ns_load<W>(a.live, b));
         // every agent's action in one coalesced load (lane = agent), read back with v_readlane; actions are
         // either packed rows (row_offsets) or the dense [B, N] layout
-        int my_action = 0;
-        if ((live_in >> lane) & 1ull)
-            my_action = a.row_offsets ? a.actions[uniform_i32(a.row_offsets[b]) + rank_below(live_in, lane)]
-                                      : a.actions[(size_t)b * n + lane];
+        int my_action[W];
+        MEL_W_FOR(h) {
+            my_action[h] = 0;
+            if (ns_mine(live_in, lane, h))
+                my_action[h] = a.row_offsets ? a.actions[uniform_i32(a.row_offsets[b]) + ns_rank_below(live_in, lane + 64 * h)]
+                                             : a.actions[(size_t)b * n + lane + 64 * h];
+        }
         // replay record of this round (only envs with acting agents): pre-state now, outcome after the world step
         float* rec_next = nullptr;
         size_t rec = 0;
-        if (a.replay.capacity > 0 && live_in) {
+        if (a.replay.capacity > 0 && ns_any(live_in)) {
             const int cur = uniform_i32(a.replay.cursor[b]);
             rec = (size_t)b * a.replay.capacity + (cur % a.replay.capacity);
             const float* src = a.env.obs_matrix + (size_t)b * n * 8;
             float* dst = a.replay.obs + rec * n * 8;
             for (int c = lane; c < n * 8; c += 64) dst[c] = src[c];
-            if (lane < n) a.replay.act[rec * n + lane] = (int8_t)my_action;
+            MEL_W_FOR(h) if (lane + 64 * h < n) a.replay.act[rec * n + lane + 64 * h] = (int8_t)my_action[h];
             if (lane == 0) {
-                a.replay.acted[rec] = live_in;
+                ns_store<W>(a.replay.acted, rec, live_in);
                 a.replay.episode[rec] = s.ep_cursor;
                 a.replay.cursor[b] = cur + 1;
             }
@@ -577,14 +651,15 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
         //     go unless the episode could end inside the sequence (every active agent dead, or the done count reaching n):
         //     those rare rounds take the sequential path.
         {
-            const uint64_t dead = s.agents & s.terminated;
-            if (dead && s.skip >= 0 && s.sel == lowest_bit(dead) && (s.agents & ~dead) != 0ull &&
-                s.done_count + __popcll(dead) - 1 < n && s.error == 0) {
-                s.sel_active &= ~dead, s.alive &= ~dead, s.terminated &= ~dead, s.info_valid &= ~dead, s.agents &= ~dead;
-                s.done_count += __popcll(dead) - 1;
+            const NodeSet<W> dead = s.agents & s.terminated;
+            if (ns_any(dead) && s.skip >= 0 && s.sel == ns_lowest(dead) && ns_any(s.agents & ~dead) &&
+                s.done_count + ns_count(dead) - 1 < n && s.error == 0) {
+                const NodeSet<W> keep = ~dead;
+                s.sel_active &= keep, s.alive &= keep, s.terminated &= keep, s.info_valid &= keep, s.agents &= keep;
+                s.done_count += ns_count(dead) - 1;
                 s.sel = s.skip;
                 s.skip = SKIP_NONE;
-                if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;   // PettingZooEnv.step (A.6), idempotent
+                MEL_W_FOR(h) if (ns_mine(s.alive, lane, h)) s.pz_reward[h] = s.reward[h];   // PettingZooEnv.step (A.6), idempotent
             }
         }
         // (2) No pending dead agent, the selection is the first active agent and the forward covered exactly the active
@@ -592,28 +667,30 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
         //     count, the selector's marks, the stored info of the next selection (the same ten values: nothing moves
         //     before the world step) - so they are applied in one go (graph.py:312-321,358, k - 1 times); the last agent
         //     takes the sequential path below, which runs the world step.
-        if (s.skip == SKIP_NONE && (s.agents & s.terminated) == 0ull && live_in != 0ull && live_in == s.sel_active &&
-            (live_in & ~s.agents) == 0ull && s.sel >= 0 && s.sel == lowest_bit(live_in) && s.sel_selected == bit(s.sel) &&
+        if (s.skip == SKIP_NONE && !ns_any(s.agents & s.terminated) && ns_any(live_in) && live_in == s.sel_active &&
+            !ns_any(live_in & ~s.agents) && s.sel >= 0 && s.sel == ns_lowest(live_in) && s.sel_selected == ns_bit<W>(s.sel) &&
             s.error == 0) {
-            const int last = 63 - __clzll((long long)live_in);
-            const uint64_t early = live_in & ~bit(last);             // agents whose sub-step is fast-forwarded
-            if (early) {
-                s.decisions += __popcll(early);
-                if ((early >> lane) & 1ull) {                        // :314-318
-                    s.cur_act = my_action;
-                    s.steps += 1;
+            const int last = ns_highest(live_in);
+            const NodeSet<W> early = live_in & ~ns_bit<W>(last);     // agents whose sub-step is fast-forwarded
+            if (ns_any(early)) {
+                s.decisions += ns_count(early);
+                const NodeSet<W> later = live_in & ~ns_bit<W>(s.sel);    // every agent that becomes the selection: a_2 .. a_k
+                MEL_W_FOR(h) {
+                    if (ns_mine(early, lane, h)) {                   // :314-318
+                        s.cur_act[h] = my_action[h];
+                        s.steps[h] += 1;
+                    }
+                    if (ns_mine(later, lane, h)) s.sel_steps[h] += 1;    // selector.py:25-34
                 }
-                const uint64_t later = live_in & ~bit(s.sel);        // every agent that becomes the selection: a_2 .. a_k
-                if ((later >> lane) & 1ull) s.sel_steps += 1;       // selector.py:25-34
                 s.sel_selected = live_in;
-                uint64_t rest = later;                               // :358 infos[next] = get_info()
-                while (rest) {
-                    const int nxt = lowest_bit(rest);
-                    rest &= rest - 1ull;
+                NodeSet<W> rest = later;                             // :358 infos[next] = get_info()
+                while (ns_any(rest)) {
+                    const int nxt = ns_lowest(rest);
+                    ns_clear_lowest(rest);
                     write_info_stats(a.env, b, nxt, s, lane);
                 }
                 s.info_valid |= later;
-                if ((s.alive >> lane) & 1ull) s.pz_reward = s.reward;
+                MEL_W_FOR(h) if (ns_mine(s.alive, lane, h)) s.pz_reward[h] = s.reward[h];
                 s.new_round = 0;                                     // the first observe of the round (:209-211)
                 s.sel = last;
             }
@@ -625,12 +702,12 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
                 break;
             }
             int action = 0;
-            if (!((s.terminated >> sel) & 1ull)) {
-                if (!((live_in >> sel) & 1ull)) {          // an agent acts that the forward did not cover
+            if (!ns_test(s.terminated, sel)) {
+                if (!ns_test(live_in, sel)) {              // an agent acts that the forward did not cover
                     s.error |= 4;
                     break;
                 }
-                action = lane_i32(my_action, sel);
+                action = node_i32<W>(my_action, sel);
             }
 #ifdef MEL_ENV_PROF
             const unsigned long long q0 = ENV_T();
@@ -638,7 +715,7 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
             const bool world = env_step(a.env, a.pool, b, s, action, lane, rec_next);
 #ifdef MEL_ENV_PROF
             ENV_MARK(s.sel);
-            asm volatile("s_nop 0" ::"v"(s.reward), "v"(s.one_hop));
+            asm volatile("s_nop 0" ::"v"(s.reward[0]), "v"(s.one_hop[0].w[0]));
             const unsigned long long q1 = ENV_T();
 #endif
             const int r = env_observe(a.env, b, s, none, 0, lane);
@@ -648,8 +725,9 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
             (world ? pw : ps) += q1 - q0, po += q2 - q1, pit += 1;
 #endif
             if (world && rec_next) {          // the world step just ran: rewards / terminations of this round
-                if (lane < n) a.replay.rew[rec * n + lane] = ((live_in >> lane) & 1ull) ? (float)s.reward : 0.f;
-                if (lane == 0) a.replay.done[rec] = s.terminated & live_in;
+                MEL_W_FOR(h) if (lane + 64 * h < n)
+                    a.replay.rew[rec * n + lane + 64 * h] = ns_mine(live_in, lane, h) ? (float)s.reward[h] : 0.f;
+                if (lane == 0) ns_store<W>(a.replay.done, rec, s.terminated & live_in);
             }
             if (r & 1) s.done_count += 1;
             if ((r & 1) && ((r & 2) || s.done_count == n)) {                  // episode over
@@ -665,7 +743,7 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
                 env_observe(a.env, b, s, none, 0, lane);
 #ifdef MEL_ENV_PROF
                 ENV_MARK(s.sel);
-                asm volatile("s_nop 0" ::"v"(s.px), "v"(s.one_hop));
+                asm volatile("s_nop 0" ::"v"(s.px[0]), "v"(s.one_hop[0].w[0]));
                 pr += ENV_T() - r0;
 #endif
                 break;
@@ -677,15 +755,15 @@ __global__ __launch_bounds__(256) void env_round_kernel(RoundArgs a) {
     const unsigned long long p2 = ENV_T();
 #endif
     // agents that will act in the coming round: exactly the selector's active set (selector.py:22-34,43-44)
-    if (lane == 0) a.live[b] = s.sel_active;
+    if (lane == 0) ns_store<W>(a.live, b, s.sel_active);
     env_store(a.env, b, lane, s);
     // optional plan sink: what the next forward's plan_masks launch would compute from the obs this launch wrote (the
     // obs positions are (float)px, (float)py: write_obs_matrix) and the active set it just published
     if (a.env.plan_adj) {
-        const uint64_t full = (n == 64) ? ~0ull : (bit(n) - 1ull);
-        const float x = lane < n ? (float)s.px : 0.f, y = lane < n ? (float)s.py : 0.f;
-        plan_masks_env(x, y, s.sel_active & full, a.env.plan_u1 ? 1 : -1, b, a.env.n_envs, n, lane,
-                       PlanSink{a.env.plan_adj, a.env.plan_live, a.env.plan_u1, a.env.plan_u2, a.env.plan_cnt});
+        float x[W], y[W];
+        MEL_W_FOR(h) x[h] = lane + 64 * h < n ? (float)s.px[h] : 0.f, y[h] = lane + 64 * h < n ? (float)s.py[h] : 0.f;
+        plan_masks_env<W>(x, y, s.sel_active & ns_full<W>(n), a.env.plan_u1 ? 1 : -1, b, a.env.n_envs, n, lane,
+                          PlanSink{a.env.plan_adj, a.env.plan_live, a.env.plan_u1, a.env.plan_u2, a.env.plan_cnt});
     }
 #ifdef MEL_ENV_PROF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -714,13 +792,13 @@ struct StepArgs {
 
 enum { OP_RESET = 0, OP_STEP = 1, OP_OBSERVE = 2 };
 
-template <int OP>
+template <int OP, int W>
 __global__ __launch_bounds__(256) void env_kernel(StepArgs a) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.n) return;
     const int lane = lane_id();
     const int b = a.env_ids ? a.env_ids[row] : (int)row;
-    Env s;
+    Env<W> s;
     env_load(a.env, b, lane, s);
     if (OP == OP_RESET) {
         env_reset(a.env, a.pool, b, s, a.episode_ids[row], a.keep_graph, lane);
@@ -750,7 +828,7 @@ __global__ __launch_bounds__(256) void env_kernel(StepArgs a) {
 
 static mel_status check_env(const mel_env_batch* env, int64_t n) {
     if (!env) return fail(MEL_ERR_INVALID_ARG, "env batch is null");
-    if (env->n_nodes < 1 || env->n_nodes > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, 64]", env->n_nodes);
+    if (env->n_nodes < 1 || env->n_nodes > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, %d]", env->n_nodes, MEL_MAX_NODES);
     if (n < 0 || n > env->n_envs) return fail(MEL_ERR_INVALID_ARG, "n=%ld outside [0, n_envs=%d]", (long)n, env->n_envs);
     if (!env->pos || !env->scalars) return fail(MEL_ERR_INVALID_ARG, "env batch is not bound (mel_env_bind)");
     if (env->log_capacity < 0 || (env->log_capacity > 0 && (!env->log_cursor || !env->log_stats || !env->log_meta)))
@@ -775,12 +853,13 @@ static EnvLayout carve_env(int32_t B, int32_t n, void* state) {
     EnvLayout L{};
     Carver c(state);
     const size_t BN = (size_t)B * n;
+    const size_t SW = (size_t)set_words(n);            // words per node set
     L.e.n_envs = B, L.e.n_nodes = n;
     L.e.pos = c.take<double>(BN * 2);
-    L.e.one_hop = c.take<uint64_t>(BN);
-    L.e.two_hop = c.take<uint64_t>(BN);
-    L.e.node_sets = c.take<uint64_t>((size_t)B * 8);
-    L.e.sel_sets = c.take<uint64_t>((size_t)B * 4);
+    L.e.one_hop = c.take<uint64_t>(BN * SW);
+    L.e.two_hop = c.take<uint64_t>(BN * SW);
+    L.e.node_sets = c.take<uint64_t>((size_t)B * 8 * SW);
+    L.e.sel_sets = c.take<uint64_t>((size_t)B * 4 * SW);
     L.e.scalars = c.take<int32_t>((size_t)B * MEL_ENV_SCALARS);
     L.e.agent_msgs = c.take<int32_t>(BN);
     L.e.received = c.take<int32_t>(BN);
@@ -842,7 +921,8 @@ mel_status mel_env_reset(mel_env_batch* env, const mel_episode_pool* pool, const
     a.env = *env, a.pool = *pool, a.env_ids = env_ids, a.episode_ids = episode_ids, a.n = n, a.keep_graph = keep_graph;
     if (out) a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_RESET, static_cast<hipStream_t>(stream));
-    MEL_LAUNCH(env_kernel<OP_RESET>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (env->n_nodes > 64) MEL_LAUNCH((env_kernel<OP_RESET, 2>), dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else MEL_LAUNCH((env_kernel<OP_RESET, 1>), dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_reset");
 }
 
@@ -860,7 +940,8 @@ mel_status mel_env_step(mel_env_batch* env, const mel_episode_pool* pool, const 
     a.episode_table = episode_table, a.table_stride = table_stride;
     if (out) a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
-    MEL_LAUNCH(env_kernel<OP_STEP>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (env->n_nodes > 64) MEL_LAUNCH((env_kernel<OP_STEP, 2>), dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else MEL_LAUNCH((env_kernel<OP_STEP, 1>), dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_step");
 }
 
@@ -894,7 +975,8 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
         a.replay = *replay;
     }
     StageScope t(MEL_STAGE_ENV_STEP, static_cast<hipStream_t>(stream));
-    MEL_LAUNCH(env_round_kernel, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (env->n_nodes > 64) MEL_LAUNCH(env_round_kernel<2>, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else MEL_LAUNCH(env_round_kernel<1>, dim3((env->n_envs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_round");
 }
 
@@ -939,7 +1021,8 @@ mel_status mel_env_observe(mel_env_batch* env, const int32_t* env_ids, int64_t n
     StepArgs a{};
     a.env = *env, a.env_ids = env_ids, a.n = n, a.out = *out, a.has_out = 1;
     StageScope t(MEL_STAGE_ENV_OBSERVE, static_cast<hipStream_t>(stream));
-    MEL_LAUNCH(env_kernel<OP_OBSERVE>, dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (env->n_nodes > 64) MEL_LAUNCH((env_kernel<OP_OBSERVE, 2>), dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    else MEL_LAUNCH((env_kernel<OP_OBSERVE, 1>), dim3((n + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("env_observe");
 }
 

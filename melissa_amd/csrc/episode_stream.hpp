@@ -213,6 +213,7 @@ __device__ __forceinline__ uint32_t mt_masked(Mt& m, uint32_t rng, int lane) {
 }
 
 // One wavefront (a 64-thread workgroup) per new episode.
+template <int W>
 __global__ __launch_bounds__(64) void episode_fill_kernel(StreamArgs a) {
     __shared__ uint32_t key[624];
     const int lane = threadIdx.x;
@@ -233,27 +234,34 @@ __global__ __launch_bounds__(64) void episode_fill_kernel(StreamArgs a) {
             density = 0.1 + range * mt_double(d0, d1);
         }
         const int k_int = (int)(density * (double)n);                                               // :392
-        // permutation(n)[:k] (:393): lane i holds arr[i]; swap(i, j) for i = n-1 .. 1, j = random_interval(i)
-        int arr = lane;
+        // permutation(n)[:k] (:393): the lane of node i holds arr[i]; swap(i, j) for i = n-1 .. 1, j = random_interval(i)
+        int arr[W];
+        MEL_W_FOR(h) arr[h] = lane + 64 * h;
         for (int i = n - 1; i >= 1; --i) {
             const int j = (int)mt_masked(m, (uint32_t)i, lane);
-            const int vi = __builtin_amdgcn_readlane(arr, i), vj = __builtin_amdgcn_readlane(arr, j);
-            if (lane == i) arr = vj;
-            if (lane == j) arr = vi;
+            const int vi = node_i32<W>(arr, i), vj = node_i32<W>(arr, j);
+            MEL_W_FOR(h) {
+                if (lane + 64 * h == i) arr[h] = vj;
+                if (lane + 64 * h == j) arr[h] = vi;
+            }
         }
-        const uint64_t interested = wave_or_u64(lane < k_int ? bit(arr) : 0ull);
+        NodeSet<W> mine = ns_zero<W>();
+        MEL_W_FOR(h) if (lane + 64 * h < k_int) mine |= ns_bit<W>(arr[h]);
+        const NodeSet<W> interested = ns_wave_or(mine);
         // ---- the pool slot
         const int g = a.st.draw_graph[slot];
-        if (lane < n) {
-            const size_t src = (size_t)g * n + lane, dst = (size_t)slot * n + lane;
-            const_cast<double*>(a.pool.pos)[2 * dst] = a.graphs.pos[2 * src];
-            const_cast<double*>(a.pool.pos)[2 * dst + 1] = a.graphs.pos[2 * src + 1];
-            const_cast<uint64_t*>(a.pool.one_hop)[dst] = a.graphs.one_hop[src];
+        MEL_W_FOR(h) {
+            if (lane + 64 * h < n) {
+                const size_t src = (size_t)g * n + lane + 64 * h, dst = (size_t)slot * n + lane + 64 * h;
+                const_cast<double*>(a.pool.pos)[2 * dst] = a.graphs.pos[2 * src];
+                const_cast<double*>(a.pool.pos)[2 * dst + 1] = a.graphs.pos[2 * src + 1];
+                ns_store<W>(const_cast<uint64_t*>(a.pool.one_hop), dst, ns_load<W>(a.graphs.one_hop, src));
+            }
         }
         if (lane == 0) {
             const_cast<int32_t*>(a.pool.origin)[slot] = origin;
-            const_cast<uint64_t*>(a.pool.interested)[slot] = interested;
-            if (a.pool.scripted) const_cast<uint64_t*>(a.pool.scripted)[slot] = 0ull;      // scripted_agents_ratio == 0
+            ns_store<W>(const_cast<uint64_t*>(a.pool.interested), slot, interested);
+            if (a.pool.scripted) ns_store<W>(const_cast<uint64_t*>(a.pool.scripted), slot, ns_zero<W>());      // scripted_agents_ratio == 0
         }
         // ---- movement_np_random = RandomState(movement_seed): step * uniform(-1, 1), x's then y's per move   :316-319,382
         if (a.env.dynamic_graph) {
@@ -272,8 +280,9 @@ __global__ __launch_bounds__(64) void episode_fill_kernel(StreamArgs a) {
         }
         __syncthreads();                                                  // the slot is complete and visible to this wave
         // ---- GraphEnv.reset + World.reset for this episode into its snapshot                        core.py:398-437
-        Env s{};
-        s.skip = SKIP_NONE, s.sel = NONE, s.act = NONE, s.cur_act = NONE;
+        Env<W> s{};
+        s.skip = SKIP_NONE, s.sel = NONE;
+        MEL_W_FOR(h) s.act[h] = NONE, s.cur_act[h] = NONE;
         env_reset(a.snap, a.pool, slot, s, slot, 0, lane);
         s.ep_cursor = 0;
         env_store(a.snap, slot, lane, s);
@@ -334,7 +343,8 @@ static mel_status launch_episode_refill(const mel_episode_stream* st, const mel_
 #else
     const int grid = (int)(expect < 256 ? 256 : (expect > 4096 ? 4096 : expect));
 #endif
-    MEL_LAUNCH(episode_fill_kernel, dim3(grid), dim3(64), 0, stream, a);
+    if (env->n_nodes > 64) MEL_LAUNCH(episode_fill_kernel<2>, dim3(grid), dim3(64), 0, stream, a);
+    else MEL_LAUNCH(episode_fill_kernel<1>, dim3(grid), dim3(64), 0, stream, a);
     MEL_LAUNCH(episode_publish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, a);
     return check_launch("episode_refill");
 }

@@ -318,9 +318,10 @@ namespace mel {
 // The row lists of a forward and the encoder rows of its node-feature table in ONE launch: the first `gemm_blocks`
 // workgroups are 64 x 64 tiles of the (feature-domain) encoder GEMM, the rest run plan_lists.  The two are independent (the
 // table depends on the weights only) and each is a latency-bound launch of a few hundred workgroups on its own.
+template <int W>
 __global__ __launch_bounds__(256, 2) void plan_enc_kernel(PlanListsArgs pa, GemmBatch batch, int gemm_blocks) {
     if ((int)blockIdx.x < gemm_blocks) gemm_f32_tile<2, 2, 1, 1, GEMM_MODE_ENC>(batch, (int)blockIdx.x);
-    else plan_lists_body(pa, (int)blockIdx.x - gemm_blocks);
+    else plan_lists_body<W>(pa, (int)blockIdx.x - gemm_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,16 +410,17 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     const int hc = w->conv1.heads * w->conv1.channels;
     const size_t M = (size_t)d.bs * d.n;
     const size_t R = (size_t)d.rows_cap;
-    L.plan.adj = c.take<uint64_t>(M);
-    L.plan.live = c.take<uint64_t>(d.bs);
+    const size_t SW = (size_t)set_words(d.n);          // words per node set
+    L.plan.adj = c.take<uint64_t>(M * SW);
+    L.plan.live = c.take<uint64_t>(d.bs * SW);
     const int latent = w->q_head.layer[0].in_dim;
     // node-feature table mode: the encoder / conv1-projection buffers must also hold the N * 40 table rows
     const size_t T = (size_t)d.n * FEATURE_TUPLES_PER_DEGREE;
     const size_t rows2 = (size_t)d.u2_cap > T ? (size_t)d.u2_cap : T, rows1 = (size_t)d.u1_cap > T ? (size_t)d.u1_cap : T;
     const size_t rowsM = M > T ? M : T;
     if (w->model != MEL_MODEL_HLDGN) {
-        L.plan.u1 = c.take<uint64_t>(d.bs);
-        L.plan.u2 = c.take<uint64_t>(d.bs);
+        L.plan.u1 = c.take<uint64_t>(d.bs * SW);
+        L.plan.u2 = c.take<uint64_t>(d.bs * SW);
         L.plan.cnt = c.take<int32_t>(3 * d.bs);
         L.plan.offL = c.take<int32_t>(d.bs + 1);
         L.plan.off1 = c.take<int32_t>(d.bs + 1);
@@ -426,8 +428,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         L.plan.nid2 = c.take<int32_t>(d.u2_cap);
         L.plan.arow1 = c.take<int32_t>(d.u1_cap);
         L.plan.dm1 = c.take<float>(d.u1_cap);
-        L.plan.desc1 = c.take<TargetDesc>(d.u1_cap);
-        L.plan.desc2 = c.take<TargetDesc>(R);
+        L.plan.desc1 = c.take<char>((size_t)d.u1_cap * target_desc_bytes(d.n));
+        L.plan.desc2 = c.take<char>(R * target_desc_bytes(d.n));
         L.plan.row_env = c.take<int32_t>(R);
         L.plan.row_agent = c.take<int32_t>(R);
         L.plan.arow_g = c.take<int32_t>(R);
@@ -775,7 +777,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         if (w->flags & MEL_FWD_PLAN_READY) {       // mel_env_round's plan sink wrote the masks of this call
             if (!agent_mask) return fail(MEL_ERR_INVALID_ARG, "MEL_FWD_PLAN_READY needs the agent-set entry points");
         } else {
-            MEL_LAUNCH(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
+            if (n > 64) MEL_LAUNCH(plan_masks_kernel<2>, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
+            else MEL_LAUNCH(plan_masks_kernel<1>, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_stride, node_cols, agent_mask, L.plan, 1);
             if (mel_status st = check_launch("plan_masks")) return st;
         }
         const int inline_scan = bs <= 8192;           // beyond that the per-wave re-scan (O(bs^2 / 64) loads) loses
@@ -797,9 +800,12 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
             batch.count = 1, batch.p[0] = g, batch.start[0] = 0;
             const int tiles = ((((T + 63) / 64) * (hidden / 64)) + 7) & ~7;
             batch.start[1] = tiles;
-            MEL_LAUNCH(plan_enc_kernel, dim3(tiles + (int)((bs + 3) / 4)), dim3(256), 0, s, pa, batch, tiles);
+            if (n > 64) MEL_LAUNCH(plan_enc_kernel<2>, dim3(tiles + (int)((bs + 3) / 4)), dim3(256), 0, s, pa, batch, tiles);
+            else MEL_LAUNCH(plan_enc_kernel<1>, dim3(tiles + (int)((bs + 3) / 4)), dim3(256), 0, s, pa, batch, tiles);
+        } else if (n > 64) {
+            MEL_LAUNCH(plan_lists_kernel<2>, dim3((bs + 3) / 4), dim3(256), 0, s, pa);
         } else {
-            MEL_LAUNCH(plan_lists_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, pa);
+            MEL_LAUNCH(plan_lists_kernel<1>, dim3((bs + 3) / 4), dim3(256), 0, s, pa);
         }
         if (mel_status st = check_launch("plan_lists")) return st;
     }
@@ -1051,7 +1057,9 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         StageScope t(MEL_STAGE_PLAN, s);
         // hl_dgn.py:108 pools over the whole graph: the controlling index is read (and clamped) but unused
         if (!((w->flags & MEL_FWD_PLAN_READY) && !index_col)) {      // (else: written by mel_env_round's plan sink)
-            MEL_LAUNCH(plan_masks_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
+            if (n > 64) MEL_LAUNCH(plan_masks_kernel<2>, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
+                                   (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
+            else MEL_LAUNCH(plan_masks_kernel<1>, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols,
                                (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
             if (mel_status st = check_launch("plan_masks")) return st;
         }
@@ -1145,7 +1153,9 @@ mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n, int32_t obs
         obs_stride < n * (in_dim + 3))
         return fail(MEL_ERR_INVALID_ARG, "mel_radius_graph: bad arguments");
     clear_stale_error();
-    MEL_LAUNCH(radius_graph_kernel, dim3((bs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), obs, (int)bs, n,
+    if (n > 64) MEL_LAUNCH(radius_graph_kernel<2>, dim3((bs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), obs, (int)bs, n,
+                           obs_stride, in_dim + 3, adj);
+    else MEL_LAUNCH(radius_graph_kernel<1>, dim3((bs + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), obs, (int)bs, n,
                        obs_stride, in_dim + 3, adj);
     return check_launch("mel_radius_graph");
 }
@@ -1182,7 +1192,7 @@ mel_status mel_forward_tap(const mel_weights* w, int32_t kind, int64_t bs, int32
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e;
     if (kind == 0)
-        e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+        e = hipMemcpyAsync(out, L.plan.adj, (size_t)bs * n * set_words(n) * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
     else if (kind == 1)
         e = hipMemcpyAsync(out, L.xcat, (size_t)d.rows_cap * w->q_head.layer[0].in_dim *
                            (w->precision == MEL_PREC_BF16 ? sizeof(uint16_t) : sizeof(float)), hipMemcpyDeviceToDevice, s);

@@ -65,8 +65,8 @@ struct GradArgs {
     const float* xr;        // GATv2: x_r (targets);  Transformer: queries
     const float* att;       // [HC] GATv2 only
     const float* bias;      // [HC] or null
-    const uint64_t* adj;    // [rows] sources of target row (bit j = node j of the same graph), self excluded
-    int rows, n, lanes_per_head, kind;
+    const uint64_t* adj;    // [rows, nw] sources of target row (bit j = node j of the same graph), self excluded
+    int rows, n, nw, lanes_per_head, kind;       // nw = MEL_SET_WORDS(n)
     float scale;            // Transformer: 1 / sqrt(C)
     float* out;             // [rows, HC] relu(out + bias)
     // backward
@@ -96,10 +96,14 @@ __device__ __forceinline__ float edge_score(const GradArgs& a, const GVec<VPL>& 
 }
 
 // closed neighbourhood for GATv2 (self-loop added, A.1), open for TransformerConv (A.2)
+// (the learn path is not the hot path: one two-word code path serves every graph size, the upper word is empty for n <= 64)
 template <int KIND>
-__device__ __forceinline__ uint64_t sources_of(const GradArgs& a, int r) {
-    const uint64_t m = a.adj[r];
-    return KIND == MEL_CONV_GATV2 ? (m | (1ull << (r % a.n))) : m;
+__device__ __forceinline__ NodeSet<2> sources_of(const GradArgs& a, int r) {
+    NodeSet<2> m;
+    m.w[0] = a.adj[(size_t)r * a.nw];
+    m.w[1] = a.nw > 1 ? a.adj[(size_t)r * a.nw + 1] : 0ull;
+    if (KIND == MEL_CONV_GATV2) m |= ns_bit<2>(r % a.n);
+    return m;
 }
 
 template <int VPL, int KIND>
@@ -119,8 +123,8 @@ __global__ __launch_bounds__(256) void gat_full_forward_kernel(GradArgs a) {
     GVec<VPL> acc;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc.v[i] = 0.f;
-    for (uint64_t s = sources_of<KIND>(a, r); s; s &= s - 1) {
-        const size_t row = (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL;
+    for (NodeSet<2> s = sources_of<KIND>(a, r); ns_any(s); ns_clear_lowest(s)) {
+        const size_t row = (size_t)(g0 + ns_lowest(s)) * HC + lane * VPL;
         const GVec<VPL> xl = gload<VPL>(a.xl + row);
         const float e = edge_score<VPL, KIND>(a, xr, xl, att);
         const float mn = fmaxf(m, e);
@@ -159,11 +163,11 @@ __global__ __launch_bounds__(256) void gat_full_backward_kernel(GradArgs a) {
                 dbias.v[i] += g.v[i];
             }
         }
-        const uint64_t src = sources_of<KIND>(a, r);
+        const NodeSet<2> src = sources_of<KIND>(a, r);
         // pass 1: softmax statistics
         float m = -INFINITY, l = 0.f;
-        for (uint64_t s = src; s; s &= s - 1) {
-            const GVec<VPL> xl = gload<VPL>(a.xl + (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL);
+        for (NodeSet<2> s = src; ns_any(s); ns_clear_lowest(s)) {
+            const GVec<VPL> xl = gload<VPL>(a.xl + (size_t)(g0 + ns_lowest(s)) * HC + lane * VPL);
             const float e = edge_score<VPL, KIND>(a, xr, xl, att);
             const float mn = fmaxf(m, e);
             l = l * expf(m - mn) + expf(e - mn);
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(256) void gat_full_backward_kernel(GradArgs a) {
         const float inv = 1.f / (l + 1e-16f);
         // pass 2: S = sum_j alpha_ij (g . s_j)
         float S = 0.f;
-        for (uint64_t s = src; s; s &= s - 1) {
-            const size_t row = (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL;
+        for (NodeSet<2> s = src; ns_any(s); ns_clear_lowest(s)) {
+            const size_t row = (size_t)(g0 + ns_lowest(s)) * HC + lane * VPL;
             const GVec<VPL> xl = gload<VPL>(a.xl + row);
             const float alpha = expf(edge_score<VPL, KIND>(a, xr, xl, att) - m) * inv;
             const GVec<VPL> sv = (KIND == MEL_CONV_GATV2) ? xl : gload<VPL>(a.xv + row);
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256) void gat_full_backward_kernel(GradArgs a) {
         GVec<VPL> dxr;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) dxr.v[i] = 0.f;
-        for (uint64_t s = src; s; s &= s - 1) {
-            const size_t row = (size_t)(g0 + lowest_bit(s)) * HC + lane * VPL;
+        for (NodeSet<2> s = src; ns_any(s); ns_clear_lowest(s)) {
+            const size_t row = (size_t)(g0 + ns_lowest(s)) * HC + lane * VPL;
             const GVec<VPL> xl = gload<VPL>(a.xl + row);
             const float alpha = expf(edge_score<VPL, KIND>(a, xr, xl, att) - m) * inv;
             const GVec<VPL> sv = (KIND == MEL_CONV_GATV2) ? xl : gload<VPL>(a.xv + row);
@@ -338,7 +342,7 @@ mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, co
     const int hc = heads * channels;
     GradArgs a{};
     a.xl = xl, a.xv = (kind == MEL_CONV_GATV2) ? xl : xv, a.xr = xr, a.att = att, a.bias = bias, a.adj = adj;
-    a.rows = (int)(bs * n), a.n = n, a.lanes_per_head = channels / (hc / 64), a.kind = kind;
+    a.rows = (int)(bs * n), a.n = n, a.nw = set_words(n), a.lanes_per_head = channels / (hc / 64), a.kind = kind;
     a.scale = 1.0f / sqrtf((float)channels), a.out = out;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int grid = (a.rows + 3) / 4;
@@ -357,7 +361,7 @@ mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, c
     const int hc = heads * channels;
     GradArgs a{};
     a.xl = xl, a.xv = (kind == MEL_CONV_GATV2) ? xl : xv, a.xr = xr, a.att = att, a.adj = adj;
-    a.rows = (int)(bs * n), a.n = n, a.lanes_per_head = channels / (hc / 64), a.kind = kind;
+    a.rows = (int)(bs * n), a.n = n, a.nw = set_words(n), a.lanes_per_head = channels / (hc / 64), a.kind = kind;
     a.scale = 1.0f / sqrtf((float)channels);
     a.out = const_cast<float*>(out), a.gout = grad_out, a.dxl = dxl, a.dxv = dxv, a.dxr = dxr, a.datt = datt, a.dbias = dbias;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -41,7 +41,13 @@ __device__ __forceinline__ void select_fused(const float (&q)[8], float mean, fl
 }
 
 // per-env logits (HL-DGN): agent i of env b takes argmax / eps-greedy from the env's values with the stream of
-// select_envs_kernel (key b*64 + i); act is the dense [bs, n_nodes] layout
+// select_envs_kernel (key b * 64 * MEL_SET_WORDS(n_nodes) + i); act is the dense [bs, n_nodes] layout
+__device__ __forceinline__ bool live_bit(const uint64_t* live, long b, int n_nodes, int i) {
+    return (live[b * ((n_nodes + 63) >> 6) + (i >> 6)] >> (i & 63)) & 1ull;
+}
+__device__ __forceinline__ uint32_t env_agent_key(long b, int n_nodes, int i) {
+    return (uint32_t)(b * (64 * ((n_nodes + 63) >> 6)) + i);
+}
 __device__ __forceinline__ void select_env_agent(const float (&q)[8], float mean, float v, int na, const mel_select& sel,
                                                  int b, int i) {
     int best = 0;
@@ -51,7 +57,7 @@ __device__ __forceinline__ void select_env_agent(const float (&q)[8], float mean
         if (a < na && q[a] - mean + v > bv) bv = q[a] - mean + v, best = a;
     if (sel.eps > 0.f) {
         const uint32_t step = sel.step_dev ? *sel.step_dev : 0u;
-        const uint32_t base = mix32(sel.seed ^ mix32(step * 0x9e3779b9U + (uint32_t)(b * 64 + i)));
+        const uint32_t base = mix32(sel.seed ^ mix32(step * 0x9e3779b9U + env_agent_key(b, sel.n_nodes, i)));
         if (u01(base) < sel.eps) {
             best = 0, bv = -1.f;
             for (int a = 0; a < na; ++a) {
@@ -94,7 +100,8 @@ __device__ __forceinline__ void dueling_row(const float* hq, int kq, const float
     for (int a = 0; a < 8; ++a)
         if (a < na && lane == a) logits[(size_t)b * na + a] = q[a] - mean + v;
     if (sel.act && sel.live) {                // every lane holds the row's values after the butterfly sums
-        if (lane < sel.n_nodes && ((sel.live[b] >> lane) & 1ull)) select_env_agent(q, mean, v, na, sel, b, lane);
+        for (int i = lane; i < sel.n_nodes; i += 64)
+            if (live_bit(sel.live, b, sel.n_nodes, i)) select_env_agent(q, mean, v, na, sel, b, i);
     } else if (sel.act && lane == 0) {
         select_fused(q, mean, v, na, sel, b);
     }
@@ -266,9 +273,8 @@ __global__ __launch_bounds__(512, 4) void head_finish_kernel(HeadFinish f) {
                 for (int a = 0; a < HF_MAX_ACTIONS; ++a)
                     if (a < na && j16 == a) f.logits[(size_t)b * na + a] = q[a] - mean + v;
                 if (f.sel.act && f.sel.live) {        // the row's 16 lanes share its agents (all of them hold q and v)
-                    const uint64_t lv = f.sel.live[b];
                     for (int i = j16; i < f.sel.n_nodes; i += 16)
-                        if ((lv >> i) & 1ull) select_env_agent(q, mean, v, na, f.sel, b, i);
+                        if (live_bit(f.sel.live, b, f.sel.n_nodes, i)) select_env_agent(q, mean, v, na, f.sel, b, i);
                 } else if (f.sel.act && j16 == 0) {
                     select_fused(q, mean, v, na, f.sel, b);
                 }
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void select_envs_kernel(const float* __restric
     if (t >= bs * n) return;
     const long b = t / n;
     const int i = (int)(t - b * n);
-    if (!((live[b] >> i) & 1ull)) return;
+    if (!live_bit(live, b, n, i)) return;
     const float* q = logits + b * na;
     int best = 0;
     float bv = -INFINITY;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256) void select_envs_kernel(const float* __restric
         if (q[a] > bv) bv = q[a], best = a;
     if (eps > 0.f) {
         const uint32_t step = step_dev ? *step_dev : 0u;
-        const uint32_t base = mix32(seed ^ mix32(step * 0x9e3779b9U + (uint32_t)(b * 64 + i)));
+        const uint32_t base = mix32(seed ^ mix32(step * 0x9e3779b9U + env_agent_key(b, n, i)));
         if (u01(base) < eps) {
             best = 0, bv = -1.f;
             for (int a = 0; a < na; ++a) {

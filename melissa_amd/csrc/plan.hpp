@@ -18,16 +18,20 @@ namespace mel {
 // Rows are packed per env in id order, so the packed position of node j is popcount(mask below j).
 // ------------------------------------------------------------------------------------------------
 // everything the attention kernel needs to know about one target row, in one 32-byte load
+// (W = 1: 32 bytes; W = 2, graphs of 65 .. 128 nodes: 48 bytes)
+template <int W>
 struct TargetDesc {
-    uint64_t sources;   // source nodes of the target (closed neighbourhood for GATv2, open for TransformerConv)
-    uint64_t smask;     // node set the source rows are packed by
+    NodeSet<W> sources; // source nodes of the target (closed neighbourhood for GATv2, open for TransformerConv)
+    NodeSet<W> smask;   // node set the source rows are packed by
     int32_t soff;       // first source row of the env
     int32_t env;
     int32_t node;
     int32_t cat_row;    // conv1: agent row whose head input takes x_1 / x_2 from this target, or -1
 };
+inline size_t target_desc_bytes(int n_nodes) { return n_nodes > 64 ? sizeof(TargetDesc<2>) : sizeof(TargetDesc<1>); }
 
 struct PlanBuffers {
+    // node sets: MEL_SET_WORDS(N) words each
     uint64_t* adj;      // [bs*N] sources of target i (radius rule, self excluded)
     uint64_t* live;     // [bs]   L: controlling agents of the env
     uint64_t* u1;       // [bs]
@@ -39,8 +43,8 @@ struct PlanBuffers {
     int32_t* nid2;      // [sum|U2|] global node id (b*N + i) of packed row
     int32_t* arow1;     // [sum|U1|] row of the U2 list holding the same node
     float* dm1;         // [sum|U1|] decision-maker flag of the node (l_dgn.py:128)
-    TargetDesc* desc1;  // [sum|U1|] conv1 target rows
-    TargetDesc* desc2;  // [R]       conv2 target rows (one per agent row)
+    void* desc1;        // [sum|U1|] TargetDesc<W>: conv1 target rows
+    void* desc2;        // [R]       TargetDesc<W>: conv2 target rows (one per agent row)
     int32_t* row_env;   // [R] env of agent row r
     int32_t* row_agent; // [R] agent (node id) of agent row r
     int32_t* arow_g;    // [R] row of the U1 list holding the agent
@@ -53,21 +57,27 @@ struct PlanBuffers {
 };
 
 // standalone adjacency for the learn path (one wave per observation row)
+template <int W>
 __global__ __launch_bounds__(256) void radius_graph_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
                                                            int node_cols, uint64_t* __restrict__ adj) {
     const int lane = lane_id();
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
-    float x = 0.f, y = 0.f;
-    if (lane < n) {
-        const float* p = obs + (size_t)b * obs_stride + lane * node_cols;
-        x = p[0], y = p[1];
+    float x[W], y[W];
+    MEL_W_FOR(h) {
+        x[h] = 0.f, y[h] = 0.f;
+        if (lane + 64 * h < n) {
+            const float* p = obs + (size_t)b * obs_stride + (lane + 64 * h) * node_cols;
+            x[h] = p[0], y[h] = p[1];
+        }
     }
-    const uint64_t m = radius_sources(x, y, lane, n);
-    if (lane < n) adj[(size_t)b * n + lane] = m;
+    NodeSet<W> m[W];
+    radius_sources<W>(x, y, lane, n, m);
+    MEL_W_FOR(h) if (lane + 64 * h < n) ns_store<W>(adj, (size_t)b * n + lane + 64 * h, m[h]);
 }
 
 // agent_mask == null: one agent per row, taken from the index column (common.py:63)
+template <int W>
 __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict__ obs, int bs, int n,
                                                          int obs_stride, int node_cols,
                                                          const uint64_t* __restrict__ agent_mask, PlanBuffers p,
@@ -76,23 +86,25 @@ __global__ __launch_bounds__(256) void plan_masks_kernel(const float* __restrict
     if (b >= bs) return;
     const int lane = lane_id();
     const float* row = obs + (size_t)b * obs_stride;
-    float x = 0.f, y = 0.f;
-    if (lane < n) {
-        x = row[lane * node_cols];
-        y = row[lane * node_cols + 1];
+    float x[W], y[W];
+    MEL_W_FOR(h) {
+        x[h] = 0.f, y[h] = 0.f;
+        if (lane + 64 * h < n) {
+            x[h] = row[(lane + 64 * h) * node_cols];
+            y[h] = row[(lane + 64 * h) * node_cols + 1];
+        }
     }
-    const uint64_t full = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-    uint64_t live = 0;
+    NodeSet<W> live = ns_zero<W>();
     if (want_receptive >= 0) {
         if (agent_mask) {
-            live = agent_mask[b] & full;
+            live = ns_load<W>(agent_mask, b) & ns_full<W>(n);
         } else {                               // obs[:, -1].clamp(0, N-1).long()
             float gf = row[n * node_cols];
             gf = fminf(fmaxf(gf, 0.f), (float)(n - 1));
-            live = 1ull << (int)gf;
+            live = ns_bit<W>((int)gf);
         }
     }
-    plan_masks_env(x, y, live, want_receptive, b, bs, n, lane, PlanSink{p.adj, p.live, p.u1, p.u2, p.cnt});
+    plan_masks_env<W>(x, y, live, want_receptive, b, bs, n, lane, PlanSink{p.adj, p.live, p.u1, p.u2, p.cnt});
 }
 
 // exclusive scans of |L|, |U1|, |U2| over the batch (single workgroup, any bs)
@@ -139,6 +151,7 @@ struct PlanListsArgs {
 
 // body of plan_lists_kernel for workgroup `block` (four envs): a device function so that plan_enc_kernel (fwd.hip) can run
 // it beside the encoder rows of the node-feature table in one launch
+template <int W>
 __device__ __forceinline__ void plan_lists_body(const PlanListsArgs& a, const int block) {
     const float* __restrict__ obs = a.obs;
     const int bs = a.bs, n = a.n, obs_stride = a.obs_stride, node_cols = a.node_cols;
@@ -150,15 +163,17 @@ __device__ __forceinline__ void plan_lists_body(const PlanListsArgs& a, const in
     const int lane = lane_id();
     if (b == 0 && lane == 0) p.fmeta[0] = table_rows;
     if (table_rows > 0) {                           // tuple ids for the node-feature table path
-        int bad = 0, id = 0;
-        if (lane < n) id = node_feature_id(obs + (size_t)b * obs_stride + lane * node_cols + 2, n, &bad);
-        if (lane < n) p.fid[(size_t)b * n + lane] = id;
+        int bad = 0;
+        MEL_W_FOR(h) {
+            const int node = lane + 64 * h;
+            if (node < n) p.fid[(size_t)b * n + node] = node_feature_id(obs + (size_t)b * obs_stride + node * node_cols + 2, n, &bad);
+        }
         const int any_bad = __ballot(bad != 0) != 0ull;
         if (lane == 0) p.fbad[b] = any_bad;
     } else if (lane == 0) {
         p.fbad[b] = 0;
     }
-    const uint64_t live = p.live[b], u1 = p.u1[b], u2 = p.u2[b];
+    const NodeSet<W> live = ns_load<W>(p.live, b), u1 = ns_load<W>(p.u1, b), u2 = ns_load<W>(p.u2, b);
     int oL, o1, o2;
     if (inline_scan) {
         // exclusive prefix of the three per-env counts, recomputed by every wave from the cnt array (a few KB out
@@ -175,29 +190,38 @@ __device__ __forceinline__ void plan_lists_body(const PlanListsArgs& a, const in
         oL = p.offL[b], o1 = p.off1[b], o2 = p.off2[b];
     }
     const float* row = obs + (size_t)b * obs_stride;
-    const float dm = (lane < n) ? row[lane * node_cols + node_cols - 1] : 0.f;
-    if ((u2 >> lane) & 1ull) p.nid2[o2 + rank_below(u2, lane)] = b * n + lane;
-    if ((u1 >> lane) & 1ull) {
-        const int r1 = o1 + rank_below(u1, lane);
-        p.arow1[r1] = o2 + rank_below(u2, lane);
-        p.dm1[r1] = dm;
-    }
-    const uint64_t mine = (lane < n) ? (p.adj[(size_t)b * n + lane] | (self_loops ? (1ull << lane) : 0ull)) : 0ull;
-    const bool is_agent = (live >> lane) & 1ull;
-    const int rL = oL + rank_below(live, lane);
-    if ((u1 >> lane) & 1ull) {
-        TargetDesc d;
-        d.sources = mine, d.smask = u2, d.soff = o2, d.env = b, d.node = lane, d.cat_row = is_agent ? rL : -1;
-        p.desc1[o1 + rank_below(u1, lane)] = d;
-    }
-    if (is_agent) {
-        p.row_env[rL] = b;
-        p.row_agent[rL] = lane;
-        p.arow_g[rL] = o1 + rank_below(u1, lane);
-        p.dm_g[rL] = dm;
-        TargetDesc d;
-        d.sources = mine, d.smask = u1, d.soff = o1, d.env = b, d.node = lane, d.cat_row = rL;
-        p.desc2[rL] = d;
+    TargetDesc<W>* desc1 = static_cast<TargetDesc<W>*>(p.desc1);
+    TargetDesc<W>* desc2 = static_cast<TargetDesc<W>*>(p.desc2);
+    MEL_W_FOR(h) {
+        const int node = lane + 64 * h;
+        const float dm = (node < n) ? row[node * node_cols + node_cols - 1] : 0.f;
+        if (ns_mine(u2, lane, h)) p.nid2[o2 + ns_rank_below(u2, node)] = b * n + node;
+        if (ns_mine(u1, lane, h)) {
+            const int r1 = o1 + ns_rank_below(u1, node);
+            p.arow1[r1] = o2 + ns_rank_below(u2, node);
+            p.dm1[r1] = dm;
+        }
+        NodeSet<W> mine = ns_zero<W>();
+        if (node < n) {
+            mine = ns_load<W>(p.adj, (size_t)b * n + node);
+            if (self_loops) mine |= ns_bit<W>(node);
+        }
+        const bool is_agent = ns_mine(live, lane, h);
+        const int rL = oL + ns_rank_below(live, node);
+        if (ns_mine(u1, lane, h)) {
+            TargetDesc<W> d;
+            d.sources = mine, d.smask = u2, d.soff = o2, d.env = b, d.node = node, d.cat_row = is_agent ? rL : -1;
+            desc1[o1 + ns_rank_below(u1, node)] = d;
+        }
+        if (is_agent) {
+            p.row_env[rL] = b;
+            p.row_agent[rL] = node;
+            p.arow_g[rL] = o1 + ns_rank_below(u1, node);
+            p.dm_g[rL] = dm;
+            TargetDesc<W> d;
+            d.sources = mine, d.smask = u1, d.soff = o1, d.env = b, d.node = node, d.cat_row = rL;
+            desc2[rL] = d;
+        }
     }
     if (row_offsets_out && lane == 0) {
         row_offsets_out[b] = oL;
@@ -205,7 +229,8 @@ __device__ __forceinline__ void plan_lists_body(const PlanListsArgs& a, const in
     }
 }
 
-__global__ __launch_bounds__(256) void plan_lists_kernel(PlanListsArgs a) { plan_lists_body(a, (int)blockIdx.x); }
+template <int W>
+__global__ __launch_bounds__(256) void plan_lists_kernel(PlanListsArgs a) { plan_lists_body<W>(a, (int)blockIdx.x); }
 
 // HL-DGN has no row lists: the tuple ids alone (one wave per env)
 __global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
@@ -218,9 +243,9 @@ __global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restric
         if (lane == 0) p.fbad[b] = 0;
         return;
     }
-    int bad = 0, id = 0;
-    if (lane < n) id = node_feature_id(obs + (size_t)b * obs_stride + lane * node_cols + 2, n, &bad);
-    if (lane < n) p.fid[(size_t)b * n + lane] = id;
+    int bad = 0;
+    for (int node = lane; node < n; node += 64)
+        p.fid[(size_t)b * n + node] = node_feature_id(obs + (size_t)b * obs_stride + node * node_cols + 2, n, &bad);
     const int any_bad = __ballot(bad != 0) != 0ull;
     if (lane == 0) p.fbad[b] = any_bad;
 }

@@ -9,22 +9,33 @@ namespace mel {
 // [3P] torch_cluster radius_graph(pos, r=0.2, loop=False, max_num_neighbors=32) on the fp32 obs
 // positions (common.py:47-48): d2 = dx*dx + dy*dy < float(0.2*0.2), no fma; per target
 // the first 33 hits in index order (self included) survive, then self is dropped.
-__device__ __forceinline__ uint64_t radius_sources(float x, float y, int lane, int n) {
+// x[h], y[h] / src[h]: node lane + 64 h (zeros / empty for nodes >= n).
+template <int W>
+__device__ __forceinline__ void radius_sources(const float (&x)[W], const float (&y)[W], int lane, int n,
+                                               NodeSet<W> (&src)[W]) {
     // node j's position as an LDS broadcast instead of two v_readlane (see geometric_one_hop in env.hip); the callers'
     // workgroups are 4 wavefronts
-    __shared__ float sx[4][64], sy[4][64];
+    __shared__ float sx[4][64 * W], sy[4][64 * W];
     const int w = (threadIdx.x >> 6) & 3;
-    sx[w][lane] = x, sy[w][lane] = y;
+    MEL_W_FOR(h) sx[w][lane + 64 * h] = x[h], sy[w][lane + 64 * h] = y[h];
     const float r2 = (float)(0.2 * 0.2);
-    uint64_t m = 0;
+    MEL_W_FOR(h) src[h] = ns_zero<W>();
+    MEL_W_FOR(k) {
+        const int cnt = n - 64 * k < 64 ? n - 64 * k : 64;
 #pragma unroll 5
-    for (int j = 0; j < n; ++j) {
-        const float dx = x - sx[w][j], dy = y - sy[w][j];
-        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-        if (d2 < r2) m |= 1ull << j;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float xj = sx[w][64 * k + jj], yj = sy[w][64 * k + jj];
+            MEL_W_FOR(h) {
+                const float dx = x[h] - xj, dy = y[h] - yj;
+                const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                if (d2 < r2) src[h].w[k] |= 1ull << jj;
+            }
+        }
     }
-    while (__popcll(m) > 33) m &= ~(1ull << (63 - __clzll((long long)m)));
-    return (lane < n) ? (m & ~(1ull << lane)) : 0ull;
+    MEL_W_FOR(h) {
+        while (ns_count(src[h]) > 33) src[h] = src[h] & ~ns_bit<W>(ns_highest(src[h]));
+        src[h] = (lane + 64 * h < n) ? (src[h] & ~ns_bit<W>(lane + 64 * h)) : ns_zero<W>();
+    }
 }
 
 // ---- node-feature table (MEL_FWD_INTEGER_FEATURES) ---------------------------------------------------------------------
@@ -50,9 +61,10 @@ __device__ __forceinline__ int node_feature_id(const float* f, int n, int* bad) 
     return d * FEATURE_TUPLES_PER_DEGREE + m * 8 + a * 4 + i * 2 + h;
 }
 
-// the plan masks of one env from its fp32 node positions (lane = node) and its agent set; want_receptive < 0: adjacency
-// only (HL-DGN), 0: adjacency + agent set, 1: + one- / two-hop sets and sizes.  Shared by plan_masks_kernel and the env
-// round kernel's plan sink (mel_env_batch.plan_*), which therefore write bit-identical buffers.
+// the plan masks of one env from its fp32 node positions (x[h], y[h]: node lane + 64 h) and its agent set;
+// want_receptive < 0: adjacency only (HL-DGN), 0: adjacency + agent set, 1: + one- / two-hop sets and sizes.  Shared by
+// plan_masks_kernel and the env round kernel's plan sink (mel_env_batch.plan_*), which therefore write bit-identical
+// buffers.  Sets are W words each (MEL_SET_WORDS).
 struct PlanSink {
     uint64_t* adj;
     uint64_t* live;
@@ -60,25 +72,32 @@ struct PlanSink {
     uint64_t* u2;
     int32_t* cnt;
 };
-__device__ __forceinline__ void plan_masks_env(float x, float y, uint64_t live, int want_receptive, int b, int bs, int n,
-                                               int lane, const PlanSink& p) {
-    const uint64_t src = radius_sources(x, y, lane, n);
-    if (lane < n) p.adj[(size_t)b * n + lane] = src;
+template <int W>
+__device__ __forceinline__ void plan_masks_env(const float (&x)[W], const float (&y)[W], const NodeSet<W>& live,
+                                               int want_receptive, int b, int bs, int n, int lane, const PlanSink& p) {
+    NodeSet<W> src[W];
+    radius_sources<W>(x, y, lane, n, src);
+    MEL_W_FOR(h) if (lane + 64 * h < n) ns_store<W>(p.adj, (size_t)b * n + lane + 64 * h, src[h]);
     if (want_receptive < 0) return;
     if (!want_receptive) {
-        if (lane == 0) p.live[b] = live;
+        if (lane == 0) ns_store<W>(p.live, b, live);
         return;
     }
-    const uint64_t closed = (lane < n) ? (src | (1ull << lane)) : 0ull;   // sources incl. self-loop
-    const uint64_t u1 = wave_or_u64(((live >> lane) & 1ull) ? closed : 0ull);
-    const uint64_t u2 = wave_or_u64(((u1 >> lane) & 1ull) ? closed : 0ull);
+    NodeSet<W> closed[W];                                                // sources incl. self-loop
+    MEL_W_FOR(h) closed[h] = (lane + 64 * h < n) ? (src[h] | ns_bit<W>(lane + 64 * h)) : ns_zero<W>();
+    NodeSet<W> acc = ns_zero<W>();
+    MEL_W_FOR(h) if (ns_mine(live, lane, h)) acc |= closed[h];
+    const NodeSet<W> u1 = ns_wave_or(acc);
+    acc = ns_zero<W>();
+    MEL_W_FOR(h) if (ns_mine(u1, lane, h)) acc |= closed[h];
+    const NodeSet<W> u2 = ns_wave_or(acc);
     if (lane == 0) {
-        p.live[b] = live;
-        p.u1[b] = u1;
-        p.u2[b] = u2;
-        p.cnt[b] = __popcll(live);
-        p.cnt[bs + b] = __popcll(u1);
-        p.cnt[2 * bs + b] = __popcll(u2);
+        ns_store<W>(p.live, b, live);
+        ns_store<W>(p.u1, b, u1);
+        ns_store<W>(p.u2, b, u2);
+        p.cnt[b] = ns_count(live);
+        p.cnt[bs + b] = ns_count(u1);
+        p.cnt[2 * bs + b] = ns_count(u2);
     }
 }
 

@@ -19,11 +19,55 @@ RADIUS_OF_INFLUENCE = 0.20
 NODES_MOVEMENT_STEP = 0.06      # constants.py:4
 
 
+# ---- node sets (include/melissa_hip.h, MEL_SET_WORDS): a set of nodes of an N-node graph is W = ceil(N / 64) uint64 words,
+# word k = nodes 64 k .. 64 k + 63.  N <= 64: one uint64 per set and arrays of sets have exactly the shape they always had
+# ([N], [B], ...); 64 < N <= 128: a trailing [2] axis.
+def set_words(n: int) -> int:
+    return (int(n) + 63) // 64
+
+
+def set_shape(n: int) -> tuple:
+    """Trailing shape of an array of node sets: () for N <= 64, (W,) beyond."""
+    w = set_words(n)
+    return () if w == 1 else (w,)
+
+
+def int_to_set(mask: int, n: int):
+    """Python int bit mask -> np.uint64 scalar (N <= 64) or uint64 [W]."""
+    w = set_words(n)
+    if w == 1:
+        return np.uint64(mask & 0xFFFFFFFFFFFFFFFF)
+    return np.array([(mask >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(w)], dtype=np.uint64)
+
+
+def set_to_int(words) -> int:
+    """np.uint64 scalar / uint64 [W] (or their int64 bit patterns) -> Python int bit mask."""
+    a = np.atleast_1d(np.asarray(words))
+    if a.dtype != np.uint64:
+        a = a.astype(np.int64).view(np.uint64)
+    out = 0
+    for k, v in enumerate(a):
+        out |= int(v) << (64 * k)
+    return out
+
+
+def sets_to_bool(words: np.ndarray, n: int) -> np.ndarray:
+    """uint64 [..., (W)] node sets -> bool [..., n] membership."""
+    a = np.asarray(words)
+    if a.dtype != np.uint64:
+        a = a.astype(np.int64).view(np.uint64)
+    w = set_words(n)
+    if w == 1:
+        a = a[..., None]
+    node = np.arange(n)
+    return ((a[..., node // 64] >> (node % 64).astype(np.uint64)) & np.uint64(1)).astype(bool)
+
+
 @dataclass
 class Graph:
-    """A graph as the env consumes it: float64 node positions + one-hop bit masks (uint64 per node)."""
+    """A graph as the env consumes it: float64 node positions + one-hop node sets (uint64 per node; [N, 2] beyond 64 nodes)."""
     pos: np.ndarray              # [N, 2] float64
-    one_hop: np.ndarray          # [N] uint64
+    one_hop: np.ndarray          # [N] uint64 ([N, W] for N > 64)
 
     @staticmethod
     def from_positions(pos, radius: float = RADIUS_OF_INFLUENCE) -> "Graph":
@@ -51,7 +95,7 @@ class Graph:
     def is_connected(self) -> bool:
         n = len(self.one_hop)
         seen, frontier = 1, 1
-        masks = [int(m) for m in self.one_hop]
+        masks = [set_to_int(m) for m in self.one_hop]
         while frontier:
             nxt = 0
             for i in range(n):
@@ -63,9 +107,15 @@ class Graph:
 
 
 def adjacency_to_masks(adj: np.ndarray) -> np.ndarray:
+    """bool [N, N] -> uint64 [N] (N <= 64) or [N, W] node sets (bit j of row i = adj[i, j])."""
     n = adj.shape[0]
-    weights = (np.uint64(1) << np.arange(n, dtype=np.uint64))
-    return (adj.astype(np.uint64) * weights[None, :]).sum(axis=1, dtype=np.uint64)
+    w = set_words(n)
+    out = np.zeros((n, w), dtype=np.uint64)
+    for k in range(w):
+        cols = adj[:, 64 * k: 64 * (k + 1)]
+        weights = (np.uint64(1) << np.arange(cols.shape[1], dtype=np.uint64))
+        out[:, k] = (cols.astype(np.uint64) * weights[None, :]).sum(axis=1, dtype=np.uint64)
+    return out[:, 0] if w == 1 else out
 
 
 def synthetic_graph_pool(n: int, count: int, first_seed: int = 0, radius: float = RADIUS_OF_INFLUENCE):
@@ -92,7 +142,7 @@ def packed_graph_pool(n: int, count: int, first_seed: int = 0, radius: float = R
     About 0.5 ms per accepted graph at N = 50 (one in four candidates is connected)."""
     import random
     pos_out = np.empty((count, n, 2), dtype=np.float64)
-    hop_out = np.empty((count, n), dtype=np.uint64)
+    hop_out = np.empty((count, n) + set_shape(n), dtype=np.uint64)
     seeds = np.empty(count, dtype=np.int64)
     got, s = 0, first_seed
     while got < count:
@@ -106,7 +156,8 @@ def packed_graph_pool(n: int, count: int, first_seed: int = 0, radius: float = R
 
 
 def save_graph_pool(path: str, pos: np.ndarray, one_hop: np.ndarray, seeds=None):
-    """Packed graph dataset on disk: ``pos`` f64 [G, N, 2] + ``adj`` u64 [G, N] (bit j of adj[g, i] = edge i - j)."""
+    """Packed graph dataset on disk: ``pos`` f64 [G, N, 2] + ``adj`` u64 [G, N] (bit j of adj[g, i] = edge i - j;
+    [G, N, 2] words beyond 64 nodes)."""
     np.savez(path, pos=np.ascontiguousarray(pos, dtype=np.float64), adj=np.ascontiguousarray(one_hop, dtype=np.uint64),
              **({"seeds": np.asarray(seeds)} if seeds is not None else {}))
 
@@ -230,15 +281,15 @@ def pack_episodes(episodes, graphs, n: int, max_moves: int, dynamic: bool):
     """-> dict of numpy arrays in mel_episode_pool layout."""
     e = len(episodes)
     pos = np.zeros((e, n, 2), dtype=np.float64)
-    one_hop = np.zeros((e, n), dtype=np.uint64)
-    interested = np.zeros(e, dtype=np.uint64)
-    scripted = np.zeros(e, dtype=np.uint64)
+    one_hop = np.zeros((e, n) + set_shape(n), dtype=np.uint64)
+    interested = np.zeros((e,) + set_shape(n), dtype=np.uint64)
+    scripted = np.zeros((e,) + set_shape(n), dtype=np.uint64)
     origin = np.zeros(e, dtype=np.int32)
     moves = np.zeros((e, max_moves if dynamic else 1, 2, n), dtype=np.float64)
     for k, ep in enumerate(episodes):
         g = graphs[ep.graph_index]
         pos[k], one_hop[k] = g.pos, g.one_hop
-        interested[k], origin[k], scripted[k] = np.uint64(ep.interested), ep.origin, np.uint64(ep.scripted)
+        interested[k], origin[k], scripted[k] = int_to_set(ep.interested, n), ep.origin, int_to_set(ep.scripted, n)
         if dynamic:
             moves[k] = movement_offsets(ep.movement_seed, n, max_moves)
     return dict(pos=pos, one_hop=one_hop, interested=interested, origin=origin, moves=moves, scripted=scripted)

@@ -11,9 +11,9 @@ loops (``melissa_amd.collect``) take their episodes from an :class:`EpisodeStrea
   algorithms (PCG64 ``Generator.integers`` / ``choice``; legacy MT19937 ``RandomState`` randint / uniform / choice /
   the ``0.06 * uniform(-1, 1)`` movement offsets), copies the graph out of the packed dataset in HBM (the replacement of
   ``pickle.load`` per episode, core.py:450-452), and runs ``GraphEnv.reset`` + ``World.reset`` into the slot's snapshot;
-* the loop calls :meth:`EpisodeSupply.before_step` once per iteration: every ``period`` iterations the refill is issued
-  on a SIDE stream (ordered after the main stream's work so far by an event, so it reads exact episode cursors), and the
-  main stream waits for it one period later.  An env starts at most one episode per iteration, so with
+* the loop calls :meth:`before_step` / :meth:`after_step` once per iteration: every ``period`` iterations the refill is
+  issued on a SIDE stream - ordered after the main stream's work so far by an event (it reads exact episode cursors; the
+  main stream waits for it one period later), or, in the round loop, paced by a gate on the device-side round counter.  An env starts at most one episode per iteration, so with
   ``2 * period <= ring - 1`` no env can reach a slot that is being written or an episode that is not there yet; the env
   kernels check that anyway (``MEL_ENV_ERR_EPISODE_UNDERRUN``).
 
@@ -66,6 +66,9 @@ class StaticSupply:
         return self.table[:, 0].contiguous()
 
     def before_step(self, iteration: int, round_counter=None):
+        pass
+
+    def after_step(self, iteration: int, round_counter=None):
         pass
 
     def describe(self) -> dict:
@@ -146,31 +149,22 @@ class EpisodeStream:
     def first_episode_ids(self) -> torch.Tensor:
         return self.table[:, 0].contiguous()
 
+    def _paced(self, round_counter) -> bool:
+        # paced mode needs slack: a refill gated behind iteration i reads the cursors that iteration left, finishes within the
+        # next iteration or two, and must cover every episode an env can start until the NEXT refill has finished, i.e. up to
+        # period + 1 more: period <= ring - 3 (one more of margin kept).  Small test rings fall back to events.
+        return (round_counter is not None and self.period <= self.ring - 4
+                and os.environ.get("MEL_STREAM_SYNC", "paced") == "paced")
+
     def before_step(self, iteration: int, round_counter: "torch.Tensor | None" = None):
         """Call before launching iteration number ``iteration`` (0-based) on the current stream.  Every ``period``
         iterations one refill is issued on the side stream, ordered after the main stream's progress in one of two ways:
 
-        * ``round_counter`` given (the device counter mel_env_round advances once per round, RoundLoop): a pacing gate
-          (mel_wait_counter) on the SIDE stream polls it until this iteration's env launch has started, i.e. the previous
-          iteration is complete; nothing touches the main stream (an event record / wait between HIP-graph replays costs
-          the replayed step ~8 us on this stack, measured).  Nothing orders the main stream behind the refill either: a
-          refill takes ~0.15 ms and no env can need its episodes before ``ring - period - 3`` more iterations; should that
-          ever fail, the env kernels' produced check raises MEL_ENV_ERR_EPISODE_UNDERRUN (an error, never a stale slot).
+        * ``round_counter`` given (the device counter mel_env_round advances once per round, RoundLoop): nothing happens
+          here - the loop calls :meth:`after_step` once the iteration's launches are enqueued.
         * no counter (DecisionLoop): events - the side stream waits for an event recorded on the main stream, and the main
           stream waits for the refill one period later."""
-        if iteration % self.period:
-            return
-        # paced mode needs slack: a refill gated at iteration i reads cursors of iteration i-1 or i, finishes within the next
-        # iteration or two, and must cover every episode an env can start until the NEXT refill has finished, i.e. up to
-        # period + 1 more: period <= ring - 3 (one more of margin kept).  Small test rings fall back to events.
-        if (round_counter is not None and self.period <= self.ring - 4
-                and os.environ.get("MEL_STREAM_SYNC", "paced") == "paced"):
-            with torch.cuda.stream(self.side):
-                # (the gate is satisfied by the env launch this very step() call issues next; the 2 s bound only guards the
-                #  process exit should that launch never come.  The host can run hundreds of replays ahead of the GPU.)
-                _lib.check(self.lib.mel_wait_counter(round_counter.data_ptr(), (iteration + 1) & 0xFFFFFFFF, 2000000,
-                                                     _lib.current_stream_ptr(self.venv.device)), "mel_wait_counter")
-                self.refill(max_new=self._max_new)
+        if iteration % self.period or self._paced(round_counter):
             return
         main = torch.cuda.current_stream(self.venv.device)
         if self._ev_done is not None:
@@ -182,6 +176,25 @@ class EpisodeStream:
             if self._ev_done is None:
                 self._ev_done = torch.cuda.Event()
             self._ev_done.record(self.side)
+
+    def after_step(self, iteration: int, round_counter: "torch.Tensor | None" = None):
+        """Call after iteration number ``iteration``'s launches are ENQUEUED on the current stream (RoundLoop).  Paced mode:
+        a gate (mel_wait_counter) on the SIDE stream polls the device-side round counter until that iteration's env launch
+        has started, then the refill runs; nothing touches the main stream (an event record / wait between HIP-graph
+        replays costs the replayed step ~8 us on this stack, measured).  The gate only ever waits for work that is already
+        in a queue: issued BEFORE the launch it waits for (as round 2's first version did) it stalls for its whole 2 s bound
+        whenever the runtime maps the side stream and the main stream onto the same in-order hardware queue (seen in a
+        process that had created other streams before: 28 refills x 2 s in a 200-step run).  Nothing orders the main
+        stream behind the refill either: a refill takes ~0.15 ms and no env can need its episodes before
+        ``ring - period - 3`` more iterations; should that ever fail, the env kernels' produced check raises
+        MEL_ENV_ERR_EPISODE_UNDERRUN (an error, never a stale slot)."""
+        if iteration % self.period or not self._paced(round_counter):
+            return
+        with torch.cuda.stream(self.side):
+            # (the 2 s bound only guards the process exit; the host can run hundreds of replays ahead of the GPU)
+            _lib.check(self.lib.mel_wait_counter(round_counter.data_ptr(), (iteration + 1) & 0xFFFFFFFF, 2000000,
+                                                 _lib.current_stream_ptr(self.venv.device)), "mel_wait_counter")
+            self.refill(max_new=self._max_new)
 
     def drawn(self) -> int:
         """Episodes drawn so far over all envs (synchronises)."""

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .episodes import EpisodeSampler, Graph, pack_episodes
+from .episodes import EpisodeSampler, Graph, pack_episodes, set_shape, set_words, sets_to_bool
 
 LOGGER_KEYS = ("total_messages_transmitted", "coverage", "messages_sent", "messages_received", "n_neighbours",
                "interested_agents", "coverage_interested_fraction", "coverage_interested_count",
@@ -58,10 +58,11 @@ class DevicePool:
         the device sampler fills - nothing to upload)."""
         self = cls.__new__(cls)
         z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=device)
-        self.tensors = dict(pos=z(n_episodes, n, 2, dtype=torch.float64), one_hop=z(n_episodes, n, dtype=torch.int64),
-                            interested=z(n_episodes, dtype=torch.int64), origin=z(n_episodes, dtype=torch.int32),
+        ws = set_shape(n)                          # node sets: one int64 word per set up to 64 nodes, [W] beyond
+        self.tensors = dict(pos=z(n_episodes, n, 2, dtype=torch.float64), one_hop=z(n_episodes, n, *ws, dtype=torch.int64),
+                            interested=z(n_episodes, *ws, dtype=torch.int64), origin=z(n_episodes, dtype=torch.int32),
                             moves=z(n_episodes, max_moves if dynamic else 1, 2, n, dtype=torch.float64),
-                            scripted=z(n_episodes, dtype=torch.int64))
+                            scripted=z(n_episodes, *ws, dtype=torch.int64))
         self.struct = _lib.MelEpisodePool()
         self.struct.n_episodes, self.struct.n_nodes = n_episodes, n
         self.struct.max_moves = max_moves if dynamic else 1
@@ -132,7 +133,7 @@ class ObsBuffers:
         self.rew = torch.empty(rows, n, dtype=torch.float64, device=device)
         self.terminated = torch.empty(rows, dtype=torch.uint8, device=device)
         self.flags = torch.empty(rows, 4, dtype=torch.int32, device=device)
-        self.active_nb = torch.empty(rows, dtype=torch.int64, device=device)
+        self.active_nb = torch.empty(rows, *set_shape(n), dtype=torch.int64, device=device)
         self.stats = torch.empty(rows, _lib.ENV_LOGGER_STATS, dtype=torch.float64, device=device)
         s = _lib.MelEnvObs()
         s.obs, s.obs_stride = self.obs.data_ptr(), self.obs.stride(0)
@@ -255,9 +256,10 @@ class HipGraphVectorEnv:
         return self.state[off: off + self.env_num * _lib.ENV_SCALARS * 4].view(torch.int32).view(self.env_num, -1)
 
     def node_sets(self) -> torch.Tensor:
-        """[B, 8] int64 bit patterns of the MEL_SET_* node sets (device)."""
+        """[B, 8] int64 bit patterns of the MEL_SET_* node sets (device); [B, 8, W] beyond 64 nodes."""
         off = self.env.node_sets - self.state.data_ptr()
-        return self.state[off: off + self.env_num * 8 * 8].view(torch.int64).view(self.env_num, 8)
+        w = set_words(self.n)
+        return self.state[off: off + self.env_num * 8 * 8 * w].view(torch.int64).view(self.env_num, 8, *set_shape(self.n))
 
     def _field(self, ptr, per_env, dtype):
         off = ptr - self.state.data_ptr()
@@ -272,10 +274,11 @@ class HipGraphVectorEnv:
         return self._field(self.env.pos, 2 * self.n, torch.float64).view(self.env_num, self.n, 2)
 
     def one_hop(self):
-        return self._field(self.env.one_hop, self.n, torch.int64)
+        """[B, N] int64 bit patterns ([B, N, W] beyond 64 nodes)."""
+        return self._field(self.env.one_hop, self.n * set_words(self.n), torch.int64).view(self.env_num, self.n, *set_shape(self.n))
 
     def two_hop(self):
-        return self._field(self.env.two_hop, self.n, torch.int64)
+        return self._field(self.env.two_hop, self.n * set_words(self.n), torch.int64).view(self.env_num, self.n, *set_shape(self.n))
 
     # ------------------------------------------------------------------ reset / step
     def _reset_rows(self, ids: np.ndarray, observe: bool = True):
@@ -340,15 +343,14 @@ class HipGraphVectorEnv:
         rew = o.rew[:k].cpu().numpy()
         term = o.terminated[:k].cpu().numpy().astype(bool)
         flags = o.flags[:k].cpu().numpy()
-        nb = o.active_nb[:k].cpu().numpy().view(np.uint64)
+        nb = sets_to_bool(o.active_nb[:k].cpu().numpy().view(np.uint64), self.n)
         stats = o.stats[:k].cpu().numpy()
-        shifts = np.arange(self.n, dtype=np.uint64)
         obs, info = [], []
         for r in range(k):
             obs.append({"agent_id": str(int(agent[r])), "obs": obs_h[r], "mask": mask[r]})
             d = {"env_id": int(ids[r]), "env_step": int(flags[r, 0]), "environment_step": bool(flags[r, 1]),
                  "explicit_reset": bool(flags[r, 2]),
-                 "active_one_hop_neighbors": ((nb[r] >> shifts) & np.uint64(1)).astype(np.bool_)}
+                 "active_one_hop_neighbors": nb[r]}
             if flags[r, 3]:
                 d["logger_stats"] = {key: stats[r, j] for j, key in enumerate(LOGGER_KEYS)}
             info.append(d)
@@ -372,7 +374,7 @@ class HipGraphVectorEnv:
     def round_device(self, pool: DevicePool, actions: torch.Tensor | None, row_offsets: torch.Tensor | None,
                      live: torch.Tensor, episode_table: torch.Tensor | None, first: bool = False,
                      round_counter: torch.Tensor | None = None, replay=None):
-        """One whole env round for every env (mel_env_round).  ``live`` int64 [B] is read (the active sets the
+        """One whole env round for every env (mel_env_round).  ``live`` int64 [B] ([B, W] beyond 64 nodes) is read (the active sets the
         actions were computed for) and overwritten with the next round's active sets."""
         _lib.check(self.lib.mel_env_round(
             C.byref(self.env), C.byref(pool.struct), actions.data_ptr() if actions is not None else None,

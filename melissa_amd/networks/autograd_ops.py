@@ -27,10 +27,11 @@ def _stream(t: torch.Tensor):
 
 
 def radius_graph(obs: torch.Tensor, n_nodes: int, in_dim: int) -> torch.Tensor:
-    """obs: CUDA fp32 [bs, >= n*(in_dim+3)] -> int64 [bs*n] bit patterns (bit j = node j is a source)."""
+    """obs: CUDA fp32 [bs, >= n*(in_dim+3)] -> int64 [bs*n] bit patterns (bit j = node j is a source); [bs*n, 2] words
+    beyond 64 nodes (MEL_SET_WORDS)."""
     assert obs.is_cuda and obs.dtype == torch.float32 and obs.stride(-1) == 1
     bs = obs.shape[0]
-    adj = torch.empty(bs * n_nodes, dtype=torch.int64, device=obs.device)
+    adj = torch.empty(bs * n_nodes, *(() if n_nodes <= 64 else (_lib.set_words(n_nodes),)), dtype=torch.int64, device=obs.device)
     _lib.check(_lib.load().mel_radius_graph(obs.data_ptr(), bs, n_nodes, obs.stride(0), in_dim, adj.data_ptr(), _stream(obs)),
                "mel_radius_graph")
     return adj

@@ -267,14 +267,15 @@ class HipForwardMixin:
         return out
 
     def hip_tap(self, kind: int, bs: int, rows_cap: int = 0, workspace: torch.Tensor | None = None) -> torch.Tensor:
-        """Parity tap after a HIP forward: 0 = adjacency masks [bs, N] int64 bit patterns, 1 = head input
+        """Parity tap after a HIP forward: 0 = adjacency masks [bs, N] int64 bit patterns ([bs, N, 2] beyond 64 nodes), 1 = head input
         [rows, latent], 2 = int32 [3] rows processed (sum|U1|, sum|U2|, agent rows).  ``rows_cap`` = 0 after
         ``hip_forward``, else the cap given to ``hip_forward_agents``."""
         lib = _lib.load()
         w = self._weights()
         ws = workspace if workspace is not None else (self._ws_agents if rows_cap else self._ws)
         if kind == 0:
-            out = torch.empty(bs, self.agents_num, dtype=torch.int64, device=ws.device)
+            out = torch.empty(bs, self.agents_num, *(() if self.agents_num <= 64 else (_lib.set_words(self.agents_num),)),
+                              dtype=torch.int64, device=ws.device)
         elif kind == 1:
             out = torch.empty(rows_cap or bs, w.q_head.layer[0].in_dim, device=ws.device,
                               dtype=torch.bfloat16 if self.feature_dtype == "bf16" else torch.float32)
@@ -337,7 +338,7 @@ class HipForwardMixin:
                            plan_ready: bool = False, integer_features: bool = False):
         """L-DGN for a set of controlling agents per env (round-batched loop).  ``obs_matrix``: CUDA fp32
         [bs, >= 8N] (row b = env b's obs_matrix, any row stride), ``agent_mask``: CUDA int64 [bs] bit
-        patterns.  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
+        patterns ([bs, 2] words beyond 64 nodes).  Returns (logits [rows_cap, A] - rows ordered by env then agent id -, row_offsets [bs+1])."""
         if self._MODEL == _lib.MODEL_HLDGN:
             raise RuntimeError("hip_forward_agents is the L-DGN / DGN-R entry point")
         lib = _lib.load()

@@ -21,8 +21,11 @@ class RoundReplay:
         dev = torch.device(device)
         self.obs = torch.zeros(n_envs, capacity, 8 * n_nodes, dtype=torch.float32, device=dev)
         self.obs_next = torch.zeros_like(self.obs)
-        self.acted = torch.zeros(n_envs, capacity, dtype=torch.int64, device=dev)
-        self.done = torch.zeros(n_envs, capacity, dtype=torch.int64, device=dev)
+        # node sets (who acted / who was terminated by the round): one int64 word up to 64 nodes, [W] words beyond
+        self.W = _lib.set_words(n_nodes)
+        ws = () if self.W == 1 else (self.W,)
+        self.acted = torch.zeros(n_envs, capacity, *ws, dtype=torch.int64, device=dev)
+        self.done = torch.zeros(n_envs, capacity, *ws, dtype=torch.int64, device=dev)
         self.act = torch.zeros(n_envs, capacity, n_nodes, dtype=torch.int8, device=dev)
         self.rew = torch.zeros(n_envs, capacity, n_nodes, dtype=torch.float32, device=dev)
         self.episode = torch.full((n_envs, capacity), -1, dtype=torch.int32, device=dev)
@@ -33,15 +36,28 @@ class RoundReplay:
         s.acted, s.done, s.act = self.acted.data_ptr(), self.done.data_ptr(), self.act.data_ptr()
         s.rew, s.episode, s.cursor = self.rew.data_ptr(), self.episode.data_ptr(), self.cursor.data_ptr()
         self.struct = s
-        self._bits = (torch.ones(1, dtype=torch.int64, device=dev) << torch.arange(n_nodes, device=dev))
+        node = torch.arange(n_nodes, device=dev)
+        self._word, self._shift = node // 64, node % 64
 
     def __len__(self) -> int:
         """Transitions currently held (synchronises)."""
         valid = self._valid_slots()
         return int(self._popcount(self.acted[valid]).sum())
 
+    def _members(self, m: torch.Tensor) -> torch.Tensor:
+        """node sets int64 [..., (W)] -> bool [..., N]."""
+        if self.W == 1:
+            m = m[..., None]
+        return ((m[..., self._word] >> self._shift) & 1) != 0
+
+    def _has(self, m: torch.Tensor, agent: torch.Tensor) -> torch.Tensor:
+        """node sets int64 [bs, (W)], agent [bs] -> bool [bs]: is agent[i] a member of m[i]?"""
+        if self.W == 1:
+            m = m[..., None]
+        return ((m.gather(-1, (agent // 64)[:, None]).squeeze(-1) >> (agent % 64)) & 1) != 0
+
     def _popcount(self, m: torch.Tensor) -> torch.Tensor:
-        return ((m[..., None] & self._bits) != 0).sum(-1)
+        return self._members(m).sum(-1)
 
     def _valid_slots(self) -> torch.Tensor:
         filled = torch.clamp(self.cursor.long(), max=self.K)                       # [B]
@@ -60,12 +76,11 @@ class RoundReplay:
         e, k = idx // self.K, idx % self.K
         mask = self.acted[e, k]
         # pick the j-th acting agent uniformly
-        bits = (mask[:, None] & self._bits) != 0                                   # [bs, N]
+        bits = self._members(mask)                                                 # [bs, N]
         u = torch.rand(batch_size, device=dev, generator=generator)
         target = (u * bits.sum(1)).floor().long().clamp(max=self.n - 1)
         order = torch.cumsum(bits.long(), dim=1) - 1
         agent = ((order == target[:, None]) & bits).float().argmax(dim=1)
-        abit = self._bits[agent]
         ret = torch.zeros(batch_size, device=dev)
         boot_w = torch.ones(batch_size, device=dev)
         alive = torch.ones(batch_size, dtype=torch.bool, device=dev)
@@ -74,11 +89,11 @@ class RoundReplay:
         newest = (self.cursor[e].long() - 1) % self.K
         kk = k.clone()
         for j in range(n_step):
-            ok = alive & (self.episode[e, kk] == ep0) & ((self.acted[e, kk] & abit) != 0) & valid[e, kk]
+            ok = alive & (self.episode[e, kk] == ep0) & self._has(self.acted[e, kk], agent) & valid[e, kk]
             ret = ret + torch.where(ok, (gamma ** j) * self.rew[e, kk, agent], torch.zeros((), device=dev))
             boot_slot = torch.where(ok, kk, boot_slot)
             boot_w = torch.where(ok, torch.full((), gamma ** (j + 1), device=dev), boot_w)
-            finished = ok & ((self.done[e, kk] & abit) != 0)
+            finished = ok & self._has(self.done[e, kk], agent)
             boot_w = torch.where(finished, torch.zeros((), device=dev), boot_w)
             alive = ok & ~finished & (kk != newest)          # cannot walk past the newest record
             kk = (kk + 1) % self.K
@@ -96,7 +111,7 @@ class RoundReplay:
         (rows ordered by experience, then agent id) for :class:`melissa_amd.policy.DGNPolicy`."""
         b = self.sample(batch_size, n_step, gamma, generator)
         e, k = b["env"], b["slot"]
-        bits = (self.acted[e, k][:, None] & self._bits) != 0                       # [bs, N]
+        bits = self._members(self.acted[e, k])                                     # [bs, N]
         seg, agent = torch.nonzero(bits, as_tuple=True)                            # row-major: by experience, then id
         obs = torch.cat([self.obs[e[seg], k[seg]], agent.float()[:, None]], dim=1)
         b.update(active_obs=obs, active_act=self.act[e[seg], k[seg], agent].long(), segment=seg, sibling_mask=self.acted[e, k])
@@ -117,7 +132,7 @@ class RoundReplay:
         env = torch.arange(B, device=start.device)[:, None].expand(B, K)
         ok = valid.gather(1, order)
         e, k = env[ok], order[ok]
-        bits = (self.acted[e, k][:, None] & self._bits) != 0
+        bits = self._members(self.acted[e, k])
         rec, agent = torch.nonzero(bits, as_tuple=True)
         T = rec.numel()
         row_of = torch.full((e.numel(), n), -1, dtype=torch.int64, device=start.device)
@@ -126,7 +141,7 @@ class RoundReplay:
         idx_col = agent.float()[:, None]
         out = dict(obs=torch.cat([self.obs[ee, kk], idx_col], 1), obs_next_matrix=self.obs_next[ee, kk],
                    act=self.act[ee, kk, agent].long(), rew=self.rew[ee, kk], rew_agent=self.rew[ee, kk, agent],
-                   done=(self.done[ee, kk] & self._bits[agent]) != 0, env_id=ee, agent_id=agent,
+                   done=self._has(self.done[ee, kk], agent), env_id=ee, agent_id=agent,
                    buffer_id=ee * n + agent, record_slot=kk, episode=self.episode[ee, kk].long(), indices=row_of[rec])
         return {name: t.cpu().numpy() for name, t in out.items()}
 

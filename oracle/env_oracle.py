@@ -26,7 +26,8 @@ default ratio 0 ``dm_flag`` is 1 for every node and ``World.step``'s scripted br
 are empty loops.
 
 Representation: node sets are Python ints used as N-bit masks (bit i = node i); this is exactly the
-layout the HIP kernels use (one uint64 per set, N <= 64).
+layout the HIP kernels use (one uint64 per set for N <= 64, two 64-bit words - low word first - for the reference's
+100-node size).
 """
 from __future__ import annotations
 
@@ -135,7 +136,7 @@ class OracleGraphEnv:
         if self.is_testing:
             testing_generator = np.random.RandomState(17)
             self.test_seeds_list = [testing_generator.randint(0, 1e9) for _ in range(self.num_test_episodes)]
-        assert 1 <= self.n <= 64
+        assert 1 <= self.n <= 128
         self.full = (1 << self.n) - 1
         self.radius = radius
         self.local_ratio = local_ratio

@@ -80,6 +80,14 @@ def mask_of(names):
     return m
 
 
+def words(m, n):
+    """A node set as stored in the traces: np.uint64 up to 64 nodes (the layout the HIP kernels use), an array of
+    ceil(n / 64) 64-bit words (low word first) beyond."""
+    if n <= 64:
+        return np.uint64(m)
+    return np.array([(m >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range((n + 63) // 64)], dtype=np.uint64)
+
+
 def record(rows, pz, packed, n):
     obs, term, trunc, info = packed
     env = pz.env
@@ -98,17 +106,17 @@ def record(rows, pz, packed, n):
     rows["has_stats"].append(stats is not None)
     rows["stats"].append(np.array([float(stats[k]) for k in LOGGER_KEYS] if stats is not None
                                   else [0.0] * len(LOGGER_KEYS), dtype=np.float64))
-    rows["agents_mask"].append(np.uint64(mask_of(env.agents)))
-    rows["alive_mask"].append(np.uint64(mask_of(env.terminations.keys())))
-    rows["terminated_mask"].append(np.uint64(mask_of(k for k, v in env.terminations.items() if v)))
-    rows["has_message_mask"].append(np.uint64(mask_of(a.name for a in w.agents if a.state.has_message)))
-    rows["interested_mask"].append(np.uint64(mask_of(a.name for a in w.agents if a.is_interested)))
-    rows["scripted_mask"].append(np.uint64(mask_of(a.name for a in w.agents if a.is_scripted)))
+    rows["agents_mask"].append(words(mask_of(env.agents), n))
+    rows["alive_mask"].append(words(mask_of(env.terminations.keys()), n))
+    rows["terminated_mask"].append(words(mask_of(k for k, v in env.terminations.items() if v), n))
+    rows["has_message_mask"].append(words(mask_of(a.name for a in w.agents if a.state.has_message), n))
+    rows["interested_mask"].append(words(mask_of(a.name for a in w.agents if a.is_interested), n))
+    rows["scripted_mask"].append(words(mask_of(a.name for a in w.agents if a.is_scripted), n))
     rows["origin"].append(int(w.origin_agent))
     rows["pos"].append(np.array([a.pos for a in w.agents], dtype=np.float64))
-    rows["one_hop"].append(np.array([mask_of(np.where(a.one_hop_neighbours_ids)[0]) for a in w.agents],
+    rows["one_hop"].append(np.array([words(mask_of(np.where(a.one_hop_neighbours_ids)[0]), n) for a in w.agents],
                                     dtype=np.uint64))
-    rows["two_hop"].append(np.array([mask_of(np.where(a.two_hop_neighbours_ids)[0]) for a in w.agents],
+    rows["two_hop"].append(np.array([words(mask_of(np.where(a.two_hop_neighbours_ids)[0]), n) for a in w.agents],
                                     dtype=np.uint64))
 
 
@@ -155,12 +163,12 @@ def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=No
                                          dynamic_graph=dynamic, local_ratio=local_ratio)
             meta["pool_pos"] = np.array([[gg.nodes[i]["pos"] for i in range(n)] for gg in pool],
                                         dtype=np.float64)
-            adj = np.zeros((len(pool), n), dtype=np.uint64)
+            adj_int = [[0] * n for _ in pool]
             for k, gg in enumerate(pool):
                 for u, v in gg.edges():
-                    adj[k, u] |= np.uint64(1 << v)
-                    adj[k, v] |= np.uint64(1 << u)
-            meta["pool_adj"] = adj
+                    adj_int[k][u] |= 1 << v
+                    adj_int[k][v] |= 1 << u
+            meta["pool_adj"] = np.array([[words(m, n) for m in row] for row in adj_int], dtype=np.uint64)
             pz = RefPettingZoo(env)
             tape = np.random.RandomState(tape_seed).randint(0, 2, size=steps).astype(np.int8)
             rows = {k: [] for k in ("agent_id obs mask rew term trunc env_step environment_step "
@@ -198,7 +206,14 @@ def run_trace(name, n, mode, dynamic, steps, env_seed, tape_seed, local_ratio=No
     print(f"{name}: {len(out['agent_id'])} rows, {n_reset} resets -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
-def main():
+def main(only=None):
+    if only == "n100":          # the reference CLI's third size (--n-agents 100, common.py:49): two-word node sets
+        run_trace("n100_pool_dynamic", 100, "pool", True, 700, env_seed=23, tape_seed=13, n_graphs=4)
+        run_trace("n100_pool_static_lr", 100, "pool", False, 400, env_seed=24, tape_seed=14, local_ratio=0.5, n_graphs=3)
+        run_trace("n100_scripted_broadcast", 100, "pool", True, 400, env_seed=25, tape_seed=15, n_graphs=3,
+                  scripted_agents_ratio=0.3, heuristic="simple_broadcast")
+        run_trace("n70_testing_dynamic", 70, "testing", True, 500, env_seed=26, tape_seed=16, n_graphs=4, num_test_episodes=6)
+        return
     run_trace("n20_pool_static", 20, "pool", False, 700, env_seed=11, tape_seed=1)
     run_trace("n20_pool_dynamic", 20, "pool", True, 700, env_seed=12, tape_seed=2)
     run_trace("n50_pool_dynamic", 50, "pool", True, 900, env_seed=13, tape_seed=3)
@@ -218,5 +233,8 @@ def main():
               scripted_agents_ratio=0.5, heuristic="silent")
 
 
+    main("n100")
+
+
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

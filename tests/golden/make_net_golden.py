@@ -108,6 +108,12 @@ def make(name, n, rows, seed, weight_seed):
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    make("n20", 20, 28, seed=21, weight_seed=9)
-    make("n50", 50, 12, seed=22, weight_seed=9)
-    make("n12", 12, 6, seed=23, weight_seed=5)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in (None, "n20"):
+        make("n20", 20, 28, seed=21, weight_seed=9)
+    if only in (None, "n50"):
+        make("n50", 50, 12, seed=22, weight_seed=9)
+    if only in (None, "n12"):
+        make("n12", 12, 6, seed=23, weight_seed=5)
+    if only in (None, "n100"):      # the reference CLI's third size (--n-agents 100): two-word node sets in the kernels
+        make("n100", 100, 8, seed=24, weight_seed=9)

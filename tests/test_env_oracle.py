@@ -7,14 +7,14 @@ import numpy as np
 import pytest
 
 from oracle import env_oracle as eo
-from tests.trace_replay import replay, scripted_kwargs
+from tests.trace_replay import replay, scripted_kwargs, set_ints
 
 TRACES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "env_trace_*.npz")))
 
 
 def build_oracle_env(tr):
     n = int(tr["n"])
-    pool = [eo.GraphSpec(tr["pool_pos"][k], [int(x) for x in tr["pool_adj"][k]])
+    pool = [eo.GraphSpec(tr["pool_pos"][k], set_ints(tr["pool_adj"][k]))
             for k in range(tr["pool_pos"].shape[0])]
     lr = float(tr["local_ratio"])
     kw = dict(number_of_agents=n, dynamic_graph=bool(tr["dynamic"]),

@@ -37,7 +37,7 @@ def make(model, n, seed=9):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16", "f32s"])
 @pytest.mark.parametrize("model", ["l_dgn", "dgn_r", "hl_dgn"])
-@pytest.mark.parametrize("n,bs", [(20, 512), (50, 700)])
+@pytest.mark.parametrize("n,bs", [(20, 512), (50, 700), (100, 640)])
 def test_table_path_is_bit_identical_to_row_lists(model, n, bs, dtype):
     obs = torch.from_numpy(env_like_obs(n, bs, 5 + n)).cuda()
     net, _ = make(model, n)

@@ -38,9 +38,9 @@ def test_ldgn_matches_golden(path):
     assert state is None and logits.is_cuda and logits.dtype == torch.float32
     np.testing.assert_allclose(logits.cpu().numpy(), g["ldgn_logits"], atol=TOL, rtol=0)
     # intermediates: adjacency bit-exact, head input (x_1 | x_2 | x_3) within tolerance
-    adj = net.hip_tap(0, obs.shape[0]).cpu().numpy().view(np.uint64)
-    want = np.unpackbits(g["adj"], axis=-1, bitorder="little")[..., :n].astype(np.uint64)
-    want = (want << np.arange(n, dtype=np.uint64)).sum(axis=-1, dtype=np.uint64)
+    from melissa_amd.env.episodes import sets_to_bool
+    adj = sets_to_bool(net.hip_tap(0, obs.shape[0]).cpu().numpy().view(np.uint64), n)      # [bs, n, n] membership
+    want = np.unpackbits(g["adj"], axis=-1, bitorder="little")[..., :n].astype(bool)
     np.testing.assert_array_equal(adj, want)
     xcat = net.hip_tap(1, obs.shape[0]).cpu().numpy()
     np.testing.assert_allclose(xcat, np.concatenate([g["ldgn_x_1"], g["ldgn_x_2"], g["ldgn_x_3"]], axis=1),

@@ -42,13 +42,14 @@ def make(model, n, agg="max"):
 def test_radius_graph_matches_dense_rule():
     from melissa_amd.networks.autograd_ops import radius_graph
     from melissa_amd.networks.common import radius_adjacency
-    for n, bs in [(20, 33), (50, 64), (64, 5), (1, 3)]:
+    from melissa_amd.env.episodes import sets_to_bool
+    for n, bs in [(20, 33), (50, 64), (64, 5), (1, 3), (100, 9), (128, 4), (65, 3)]:
         obs = torch.from_numpy(random_obs(n, bs, n + bs)).cuda()
-        if n == 64:
+        if n in (64, 128):
             obs[:, :-1].view(bs, n, 8)[:, :, 0:2] *= 0.2          # dense clique: exercises the 32-neighbour cap
-        adj = radius_graph(obs, n, 5).view(bs, n).cpu().numpy().view(np.uint64)
+        adj = radius_graph(obs, n, 5).view(bs, n, -1).squeeze(-1).cpu().numpy().view(np.uint64)
         want = radius_adjacency(obs[:, :-1].view(bs, n, 8)[:, :, :2]).cpu().numpy()          # [bs, i, j]
-        got = ((adj[:, :, None] >> np.arange(n, dtype=np.uint64)) & np.uint64(1)).astype(bool)
+        got = sets_to_bool(adj, n)
         np.testing.assert_array_equal(got, want)
 
 
@@ -70,7 +71,7 @@ def oracle_loss_and_grads(model, agg, sd, obs_np, n, act_np, target_np, dueling=
 
 
 @pytest.mark.parametrize("model,agg", [("l_dgn", "max"), ("dgn_r", "max"), ("hl_dgn", "max"), ("hl_dgn", "mean"), ("hl_dgn", "add")])
-@pytest.mark.parametrize("n,bs", [(20, 48), (50, 16), (7, 3)])
+@pytest.mark.parametrize("n,bs", [(20, 48), (50, 16), (7, 3), (100, 6)])
 def test_hip_autograd_matches_oracle_autograd(model, agg, n, bs):
     from oracle import net_oracle as no
     obs_np = random_obs(n, bs, 300 + n)

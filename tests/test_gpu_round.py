@@ -6,6 +6,20 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+from tests.trace_replay import set_int, set_ints      # node sets in any form (uint64 scalar / words beyond 64 nodes) -> int
+
+
+def agent_masks(bs, n):
+    """Zeroed agent-set array in the ABI's layout: uint64 [bs] up to 64 nodes, [bs, 2] words beyond."""
+    return np.zeros((bs,) if n <= 64 else (bs, (n + 63) // 64), dtype=np.uint64)
+
+
+def add_agent(masks, b, a):
+    if masks.ndim == 1:
+        masks[b] |= np.uint64(1) << np.uint64(a)
+    else:
+        masks[b, a // 64] |= np.uint64(1) << np.uint64(a % 64)
 TOL = 1e-4
 DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
 
@@ -31,17 +45,17 @@ def random_obs_matrix(rng, bs, n):
 
 
 @pytest.mark.parametrize("model", ["l_dgn", "dgn_r"])
-@pytest.mark.parametrize("n,bs", [(20, 64), (50, 40), (64, 9), (5, 7)])
+@pytest.mark.parametrize("n,bs", [(20, 64), (50, 40), (64, 9), (5, 7), (100, 12), (65, 5), (128, 3)])
 def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs, model):
     from oracle import net_oracle as no
     rng = np.random.RandomState(n * 100 + bs)
     mat = random_obs_matrix(rng, bs, n)
-    masks = np.zeros(bs, dtype=np.uint64)
+    masks = agent_masks(bs, n)
     rows = []
     for b in range(bs):
         k = rng.randint(0, min(n, 12) + 1)                     # 0..12 agents, some envs with none
         for a in sorted(rng.choice(n, size=k, replace=False)):
-            masks[b] |= np.uint64(1) << np.uint64(a)
+            add_agent(masks, b, int(a))
             rows.append((b, int(a)))
     net, sd = make_ldgn(n, model=model)
     cap = bs * n
@@ -50,7 +64,7 @@ def test_forward_agents_rows_match_oracle_and_per_row_forward(n, bs, model):
         logits, offsets = net.hip_forward_agents(obs_matrix, torch.from_numpy(masks.view(np.int64)).cuda(), cap)
     offsets = offsets.cpu().numpy()
     assert offsets[-1] == len(rows)
-    assert list(offsets[:-1]) == list(np.concatenate([[0], np.cumsum([bin(int(m)).count("1") for m in masks])])[:-1])
+    assert list(offsets[:-1]) == list(np.concatenate([[0], np.cumsum([bin(set_int(m)).count("1") for m in masks])])[:-1])
     # the same (env, agent) rows as explicit observation rows with the index column
     obs_rows = np.concatenate([mat.reshape(bs, -1)[[b for b, _ in rows]],
                                np.array([[a] for _, a in rows], dtype=np.float32)], axis=1)
@@ -96,7 +110,8 @@ def oracle_round(pz, act_of_agent):
 
 @pytest.mark.parametrize("n,dynamic,supply", [(20, True, "table"), (12, False, "table"), (50, True, "table"),
                                                (50, False, "table"), (20, True, "stream"), (12, False, "stream"),
-                                               (50, True, "stream")])
+                                               (50, True, "stream"), (100, True, "table"), (100, True, "stream"),
+                                               (70, False, "stream")])
 def test_round_loop_matches_oracle(n, dynamic, supply):
     """``supply`` "stream": the episodes come from the device sampler through a 5-slot ring (3 slots at N = 50; refilled every 2 rounds - every round -
     on a side stream), so every env's k-th reset - far beyond the first ring - must equal the oracle env's k-th reset."""
@@ -126,7 +141,7 @@ def test_round_loop_matches_oracle(n, dynamic, supply):
                          episodes=({k: v for k, v in packed.items()}, np.ascontiguousarray(table[:, 1:])))
     refs = []
     for b in range(B):
-        env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in graphs],
+        env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), set_ints(g.one_hop)) for g in graphs],
                                 dynamic_graph=dynamic,
                                 np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))))
         pz = eo.OraclePettingZooEnv.__new__(eo.OraclePettingZooEnv)
@@ -138,14 +153,14 @@ def test_round_loop_matches_oracle(n, dynamic, supply):
     for it in range(K):
         live = loop.live.cpu().numpy().view(np.uint64).copy()
         for b, pz in enumerate(refs):
-            assert int(live[b]) == pz.env.sel_active, (it, b)
+            assert set_int(live[b]) == pz.env.sel_active, (it, b)
         mat = venv.obs_matrix().cpu().numpy().copy()
         loop.step()
         torch.cuda.synchronize()
         offsets = loop.offsets.cpu().numpy()
         act = loop.act.cpu().numpy()
         logits = loop.logits.cpu().numpy()
-        rows = [(b, a) for b in range(B) for a in range(n) if (int(live[b]) >> a) & 1]
+        rows = [(b, a) for b in range(B) for a in range(n) if (set_int(live[b]) >> a) & 1]
         assert offsets[-1] == len(rows)
         if rows:
             obs_rows = np.concatenate([mat[[b for b, _ in rows]], np.array([[a] for _, a in rows], np.float32)], axis=1)
@@ -155,16 +170,16 @@ def test_round_loop_matches_oracle(n, dynamic, supply):
         cursor = replay.cursor.cpu().numpy()
         for b, pz in enumerate(refs):
             np.testing.assert_array_equal(mat[b].reshape(n, 8), pz.env.obs_matrix)
-            acts = {a: act[offsets[b] + k] for k, a in enumerate(a for a in range(n) if (int(live[b]) >> a) & 1)}
+            acts = {a: act[offsets[b] + k] for k, a in enumerate(a for a in range(n) if (set_int(live[b]) >> a) & 1)}
             ep_before = pz.env_episode = getattr(pz, "env_episode", 0)
             outcome = oracle_round(pz, acts)
-            if int(live[b]):                                   # the replay record of this round
+            if set_int(live[b]):                               # the replay record of this round
                 slot = (int(cursor[b]) - 1) % replay.K
                 assert outcome is not None
                 np.testing.assert_array_equal(replay.obs[b, slot].cpu().numpy(), mat[b])
                 np.testing.assert_array_equal(replay.obs_next[b, slot].cpu().numpy(), outcome["obs_next"].reshape(-1))
-                assert int(replay.acted[b, slot].cpu().numpy().view(np.uint64)) == int(live[b])
-                assert int(replay.done[b, slot].cpu().numpy().view(np.uint64)) == outcome["terminated"] & int(live[b])
+                assert set_int(replay.acted[b, slot].cpu().numpy().view(np.uint64)) == set_int(live[b])
+                assert set_int(replay.done[b, slot].cpu().numpy().view(np.uint64)) == outcome["terminated"] & set_int(live[b])
                 rec_act, rec_rew = replay.act[b, slot].cpu().numpy(), replay.rew[b, slot].cpu().numpy()
                 for a_id, a_val in acts.items():
                     assert rec_act[a_id] == a_val
@@ -176,11 +191,11 @@ def test_round_loop_matches_oracle(n, dynamic, supply):
         one_hop = venv.one_hop().cpu().numpy().view(np.uint64)
         for b, pz in enumerate(refs):
             e = pz.env
-            assert int(s[b, L.SET_HAS_MESSAGE]) == e.has_message and int(s[b, L.SET_AGENTS]) == e.agents
-            assert int(s[b, L.SET_TERMINATED]) == e.terminated and int(s[b, L.SET_ALIVE]) == e.alive
+            assert set_int(s[b, L.SET_HAS_MESSAGE]) == e.has_message and set_int(s[b, L.SET_AGENTS]) == e.agents
+            assert set_int(s[b, L.SET_TERMINATED]) == e.terminated and set_int(s[b, L.SET_ALIVE]) == e.alive
             assert int(sc[b, L.S_SELECTION]) == e.agent_selection and int(sc[b, L.S_NUM_MOVES]) == e.num_moves
             np.testing.assert_array_equal(pos[b], e.pos)
-            assert [int(x) for x in one_hop[b]] == e.adj
+            assert set_ints(one_hop[b]) == e.adj
     c = loop.counters()
     assert c["errors"] == 0 and c["episodes"] >= 3 and checked_rows > 100 and recorded_rounds > 100
     if supply == "stream":                     # every env went round its ring at least once
@@ -270,7 +285,7 @@ def test_replay_sampling_and_dqn_learner():
     assert any(k.startswith("model_old.") for k in policy.state_dict())
 
 
-@pytest.mark.parametrize("n", [20, 50])
+@pytest.mark.parametrize("n", [20, 50, 100])
 @pytest.mark.parametrize("scripted", [None, (0.3, "simple_broadcast"), (0.4, "broadcast_if_any_interested")],
                          ids=["all-policy", "scripted-broadcast", "scripted-interested"])
 def test_hldgn_round_loop_matches_oracle(scripted, n):
@@ -298,7 +313,7 @@ def test_hldgn_round_loop_matches_oracle(scripted, n):
                      episodes=(packed, np.ascontiguousarray(table[:, 1:])))
     refs = []
     for b in range(B):
-        env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in graphs],
+        env = eo.OracleGraphEnv(n, graph_pool=[eo.GraphSpec(g.pos.copy(), set_ints(g.one_hop)) for g in graphs],
                                 dynamic_graph=True,
                                 np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed + b))), **skw)
         pz = eo.OraclePettingZooEnv.__new__(eo.OraclePettingZooEnv)
@@ -312,7 +327,7 @@ def test_hldgn_round_loop_matches_oracle(scripted, n):
         if scripted:
             sets = venv.node_sets().cpu().numpy().view(np.uint64)
             for b, pz in enumerate(refs):
-                assert int(sets[b, L.SET_SCRIPTED]) == pz.env.scripted and int(live[b]) & pz.env.scripted == 0
+                assert set_int(sets[b, L.SET_SCRIPTED]) == pz.env.scripted and set_int(live[b]) & pz.env.scripted == 0
                 saw_scripted |= pz.env.scripted != 0
         loop.step()
         torch.cuda.synchronize()
@@ -322,12 +337,12 @@ def test_hldgn_round_loop_matches_oracle(scripted, n):
         want = no.hldgn_forward(sd, obs_rows, n, aggregator="max").numpy()
         np.testing.assert_allclose(logits, want, atol=TOL, rtol=0)
         for b, pz in enumerate(refs):
-            acts = {a: act[b, a] for a in range(n) if (int(live[b]) >> a) & 1}
+            acts = {a: act[b, a] for a in range(n) if (set_int(live[b]) >> a) & 1}
             assert all(v == int(np.argmax(logits[b])) for v in acts.values())
             oracle_round(pz, acts)
         s = venv.node_sets().cpu().numpy().view(np.uint64)
         for b, pz in enumerate(refs):
-            assert int(s[b, L.SET_HAS_MESSAGE]) == pz.env.has_message and int(s[b, L.SET_AGENTS]) == pz.env.agents
+            assert set_int(s[b, L.SET_HAS_MESSAGE]) == pz.env.has_message and set_int(s[b, L.SET_AGENTS]) == pz.env.agents
             np.testing.assert_array_equal(venv.positions()[b].cpu().numpy(), pz.env.pos)
     assert loop.counters()["errors"] == 0
     assert saw_scripted == bool(scripted)

@@ -7,6 +7,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+from tests.trace_replay import set_int      # node sets (uint64 scalar, or words beyond 64 nodes) -> int
 DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
 
 
@@ -21,7 +23,8 @@ def _expected(venv, seed, count):
 
 @pytest.mark.parametrize("n,n_graphs,dynamic,density,fixed", [(20, 5, True, None, False), (50, 64, True, None, False),
                                                                (64, 3, True, None, False), (12, 7, False, 0.35, False),
-                                                               (20, 1, False, None, True), (50, 50000, True, None, False)])
+                                                               (20, 1, False, None, True), (50, 50000, True, None, False),
+                                                               (100, 4, True, None, False), (70, 3, False, 0.6, False)])
 def test_device_sampler_matches_numpy_protocol(n, n_graphs, dynamic, density, fixed):
     from melissa_amd import _lib as L
     from melissa_amd.env import Graph, HipGraphVectorEnv, synthetic_graph_pool
@@ -52,7 +55,7 @@ def test_device_sampler_matches_numpy_protocol(n, n_graphs, dynamic, density, fi
                 slot = b * K + j % K
                 ep = want[b][j + discard]
                 g = graphs[ep.graph_index]
-                assert t["origin"][slot] == ep.origin and int(t["interested"][slot].view(np.uint64)) == ep.interested, (b, j)
+                assert t["origin"][slot] == ep.origin and set_int(t["interested"][slot]) == ep.interested, (b, j)
                 np.testing.assert_array_equal(t["pos"][slot], g.pos)
                 np.testing.assert_array_equal(t["one_hop"][slot].view(np.uint64), g.one_hop)
                 if dynamic:

@@ -283,17 +283,32 @@ def test_bench_cpu_baseline_variants_run():
     assert ft["conv1_lin"] == 2.0 * 4000 * 512 * 128 and ft["encoder"] == 2000 * 34048 and ft["conv2_lin"] == fl["conv2_lin"]
 
 
-def test_graphs_beyond_64_nodes_are_refused_up_front():
-    """The reference CLI offers --n-agents 100 (common.py:49); the kernels hold one node per wavefront lane, so that size is
-    refused by the constructors with a clear message instead of failing at the first launch."""
-    with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
-        LDGNNetwork(5, 128, 2, 4, 100, dueling_param=DUEL(), backend="torch")
-    with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
-        HLDGNNetwork(5, 128, 2, 4, 65, aggregator="max", dueling_param=DUEL(), backend="torch")
+def test_graph_size_limits_and_two_word_node_sets():
+    """The reference CLI offers --n-agents 20 / 50 / 100 (common.py:49): all three are accepted (beyond 64 nodes a node set is
+    two 64-bit words); beyond 128 nodes the constructors refuse up front with a clear message."""
+    from melissa_amd.env.episodes import Graph, int_to_set, pack_episodes, set_to_int, sets_to_bool, Episode
+    with pytest.raises(ValueError, match="outside \\[1, 128\\]"):
+        LDGNNetwork(5, 128, 2, 4, 129, dueling_param=DUEL(), backend="torch")
     from melissa_amd.env import HipGraphVectorEnv
-    with pytest.raises(ValueError, match="outside \\[1, 64\\]"):
-        HipGraphVectorEnv(2, 100, graph_pool=synthetic_graph_pool(12, 1, 0), device="cpu")
-    LDGNNetwork(5, 128, 2, 4, 64, dueling_param=DUEL(), backend="torch")
+    with pytest.raises(ValueError, match="outside \\[1, 128\\]"):
+        HipGraphVectorEnv(2, 200, graph_pool=synthetic_graph_pool(12, 1, 0), device="cpu")
+    LDGNNetwork(5, 128, 2, 4, 100, dueling_param=DUEL(), backend="torch")
+    HLDGNNetwork(5, 128, 2, 4, 65, aggregator="max", dueling_param=DUEL(), backend="torch")
+    # packing: node sets of a 100-node graph are [.., 2] words, low word first; up to 64 nodes nothing changes shape
+    g = synthetic_graph_pool(100, 1, 0)[0]
+    assert g.one_hop.shape == (100, 2) and g.one_hop.dtype == np.uint64 and g.is_connected()
+    member = sets_to_bool(g.one_hop, 100)
+    assert member.shape == (100, 100) and (member == member.T).all() and not member.diagonal().any()
+    dx = g.pos[:, None, :] - g.pos[None, :, :]
+    want = ((dx ** 2).sum(-1) <= 0.2 ** 2) & ~np.eye(100, dtype=bool)
+    np.testing.assert_array_equal(member, want)
+    m = (1 << 99) | (1 << 64) | (1 << 63) | 5
+    assert set_to_int(int_to_set(m, 100)) == m and int_to_set(m, 100).tolist() == [(1 << 63) | 5, (1 << 35) | 1]
+    assert int_to_set(5, 50) == np.uint64(5) and set_to_int(np.uint64(5)) == 5
+    p = pack_episodes([Episode(0, 77, m, 1, 0)], [g], 100, 3, True)
+    assert p["one_hop"].shape == (1, 100, 2) and p["interested"].shape == (1, 2) and p["scripted"].shape == (1, 2)
+    assert set_to_int(p["interested"][0]) == m and p["moves"].shape == (1, 3, 2, 100)
+    assert synthetic_graph_pool(50, 1, 0)[0].one_hop.shape == (50,)
 
 
 def test_packed_graph_pool_round_trip(tmp_path):
