@@ -122,11 +122,12 @@ def cpu_baseline(n_nodes, envs=40, warm=3, reps=10, rep_seconds=1.0):
     from oracle import env_oracle as eo
     from oracle import net_oracle as no
     from melissa_amd.env import synthetic_graph_pool
+    from melissa_amd.env.episodes import set_to_int
     # torch's CPU ops on these small tensors get slower past a few dozen threads, so the port uses at most
     # 32 of the host cores (the count actually used is what is reported)
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    pool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
+    pool = [eo.GraphSpec(g.pos.copy(), [set_to_int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
     workers = [eo.OraclePettingZooEnv(eo.OracleGraphEnv(
         n_nodes, graph_pool=pool, dynamic_graph=True,
         np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(1000 + k))))) for k in range(envs)]
@@ -185,7 +186,8 @@ def _env_worker(conn, n_nodes, seeds):
     """One env-worker process of the SubprocVectorEnv-style CPU baseline: owns len(seeds) oracle envs."""
     from oracle import env_oracle as eo
     from melissa_amd.env import synthetic_graph_pool
-    pool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
+    from melissa_amd.env.episodes import set_to_int
+    pool = [eo.GraphSpec(g.pos.copy(), [set_to_int(m) for m in g.one_hop]) for g in synthetic_graph_pool(n_nodes, 8, 0)]
     envs = [eo.OraclePettingZooEnv(eo.OracleGraphEnv(
         n_nodes, graph_pool=pool, dynamic_graph=True,
         np_random=np.random.Generator(np.random.PCG64(np.random.SeedSequence(s))))) for s in seeds]
@@ -562,6 +564,8 @@ def main():
             "config1_ldgn_n20_256envs": dict(note="BASELINE configs[1]: L-DGN 20-node, 256 vectorised envs, fp32", nodes=20, envs=256),
             "config3_hldgn_512envs_per_gpu": dict(note="BASELINE configs[3]'s per-GPU share: HL-DGN 50-node, 4096 envs over 8 GPUs = 512 "
                                                        "per GPU (collect path; its collective is in learner_leg)", model="hl_dgn", envs=512),
+            "ldgn_n100_1024envs": dict(note="the reference CLI's third graph size (--n-agents 100, common.py:49; in no BASELINE config): "
+                                            "two-word node sets, two nodes per wavefront lane - same kernels, same loop", nodes=100),
             "aec_order_loop": dict(note="the reference collector's granularity (multi_agent_collector.py:150-308): one agent decision "
                                         "per env per step", mode="aec"),
             "two_streams": dict(note="the headline workload as two half-batches of 512 envs on two HIP streams, each replaying its own "

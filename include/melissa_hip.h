@@ -188,8 +188,9 @@ typedef struct mel_select {
     uint32_t        seed;
     const uint32_t* step_dev;  /* optional device counter added to the stream position             */
     /* per-env logits (HL-DGN, mel_hldgn_forward_envs_select): every agent i in live[b] takes its action from row b,
-     * act is the dense [bs, n_nodes] layout of mel_select_action_envs and the stream is keyed on b*64 + i          */
-    const uint64_t* live;      /* NULL: one action per logits row                                   */
+     * act is the dense [bs, n_nodes] layout of mel_select_action_envs and the stream is keyed on
+     * b * 64 * MEL_SET_WORDS(n_nodes) + i                                                                           */
+    const uint64_t* live;      /* node sets [bs]; NULL: one action per logits row                   */
     int32_t         n_nodes;
     int32_t         reserved;
 } mel_select;
@@ -312,7 +313,7 @@ mel_status mel_select_action_rows(const float* logits, const int32_t* logit_row,
 
 /* Per-(env, agent) action selection from per-env logits (HL-DGN in the round loop): for every agent i in
  * live[b], act[b, i] = argmax(logits[b]) or, with probability eps, a uniformly random action (same
- * counter-based stream as mel_select_action_rows, keyed on (seed, step + *step_dev, b*64 + i)).
+ * counter-based stream as mel_select_action_rows, keyed on (seed, step + *step_dev, b * 64 * MEL_SET_WORDS(n_nodes) + i)).
  * act: device int32 [bs, n_nodes] (dense layout accepted by mel_env_round when row_offsets is NULL). */
 mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int64_t bs, int32_t n_nodes,
                                   int32_t n_actions, float eps, uint32_t seed, const uint32_t* step_dev,
@@ -320,7 +321,8 @@ mel_status mel_select_action_envs(const float* logits, const uint64_t* live, int
 
 /* ------------------------------------------------------------------------------------------------
  * Environment half.  State of B independent envs lives in caller-owned device memory laid out as
- * struct-of-arrays (one wavefront steps one env, lane = node, node sets = 64-bit masks);
+ * struct-of-arrays (one wavefront steps one env, lane = node - two nodes per lane beyond 64 -, node sets as defined at
+ * MEL_SET_WORDS);
  * mel_env_state_bytes() gives the size, mel_env_bind() carves the pointer table.
  * ------------------------------------------------------------------------------------------------ */
 #define MEL_ENV_LOGGER_STATS  10   /* graph.py:167-177, in dict order                            */

@@ -944,7 +944,7 @@ size_t mel_abi_sizeof(int32_t which) {
         default: return 0;
     }
 }
-const char* mel_version(void) { return "melissa_hip 0.4 (gfx950)"; }
+const char* mel_version(void) { return "melissa_hip 0.5 (gfx950)"; }
 
 size_t mel_prepared_weights_bytes(const mel_weights* w) {
     if (!w || w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_SPLIT) return 0;

@@ -44,8 +44,10 @@ def test_validation_errors_without_gpu(lib):
     w.model = _lib.MODEL_HLDGN
     st = lib.mel_ldgn_forward(C.byref(w), None, 4, 20, 161, None, None, 0, None)
     assert st == _lib.ERR_INVALID_ARG
-    assert lib.mel_env_state_bytes(0, 20) == 0 and lib.mel_env_state_bytes(4, 65) == 0
+    assert lib.mel_env_state_bytes(0, 20) == 0 and lib.mel_env_state_bytes(4, 129) == 0       # MEL_MAX_NODES = 128
     assert lib.mel_env_state_bytes(4, 50) > 0
+    # two-word node sets beyond 64 nodes: the state grows by the second word of every set
+    assert lib.mel_env_state_bytes(4, 100) > 2 * lib.mel_env_state_bytes(4, 50) - 4096
     assert lib.mel_version().startswith(b"melissa_hip")
 
 

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import env_oracle as eo
+from melissa_amd.env.episodes import set_to_int
 from tests.trace_replay import replay, scripted_kwargs, set_ints
 
 TRACES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "env_trace_*.npz")))
@@ -154,7 +155,7 @@ def test_invalid_scripted_ratio_and_heuristic():                              # 
 
 def test_scripted_sampling_reproducible_and_partition():                      # test_mixed...py:53-100
     mk = lambda s: np.random.Generator(np.random.PCG64(np.random.SeedSequence(s)))
-    pool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in
+    pool = [eo.GraphSpec(g.pos.copy(), [set_to_int(m) for m in g.one_hop]) for g in
             __import__("melissa_amd.env", fromlist=["synthetic_graph_pool"]).synthetic_graph_pool(20, 2, 50)]
     env = eo.OracleGraphEnv(20, graph_pool=pool, np_random=mk(1), scripted_agents_ratio=0.3, heuristic=None)
     env.reset(seed=123)

@@ -6,6 +6,7 @@ import torch
 
 from melissa_amd.env.episodes import (EpisodeSampler, Graph, movement_offsets, pack_episodes,
                                       synthetic_graph_pool)
+from melissa_amd.env.episodes import set_to_int
 from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
 from melissa_amd.policy import DQNPolicy, MultiAgentSharedPolicy
 from oracle import env_oracle as eo
@@ -256,7 +257,7 @@ def test_construct_time_samplings_line_up_with_the_wrapped_oracle():
     many, so its first reset() yields the sampler's 4th episode - what __graft_entry__.smoke() relies on."""
     n = 20
     pool = synthetic_graph_pool(n, 3, 10)
-    opool = [eo.GraphSpec(g.pos.copy(), [int(m) for m in g.one_hop]) for g in pool]
+    opool = [eo.GraphSpec(g.pos.copy(), [set_to_int(m) for m in g.one_hop]) for g in pool]
     mk = lambda: np.random.Generator(np.random.PCG64(np.random.SeedSequence(7)))
     sampler = EpisodeSampler(n, mk(), 3, False)
     episodes = [sampler.sample() for _ in range(5)]

@@ -5,12 +5,13 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.test_gpu_round as t
 for n, dyn, supply in ((50, True, "table"), (33, True, "stream"), (64, True, "stream"), (7, False, "table"), (20, False, "stream"),
-                       (12, True, "table"), (50, False, "stream"), (41, True, "stream"), (64, False, "table"), (50, True, "stream")):
+                       (12, True, "table"), (50, False, "stream"), (41, True, "stream"), (64, False, "table"), (50, True, "stream"),
+                       (100, True, "stream"), (65, True, "table"), (128, False, "stream"), (100, False, "table"), (97, True, "stream")):
     t0 = time.time()
     t.test_round_loop_matches_oracle(n, dyn, supply)
     print(f"l_dgn round loop n={n} dynamic={dyn} episodes={supply}: bit-exact env state + logits within 1e-4 of the oracle "
           f"({time.time() - t0:.1f} s)", flush=True)
-for n in (20, 50, 37):
+for n in (20, 50, 37, 100):
     for scripted in (None, (0.3, "simple_broadcast"), (0.4, "broadcast_if_any_interested"), (0.5, "silent"), (0.2, "simple_broadcast")):
         t0 = time.time()
         t.test_hldgn_round_loop_matches_oracle(scripted, n)
