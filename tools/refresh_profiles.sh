@@ -24,6 +24,8 @@ rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json       # bench.py reads roofline.traffic from profiles/ (hash-checked)
 python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.log
 echo "bench line done"
-python3 tools/soak_parity.py > $OUT/${TAG}_soak_parity.log 2>&1 || echo "SOAK FAILED"
-tail -2 $OUT/${TAG}_soak_parity.log
+if [ -z "$NO_SOAK" ]; then       # NO_SOAK=1: the soak (15-20 min with the 100-node cases) runs in its own gpurun call
+  python3 tools/soak_parity.py ldgn > $OUT/${TAG}_soak_parity.log 2>&1 || echo "SOAK FAILED"
+  tail -2 $OUT/${TAG}_soak_parity.log
+fi
 tail -c 400 $OUT/${TAG}_bench_line.json
