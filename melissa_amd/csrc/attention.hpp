@@ -21,14 +21,7 @@ struct AttArgs {
     int ld_r;
     const float* att;       // [heads*C]
     const float* bias;      // [heads*C]
-    // node sets: MEL_SET_WORDS(n) words each
-    const uint64_t* adj;    // [bs*N]
-    const uint64_t* live;   // [bs] controlling agents (ATT_ROWS: whose x_1 / x_2 go to the head input)
-    const uint64_t* tmask;  // [bs] targets, or null = all nodes
-    const uint64_t* smask;  // [bs] set the source rows are packed by, or null = all nodes
-    const int32_t* toff;    // [bs] first target row, or null = b*N
-    const int32_t* soff;    // [bs] first source row, or null = b*N
-    const int32_t* loff;    // [bs+1] first agent row of the env (ATT_ROWS) / row count at [bs] (ATT_SINGLE)
+    const uint64_t* adj;    // [bs*N] node sets (MEL_SET_WORDS(n) words each): ATT_POOL; the row kernels read TargetDesc
     int bs, n, lanes_per_head;
     int kind;               // MEL_CONV_*
     float score_scale;      // TransformerConv: 1 / sqrt(C)

@@ -845,8 +845,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         AttArgs a{};
         a.xl = ft.xl, a.ld_l = srcw, a.xr = ft.xr, a.ld_r = hc, a.att = w->conv1.att, a.bias = w->conv1.bias;
         a.kind = w->conv1.kind, a.score_scale = 1.0f / sqrtf((float)w->conv1.channels), a.bf16 = bf;
-        a.adj = L.plan.adj, a.live = L.plan.live, a.smask = L.plan.u2;
-        a.soff = L.plan.off2, a.loff = L.plan.offL, a.bs = (int)bs, a.n = n;
+        a.adj = L.plan.adj, a.bs = (int)bs, a.n = n;
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = ft.h0;
@@ -873,7 +872,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         AttArgs a{};
         a.xl = L.xl2, a.ld_l = srcw, a.xr = L.xr2, a.ld_r = hc, a.att = w->conv2.att, a.bias = w->conv2.bias;
         a.kind = w->conv2.kind, a.score_scale = 1.0f / sqrtf((float)w->conv2.channels), a.bf16 = bf;
-        a.adj = L.plan.adj, a.smask = L.plan.u1, a.soff = L.plan.off1;
+        a.adj = L.plan.adj;
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
         a.desc = L.plan.desc2, a.rows_dev = nL, a.rows_cap = R, a.rows_hint = hintL;
         a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
