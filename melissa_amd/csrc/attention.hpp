@@ -273,8 +273,11 @@ __device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
 __device__ unsigned long long g_att_prof[8];
 #endif
 
+#ifndef MEL_ATT_MINB
+#define MEL_ATT_MINB 2
+#endif
 template <int VPL, int MODE, int KIND, bool BF, int W>
-__global__ __launch_bounds__(256, 2) void gat_attend_rows_kernel(AttArgs a) {
+__global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttArgs a) {
 #ifdef MEL_ATT_PROF
     const unsigned long long p0 = __builtin_readcyclecounter();
     unsigned long long pd = 0, pa = 0, ps = 0, prows = 0;
