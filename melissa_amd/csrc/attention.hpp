@@ -155,16 +155,15 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 // KIND = MEL_CONV_TRANSFORMER: e = (q[i] . k[j]) / sqrt(C), k | v side by side, out = sum alpha v[j]
 // my_fid: table mode - the tuple ids of this lane's nodes (node lane + 64 h of the target's env); a source row is then the
 // table row of the source's tuple (one v_readlane) instead of its packed position in the row list.
-template <int VPL, int KIND, bool BF, int W>
+template <int VPL, int KIND, bool BF, int W, int G>
 __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_row, NodeSet<W> sources,
                                                   const NodeSet<W>& smask, int soff, const Vec<VPL>& att,
                                                   const Vec<VPL>& bias, int lane, const int (&my_fid)[W]) {
     const bool table = a.fid != nullptr;
     constexpr int HC = 64 * VPL;
-#ifndef MEL_ATT_G
-#define MEL_ATT_G 4      // measured 2 / 3 / 4 / 8 sources per step: 24.9 / 25.9 / 25.7 / 29.9 us (conv1, round loop)
-#endif
-    constexpr int G = MEL_ATT_G;
+    // G = sources per online-softmax step.  Row kernels: 2 - with 4 the kernel needs 112 VGPRs (four waves per SIMD), with 2 it
+    // fits 96 (five): conv1 attention 24.3 -> 22.8 us, conv2 attention 13.4 -> 13.0 us, step 0.2180 -> 0.2142 ms (two A/B
+    // pairs; 3: 24.1 us).  The HL-DGN pool kernel keeps 4 (sixteen waves per env share one workgroup's registers anyway).
     const Vec<VPL> xr = load_row<VPL, BF>(a.xr, xr_row * a.ld_r + lane * VPL);
     float m = -INFINITY, l = 0.f;
     Vec<VPL> acc;
@@ -276,6 +275,9 @@ __device__ unsigned long long g_att_prof[8];
 #ifndef MEL_ATT_MINB
 #define MEL_ATT_MINB 2
 #endif
+#ifndef MEL_ATT_G
+#define MEL_ATT_G 2      // sources per online-softmax step of the row kernels (see attend_target)
+#endif
 template <int VPL, int MODE, int KIND, bool BF, int W>
 __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttArgs a) {
 #ifdef MEL_ATT_PROF
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttA
             MEL_W_FOR(h) my_fid[h] = lane + 64 * h < a.n ? a.fid[(size_t)d.env * a.n + lane + 64 * h] : 0;
             xr_row = (size_t)node_i32<W>(my_fid, d.node);
         }
-        const Vec<VPL> o = attend_target<VPL, KIND, BF, W>(a, xr_row, d.sources, d.smask, d.soff, att, bias, lane, my_fid);
+        const Vec<VPL> o = attend_target<VPL, KIND, BF, W, MEL_ATT_G>(a, xr_row, d.sources, d.smask, d.soff, att, bias, lane, my_fid);
 #ifdef MEL_ATT_PROF
         asm volatile("s_nop 0" ::"v"(o.v[0]));
         const unsigned long long q2 = __builtin_readcyclecounter();
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     for (int t = wave; t < a.n; t += NW) {
         const NodeSet<W> sources = ns_load<W>(a.adj, (size_t)b * a.n + t) | ns_bit<W>(t);
         const size_t xr_row = a.fid ? (size_t)node_i32<W>(my_fid, t) : (size_t)(b * a.n + t);
-        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF, W>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
+        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF, W, 4>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
         // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
         const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
