@@ -38,6 +38,7 @@ PEAK_HBM_GBS = 8000.0            # same guide, HBM3E ~8 TB/s
 N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
 N_GRAPHS, RING = 1024, int(os.environ.get("MEL_BENCH_RING", "16"))
 MAX_MOVES = int(os.environ.get("MEL_BENCH_MAX_MOVES", "48"))      # movement draws kept per episode (tuning knob)
+SETTLE_ROUNDS = 64                                                 # untimed rounds after the first reset (build_workload)
 HC = HIDDEN * HEADS
 
 
@@ -83,6 +84,14 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
     else:
         venv = make_venv(envs, base)
         loop = DecisionLoop(venv, policy, seed=base, eps=0.001)
+    # Untimed settling rounds (set-up, before the W warm-up steps the caller asks for): every env has just been reset, so all
+    # of them start in round 0 of an episode and the first rounds of a run evaluate fewer agents per env than the steady
+    # state does; after SETTLE_ROUNDS the envs' episode phases are decorrelated and a short timed region (the driver's
+    # --steps 20) measures the same loop state as a long one.
+    if mode == "round":
+        with torch.no_grad():
+            loop.run(SETTLE_ROUNDS)
+        torch.cuda.synchronize()
     return net, venv, loop
 
 
@@ -617,7 +626,8 @@ def main():
                                + (f"device episode stream - every reset draws a NEW episode (graph, source, interested set, movement "
                                   f"seed) with the reference's RNG protocol, ring of {supply.get('ring')} slots per env refilled every "
                                   f"{supply.get('refill_every')} steps on a side stream inside the timed region, reset snapshots rebuilt "
-                                  f"by the refill (no episode is ever replayed)" if supply["mode"] == "device stream"
+                                  f"by the refill (no episode is ever replayed); {SETTLE_ROUNDS} untimed settling rounds after the first reset, "
+                                  f"before the warm-up" if supply["mode"] == "device stream"
                                   else f"static table of {supply.get('episodes_per_env')} pre-drawn episodes per env"),
                    "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),
                    "streams": args.streams if args.mode == "round" else 1,
