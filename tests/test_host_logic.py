@@ -6,7 +6,7 @@ import torch
 
 from melissa_amd.env.episodes import (EpisodeSampler, Graph, movement_offsets, pack_episodes,
                                       synthetic_graph_pool)
-from melissa_amd.env.episodes import set_to_int
+from melissa_amd.env.episodes import int_to_set, set_to_int
 from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
 from melissa_amd.policy import DQNPolicy, MultiAgentSharedPolicy
 from oracle import env_oracle as eo
@@ -135,8 +135,9 @@ def _filled_round_replay(n_envs=3, n=6, cap=5, rounds=7, seed=0):
             m = 0
             for a in acted:
                 m |= 1 << int(a)
-            rp.acted[e, k] = m
-            rp.done[e, k] = m if r % 4 == 3 else 0
+            words = torch.from_numpy(np.atleast_1d(int_to_set(m, n)).view(np.int64))       # one word up to 64 nodes, two beyond
+            rp.acted[e, k] = words if n > 64 else words[0]
+            rp.done[e, k] = (words if n > 64 else words[0]) if r % 4 == 3 else 0
             rp.obs[e, k] = torch.from_numpy(rng.uniform(0, 1, 8 * n).astype(np.float32))
             rp.obs_next[e, k] = torch.from_numpy(rng.uniform(0, 1, 8 * n).astype(np.float32))
             rp.act[e, k] = torch.from_numpy(rng.randint(0, 2, n).astype(np.int8))
@@ -146,17 +147,19 @@ def _filled_round_replay(n_envs=3, n=6, cap=5, rounds=7, seed=0):
     return rp
 
 
-def test_export_transitions_sibling_indices():
+@pytest.mark.parametrize("n", [6, 100])
+def test_export_transitions_sibling_indices(n):
     """collective_experience_collector.py:70-80: ``indices[j]`` of an experience = buffer index of agent j's
-    transition of the SAME env round, -1 if agent j did not act; buffer_id = env * N + agent (:251-256)."""
-    rp = _filled_round_replay()
+    transition of the SAME env round, -1 if agent j did not act; buffer_id = env * N + agent (:251-256).
+    (n = 100: the acted / done sets are two 64-bit words.)"""
+    rp = _filled_round_replay(n=n)
     ex = rp.export_transitions()
     T = len(ex["act"])
     assert T == len(rp) and ex["indices"].shape == (T, rp.n)
     key = list(zip(ex["env_id"].tolist(), ex["record_slot"].tolist()))
     for t in range(T):
         e, k, i = int(ex["env_id"][t]), int(ex["record_slot"][t]), int(ex["agent_id"][t])
-        acted = int(rp.acted[e, k])
+        acted = set_to_int(rp.acted[e, k].numpy())
         assert ex["buffer_id"][t] == e * rp.n + i and (acted >> i) & 1
         for j in range(rp.n):
             s = int(ex["indices"][t, j])
@@ -167,7 +170,7 @@ def test_export_transitions_sibling_indices():
         assert ex["indices"][t, i] == t                          # an experience is its own sibling (dgn.py sums it too)
         np.testing.assert_array_equal(ex["obs"][t, :-1], rp.obs[e, k].numpy())
         assert ex["obs"][t, -1] == i and ex["act"][t] == int(rp.act[e, k, i])
-        assert ex["rew_agent"][t] == float(rp.rew[e, k, i]) and bool(ex["done"][t]) == bool((int(rp.done[e, k]) >> i) & 1)
+        assert ex["rew_agent"][t] == float(rp.rew[e, k, i]) and bool(ex["done"][t]) == bool((set_to_int(rp.done[e, k].numpy()) >> i) & 1)
     # oldest first inside an env: record order follows write order
     for e in range(rp.B):
         eps = ex["episode"][ex["env_id"] == e]
@@ -225,14 +228,15 @@ def test_dgn_learn_equals_the_reference_loop():
     assert abs(out2["loss"] - float(want)) < 1e-6
 
 
-def test_sample_collective_siblings_and_dgn_learner_step():
+@pytest.mark.parametrize("n", [6, 70])
+def test_sample_collective_siblings_and_dgn_learner_step(n):
+    from melissa_amd.env.episodes import sets_to_bool
     from melissa_amd.policy import DGNPolicy
     from melissa_amd.replay import DGNLearner
-    n = 6
     rp = _filled_round_replay(n=n)
     g = torch.Generator().manual_seed(3)
     b = rp.sample_collective(16, n_step=2, gamma=0.9, generator=g)
-    bits = ((b["sibling_mask"][:, None] >> torch.arange(n)) & 1).bool()
+    bits = torch.from_numpy(sets_to_bool(b["sibling_mask"].numpy(), n))           # [16, n] (one- or two-word sets)
     assert b["segment"].numel() == int(bits.sum()) and (torch.bincount(b["segment"], minlength=16) == bits.sum(1)).all()
     for r in range(b["segment"].numel()):
         i = int(b["segment"][r])
