@@ -163,7 +163,7 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
     constexpr int HC = 64 * VPL;
     // G = sources per online-softmax step.  Row kernels: 2 - with 4 the kernel needs 112 VGPRs (four waves per SIMD), with 2 it
     // fits 96 (five): conv1 attention 24.3 -> 22.8 us, conv2 attention 13.4 -> 13.0 us, step 0.2180 -> 0.2142 ms (two A/B
-    // pairs; 3: 24.1 us).  The HL-DGN pool kernel keeps 4 (sixteen waves per env share one workgroup's registers anyway).
+    // pairs; 3: 24.1 us).  The HL-DGN pool kernel: 2 as well (MEL_ATT_GP: 39.9 -> 33.5 us; 1: 36.4, 3: 34.5).
     const Vec<VPL> xr = load_row<VPL, BF>(a.xr, xr_row * a.ld_r + lane * VPL);
     float m = -INFINITY, l = 0.f;
     Vec<VPL> acc;
@@ -278,6 +278,12 @@ __device__ unsigned long long g_att_prof[8];
 #ifndef MEL_ATT_G
 #define MEL_ATT_G 2      // sources per online-softmax step of the row kernels (see attend_target)
 #endif
+#ifndef MEL_POOL_NW
+#define MEL_POOL_NW 8    // waves per env of the pool kernel below 2 048 envs (16 -> 8 with two sources per step: 33.4 -> 31.6 us; 12: 35.1)
+#endif
+#ifndef MEL_ATT_GP
+#define MEL_ATT_GP 2     // ... of the HL-DGN pool kernel (4 -> 2: pool attention 39.9 -> 33.5 us, HL-DGN 512 envs 24.4 -> 26.1 M/s)
+#endif
 template <int VPL, int MODE, int KIND, bool BF, int W>
 __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttArgs a) {
 #ifdef MEL_ATT_PROF
@@ -361,7 +367,8 @@ __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttA
 // ATT_POOL (HL-DGN): one workgroup per env (every env has exactly N targets, so this is balanced):
 // conv1 attention for all nodes, decision-maker mask, max / mean / add pool over the graph.
 // NW wavefronts per env: at 512 envs per GPU four waves per workgroup leave a CU with 8 resident waves (two workgroups),
-// too few to hide the source-row latency; sixteen waves (three targets each at N = 50) fill it.
+// too few to hide the source-row latency; eight waves (MEL_POOL_NW; six or seven targets each at N = 50) with two source rows
+// per step measure best (sixteen: 33.4 us, twelve: 35.1, eight: 31.6).
 template <int VPL, bool BF, int NW, int W>
 __global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     constexpr int HC = 64 * VPL;
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void gat_attend_pool_kernel(AttArgs a) {
     for (int t = wave; t < a.n; t += NW) {
         const NodeSet<W> sources = ns_load<W>(a.adj, (size_t)b * a.n + t) | ns_bit<W>(t);
         const size_t xr_row = a.fid ? (size_t)node_i32<W>(my_fid, t) : (size_t)(b * a.n + t);
-        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF, W, 4>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
+        const Vec<VPL> o = attend_target<VPL, MEL_CONV_GATV2, BF, W, MEL_ATT_GP>(a, xr_row, sources, full, b * a.n, att, bias, lane, my_fid);
         // hl_dgn.py:105-108: mask out non-decision-makers, then pool over the graph
         const float dm = a.obs[(size_t)b * a.obs_stride + t * a.node_cols + a.node_cols - 1];
 #pragma unroll
@@ -419,8 +426,8 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 4, 1>), dim3(a.bs), dim3(256), 0, s, a);  \
         else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 4, 1>), dim3(a.bs), dim3(256), 0, s, a);        \
     } else {                                                                                                      \
-        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, 16, 1>), dim3(a.bs), dim3(1024), 0, s, a);        \
-        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, 16, 1>), dim3(a.bs), dim3(1024), 0, s, a);              \
+        if (a.bf16) MEL_LAUNCH((gat_attend_pool_kernel<V, true, MEL_POOL_NW, 1>), dim3(a.bs), dim3(64 * MEL_POOL_NW), 0, s, a);   \
+        else MEL_LAUNCH((gat_attend_pool_kernel<V, false, MEL_POOL_NW, 1>), dim3(a.bs), dim3(64 * MEL_POOL_NW), 0, s, a);         \
     }
             case 2: MEL_POOL_LAUNCH(2) break;
             case 4: MEL_POOL_LAUNCH(4) break;
