@@ -440,6 +440,12 @@ static mel_status launch_attend(const AttArgs& a, int hc, hipStream_t s, const c
         long want = ((a.rows_hint > 0 ? a.rows_hint : a.rows_cap) * 5 / 4 + 3) / 4;     // 25 % head-room, loop covers the rest
         if (want > (a.rows_cap + 3) / 4) want = (a.rows_cap + 3) / 4;
         if (want < 256) want = 256;
+#ifdef MEL_ATT_GRID_CAP
+        if (want > MEL_ATT_GRID_CAP) want = MEL_ATT_GRID_CAP;      // tuning: resident workgroups only, every wave loops
+#endif
+#ifdef MEL_ATT2_GRID_CAP
+        if (MODE == ATT_SINGLE && want > MEL_ATT2_GRID_CAP) want = MEL_ATT2_GRID_CAP;
+#endif
         const int grid = (int)((want + 7) & ~7L);       // multiple of 8: block id % 8 = XCD
 #define MEL_ATT_LAUNCH_W(V, WW)                                                                                          \
     if (a.kind == MEL_CONV_TRANSFORMER && a.bf16)                                                                     \
