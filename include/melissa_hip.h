@@ -228,6 +228,14 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
 
+/* The same product with the contraction cut into `ksplit` equal chunks that run as independent work items and are summed in
+ * chunk order afterwards: for the learn path's weight gradients dW = dY^T X, a few dozen output tiles over a contraction as
+ * long as the batch has rows (one tile per workgroup would leave most of the chip idle).  K / 32 must be a multiple of
+ * ksplit with at least two 32-steps per chunk; parts: device scratch of ksplit * M * N floats. */
+mel_status mel_gemm_f32_splitk(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
+                               int64_t M, int32_t N, int32_t K, int32_t relu, int32_t ksplit, float* parts,
+                               int64_t parts_floats, void* stream);
+
 /* The same projection on the bf16 feature path: A [M, lda] and W [N, K] device bf16, bias fp32, fp32
  * accumulation, Y [M, ldy] bf16 (y_f32 = 0) or fp32 (y_f32 = 1); K % 64 == 0, N % 64 == 0, lda % 8 == 0.
  * mel_convert_bf16: count (multiple of 8) fp32 values -> bf16, round to nearest even. */
@@ -251,8 +259,9 @@ mel_status mel_transpose_f32(const float* src, int32_t ld_src, int64_t rows, int
  * mel_gat_forward: out = relu(conv(x) + bias) given the projections (kind MEL_CONV_GATV2: xl = lin_l(x) sources,
  *   xr = lin_r(x) targets, att [HC], self-loops added, l_dgn.py:125-126; MEL_CONV_TRANSFORMER: xl = keys,
  *   xv = values, xr = queries, no self-loops, bias null, dgn_r.py:103-104).
- * mel_gat_backward: grad_out -> dxl (dxv) dxr datt dbias; dxl / dxv / datt / dbias must be ZERO on entry (they
- *   are accumulated with fp32 atomics, so their last bits depend on the order of arrival).
+ * mel_gat_backward: grad_out -> dxl (dxv) dxr datt dbias.  dxl / dxv / dxr are WRITTEN (deterministic sums: the source rows'
+ *   gradients are gathered target by target, no atomics); datt / dbias must be ZERO on entry (a few thousand fp32 atomics,
+ *   so their last bits depend on the order of arrival).  stats: device scratch, bs * n_nodes * heads * 4 floats.
  * mel_pool_forward / backward: hl_dgn.py:105-108, pooled[b] = max / mean / add over nodes of x * dm;
  *   arg [bs, HC] int32 = node of the first maximum (max only). */
 mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n_nodes, int32_t obs_stride, int32_t in_dim,
@@ -263,7 +272,7 @@ mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, co
 mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, const float* att, const uint64_t* adj,
                             const float* out, const float* grad_out, int64_t bs, int32_t n_nodes, int32_t heads,
                             int32_t channels, int32_t kind, float* dxl, float* dxv, float* dxr, float* datt,
-                            float* dbias, void* stream);
+                            float* dbias, float* stats, void* stream);
 mel_status mel_pool_forward(const float* x, const float* dm, int64_t bs, int32_t n_nodes, int32_t hc,
                             int32_t aggregator, float* pooled, int32_t* arg, void* stream);
 mel_status mel_pool_backward(const float* grad_pooled, const float* dm, const int32_t* arg, int64_t bs,

@@ -1146,6 +1146,21 @@ mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float
     return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_f32", -1, tile);
 }
 
+mel_status mel_gemm_f32_splitk(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
+                               int64_t M, int32_t N, int32_t K, int32_t relu, int32_t ksplit, float* parts, int64_t parts_floats,
+                               void* stream) {
+    if (!A || !W || !Y || !parts || M <= 0 || M > (1ll << 30) || lda < K || ldy < N)
+        return fail(MEL_ERR_INVALID_ARG, "bad split-K gemm arguments");
+    if (ksplit < 2 || K % GEMM_BK || (K / GEMM_BK) % ksplit || (K / GEMM_BK) / ksplit < 2 || N % 64 || ldy % 4 ||
+        parts_floats < (int64_t)ksplit * M * N)
+        return fail(MEL_ERR_UNSUPPORTED, "split-K gemm: K / 32 = %d must split into %d chunks of >= 2 steps, N %% 64 == 0, "
+                                         "ldy %% 4 == 0, parts >= ksplit * M * N floats", K / GEMM_BK, ksplit);
+    clear_stale_error();
+    GemmArgs g;
+    g.A = A, g.lda = lda, g.W = W, g.bias = bias, g.Y = Y, g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K, g.relu = relu;
+    return launch_gemm_splitk(g, ksplit, parts, (long)M * N, static_cast<hipStream_t>(stream), "mel_gemm_f32_splitk", -1, 0);
+}
+
 mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n, int32_t obs_stride, int32_t in_dim, uint64_t* adj,
                             void* stream) {
     if (!obs || !adj || bs < 1 || bs > (1 << 24) || n < 1 || n > MEL_MAX_NODES || in_dim < 1 || in_dim > 8 ||

@@ -12,10 +12,16 @@
 //                  d att += d e_ij * leaky(z),     d bias += g
 //     Transformer  d q[i] += d e_ij k[j] / sqrt(C),  d k[j] += d e_ij q[i] / sqrt(C),  d v[j] += alpha_ij g
 //
-// One wavefront per target row, 64 lanes x VPL channels = heads x C (same mapping as the inference kernels of
-// fwd.hip).  The backward makes three passes over the target's source rows (softmax statistics, S_i, gradients)
-// instead of storing per-edge coefficients; source-row gradients are accumulated with fp32 global atomics (each
-// row receives from ~deg targets), so their summation order - not their value beyond rounding - varies.
+// One wavefront per row, 64 lanes x VPL channels = heads x C (same mapping as the inference kernels of fwd.hip).  The
+// backward stores no per-edge coefficient and uses NO atomics on the row gradients:
+//   targets kernel  (a wave per target i)  three passes over i's source rows - softmax statistics m_i, 1 / l_i; S_i; then
+//                   d x_r[i] (d q[i]), d att, d bias - and the three per-head scalars go to `stats`;
+//   sources kernel  (a wave per source j)  walks the targets that read j (bit j of their source sets: a wave-uniform scan of
+//                   the graph's n adjacency rows), recomputes e_ij / alpha_ij from stats[i] exactly as the targets kernel
+//                   did, and sums j's gradient in target order into registers: d x_l[j] (d k[j]) and d v[j] are WRITTEN,
+//                   once, deterministically.
+// (Round 2's first version accumulated the source-row gradients with fp32 global atomics from the target side: ~190 M
+// atomics for a DGN-R update of 673 graphs - 15 of the update's 20 ms.)
 #include "common.hpp"
 
 namespace mel {
@@ -71,9 +77,11 @@ struct GradArgs {
     float* out;             // [rows, HC] relu(out + bias)
     // backward
     const float* gout;      // [rows, HC]
-    float* dxl;             // zero-initialised by the caller (atomics)
+    float* dxl;             // written by the sources kernel
     float* dxv;
-    float* dxr;
+    float* dxr;             // written by the targets kernel
+    float* stats;           // [rows, heads, 4] scratch: m_i, 1 / (l_i + eps), S_i per head (targets kernel -> sources kernel)
+    int heads;
     float* datt;            // [HC] zero-initialised
     float* dbias;           // [HC] zero-initialised, or null
 };
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void gat_full_forward_kernel(GradArgs a) {
 }
 
 template <int VPL, int KIND>
-__global__ __launch_bounds__(256) void gat_full_backward_kernel(GradArgs a) {
+__global__ __launch_bounds__(256) void gat_backward_targets_kernel(GradArgs a) {
     constexpr int HC = 64 * VPL;
     const int lane = lane_id();
     GVec<VPL> att, datt, dbias;
@@ -206,25 +214,83 @@ __global__ __launch_bounds__(256) void gat_full_backward_kernel(GradArgs a) {
                     const float dz = de * att.v[i] * (z > 0.f ? 1.f : 0.2f);
                     datt.v[i] = fmaf(de, fmaxf(z, 0.2f * z), datt.v[i]);
                     dxr.v[i] += dz;
-                    atomicAdd(a.dxl + row + i, fmaf(alpha, g.v[i], dz));
                 }
             } else {
                 const float des = de * a.scale;
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) {
-                    dxr.v[i] = fmaf(des, xl.v[i], dxr.v[i]);
-                    atomicAdd(a.dxl + row + i, des * xr.v[i]);
-                    atomicAdd(a.dxv + row + i, alpha * g.v[i]);
-                }
+                for (int i = 0; i < VPL; ++i) dxr.v[i] = fmaf(des, xl.v[i], dxr.v[i]);
             }
         }
         gstore<VPL>(a.dxr + me, dxr);
+        if (lane % a.lanes_per_head == 0) {                   // the head's three scalars (equal in all of its lanes)
+            float* st = a.stats + ((size_t)r * a.heads + lane / a.lanes_per_head) * 4;
+            st[0] = m, st[1] = inv, st[2] = S;
+        }
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         if (KIND == MEL_CONV_GATV2) atomicAdd(a.datt + lane * VPL + i, datt.v[i]);
         if (a.dbias) atomicAdd(a.dbias + lane * VPL + i, dbias.v[i]);
     }
+}
+
+// gradient of the SOURCE rows: d x_l[j] (GATv2) / d k[j], d v[j] (TransformerConv), one wave per source row j
+template <int VPL, int KIND>
+__global__ __launch_bounds__(256) void gat_backward_sources_kernel(GradArgs a) {
+    constexpr int HC = 64 * VPL;
+    const int lane = lane_id();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.rows) return;
+    const int g0 = (r / a.n) * a.n, jn = r - g0;
+    const int head = lane / a.lanes_per_head;
+    GVec<VPL> att;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) att.v[i] = 0.f;
+    if (KIND == MEL_CONV_GATV2) att = gload<VPL>(a.att + lane * VPL);
+    const size_t me = (size_t)r * HC + lane * VPL;
+    const GVec<VPL> xl = gload<VPL>(a.xl + me);                                     // x_l[j] / k[j]
+    const GVec<VPL> sv = (KIND == MEL_CONV_GATV2) ? xl : gload<VPL>(a.xv + me);     // what the targets aggregate: x_l[j] / v[j]
+    GVec<VPL> acc_l, acc_v;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc_l.v[i] = 0.f, acc_v.v[i] = 0.f;
+    for (int t = 0; t < a.n; ++t) {                         // targets in id order: a deterministic sum
+        const int ti = g0 + t;
+        const uint64_t word = a.adj[(size_t)ti * a.nw + (jn >> 6)];                 // wave-uniform
+        const bool reads_j = ((word >> (jn & 63)) & 1ull) || (KIND == MEL_CONV_GATV2 && t == jn);   // GATv2: self-loop
+        if (!reads_j) continue;
+        const size_t ti_off = (size_t)ti * HC + lane * VPL;
+        const GVec<VPL> xr = gload<VPL>(a.xr + ti_off);
+        GVec<VPL> g = gload<VPL>(a.gout + ti_off);
+        {
+            const GVec<VPL> o = gload<VPL>(a.out + ti_off);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) g.v[i] = o.v[i] > 0.f ? g.v[i] : 0.f;     // relu'
+        }
+        const float* st = a.stats + ((size_t)ti * a.heads + head) * 4;
+        const float m = st[0], inv = st[1], S = st[2];
+        const float alpha = expf(edge_score<VPL, KIND>(a, xr, xl, att) - m) * inv;  // the targets kernel's expression
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) d = fmaf(g.v[i], sv.v[i], d);
+        const float de = alpha * (head_total(d, a.lanes_per_head) - S);
+        if constexpr (KIND == MEL_CONV_GATV2) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const float z = xr.v[i] + xl.v[i];
+                const float dz = de * att.v[i] * (z > 0.f ? 1.f : 0.2f);
+                acc_l.v[i] += fmaf(alpha, g.v[i], dz);
+            }
+        } else {
+            const float des = de * a.scale;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                acc_l.v[i] = fmaf(des, xr.v[i], acc_l.v[i]);
+                acc_v.v[i] = fmaf(alpha, g.v[i], acc_v.v[i]);
+            }
+        }
+    }
+    gstore<VPL>(a.dxl + me, acc_l);
+    if constexpr (KIND == MEL_CONV_TRANSFORMER) gstore<VPL>(a.dxv + me, acc_v);
 }
 
 // ---- global pool over the graph of (x * dm): hl_dgn.py:105-108 -------------------------------------------
@@ -353,10 +419,10 @@ mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, co
 mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, const float* att, const uint64_t* adj,
                             const float* out, const float* grad_out, int64_t bs, int32_t n, int32_t heads,
                             int32_t channels, int32_t kind, float* dxl, float* dxv, float* dxr, float* datt,
-                            float* dbias, void* stream) {
+                            float* dbias, float* stats, void* stream) {
     if (mel_status st = check_gat(xl, xr, adj, bs, n, heads, channels, kind, att, xv)) return st;
-    if (!out || !grad_out || !dxl || !dxr || (kind == MEL_CONV_GATV2 && !datt) || (kind == MEL_CONV_TRANSFORMER && !dxv))
-        return fail(MEL_ERR_INVALID_ARG, "gat backward: null gradient buffer");
+    if (!out || !grad_out || !dxl || !dxr || !stats || (kind == MEL_CONV_GATV2 && !datt) || (kind == MEL_CONV_TRANSFORMER && !dxv))
+        return fail(MEL_ERR_INVALID_ARG, "gat backward: null gradient / scratch buffer");
     clear_stale_error();
     const int hc = heads * channels;
     GradArgs a{};
@@ -364,11 +430,15 @@ mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, c
     a.rows = (int)(bs * n), a.n = n, a.nw = set_words(n), a.lanes_per_head = channels / (hc / 64), a.kind = kind;
     a.scale = 1.0f / sqrtf((float)channels);
     a.out = const_cast<float*>(out), a.gout = grad_out, a.dxl = dxl, a.dxv = dxv, a.dxr = dxr, a.datt = datt, a.dbias = dbias;
+    a.stats = stats, a.heads = heads;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int grid = (a.rows + 3) / 4;
     if (grid > 2048) grid = 2048;                 // grid-stride: bounds the number of datt / dbias atomics
-    MEL_GRAD_DISPATCH(gat_full_backward_kernel, grid)
-    return check_launch("mel_gat_backward");
+    MEL_GRAD_DISPATCH(gat_backward_targets_kernel, grid)
+    if (mel_status st = check_launch("mel_gat_backward (targets)")) return st;
+    const int grid_s = (a.rows + 3) / 4;
+    MEL_GRAD_DISPATCH(gat_backward_sources_kernel, grid_s)
+    return check_launch("mel_gat_backward (sources)");
 }
 
 mel_status mel_pool_forward(const float* x, const float* dm, int64_t bs, int32_t n, int32_t hc, int32_t aggregator,

@@ -59,14 +59,15 @@ class _GatAttention(torch.autograd.Function):
         xl, xv, xr, att, adj, out = ctx.saved_tensors
         n_nodes, heads, channels, kind, has_bias = ctx.meta
         grad_out = grad_out.contiguous()
-        dxl, dxr = torch.zeros_like(xl), torch.empty_like(xr)
-        dxv = torch.zeros_like(xv) if xv is not None else None
+        dxl, dxr = torch.empty_like(xl), torch.empty_like(xr)            # written, not accumulated (no atomics on rows)
+        dxv = torch.empty_like(xv) if xv is not None else None
+        stats = torch.empty(xl.shape[0] * heads * 4, dtype=torch.float32, device=xl.device)      # per (target, head): m, 1/l, S
         datt = torch.zeros(heads * channels, dtype=torch.float32, device=xl.device) if att is not None else None
         dbias = torch.zeros(heads * channels, dtype=torch.float32, device=xl.device) if has_bias else None
         p = lambda t: t.data_ptr() if t is not None else None
         _lib.check(lib.mel_gat_backward(xl.data_ptr(), p(xv), xr.data_ptr(), p(att), adj.data_ptr(), out.data_ptr(),
                                         grad_out.data_ptr(), xl.shape[0] // n_nodes, n_nodes, heads, channels, kind,
-                                        dxl.data_ptr(), p(dxv), dxr.data_ptr(), p(datt), p(dbias), _stream(xl)),
+                                        dxl.data_ptr(), p(dxv), dxr.data_ptr(), p(datt), p(dbias), stats.data_ptr(), _stream(xl)),
                    "mel_gat_backward")
         if datt is not None:
             datt = datt.view_as(att)
@@ -124,6 +125,29 @@ def _gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, relu: bool 
     return out
 
 
+def _gemm_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int):
+    """``_gemm`` with the contraction cut into ``ksplit`` chunks (mel_gemm_f32_splitk): few output tiles, long K."""
+    m, k, n = a.shape[0], w.shape[1], w.shape[0]
+    parts = torch.empty(ksplit * m * n, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().mel_gemm_f32_splitk(a.data_ptr(), a.stride(0), w.data_ptr(), None, out.data_ptr(), out.stride(0), m, n, k,
+                                               0, ksplit, parts.data_ptr(), parts.numel(), _stream(a)), "mel_gemm_f32_splitk")
+    return out
+
+
+def _weight_grad(dy: torch.Tensor, x: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """dW [N, K] = dY^T [N, M] . X [M, K]: the contraction runs over the M rows of the batch.  N x K is a few dozen 64 x 64
+    tiles however long the batch is, so from a few thousand rows on the contraction is cut into chunks that run as
+    independent work items (M padded with zero rows to a multiple of 32 * ksplit)."""
+    m = dy.shape[0]
+    tiles = (like.shape[0] // 64) * (like.shape[1] // 64)
+    ksplit = 1
+    if m >= 2048 and tiles < 512:
+        ksplit = min(16, max(2, 1024 // tiles), m // 64)          # ~1 000 work items, at least two 32-steps per chunk
+    if ksplit < 2:
+        return _gemm(_transpose(dy, 32), _transpose(x, 32), None, torch.empty_like(like))
+    return _gemm_splitk(_transpose(dy, 32 * ksplit), _transpose(x, 32 * ksplit), torch.empty_like(like), ksplit)
+
+
 def _transpose(src: torch.Tensor, pad_to: int = 1) -> torch.Tensor:
     """[R, C] -> [C, Rp] with Rp = R rounded up to ``pad_to`` and zeros in the padding."""
     r, c = src.shape
@@ -163,7 +187,7 @@ class _HipLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:                       # dX [M, K] = dY [M, N] . W [N, K]: contraction over N
             dx = _gemm(dy, _transpose(w), None, torch.empty_like(x))
         if ctx.needs_input_grad[1]:                       # dW [N, K] = dY^T [N, M] . X [M, K]: contraction over M (padded to 32)
-            dw = _gemm(_transpose(dy, 32), _transpose(x, 32), None, torch.empty_like(w))
+            dw = _weight_grad(dy, x, w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=0)
         return dx, dw, db

@@ -140,7 +140,8 @@ def test_learn_step_uses_hip_kernels_by_default():
     assert np.isfinite(out["loss"]) and not torch.equal(before, net.conv1.att.detach())
 
 
-@pytest.mark.parametrize("m,k,n", [(37, 128, 512), (1600, 512, 512), (1, 1152, 128), (250, 128, 128), (64, 640, 256)])
+@pytest.mark.parametrize("m,k,n", [(37, 128, 512), (1600, 512, 512), (1, 1152, 128), (250, 128, 128), (64, 640, 256),
+                                   (33600, 128, 128), (5003, 256, 128), (2048, 128, 640)])     # long batches: split-K dW
 def test_hip_linear_matches_torch_linear(m, k, n):
     """The learn path's dense layers on the library's own GEMM (autograd_ops.hip_linear: y = x W^T + b, dX = dY W,
     dW = dY^T X through mel_gemm_f32 + mel_transpose_f32) against float64 torch on the CPU."""
