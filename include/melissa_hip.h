@@ -236,6 +236,14 @@ mel_status mel_gemm_f32_splitk(const float* A, int32_t lda, const float* W, cons
                                int64_t M, int32_t N, int32_t K, int32_t relu, int32_t ksplit, float* parts,
                                int64_t parts_floats, void* stream);
 
+/* The same product at MEL_PREC_F32_SPLIT (fp32 operands and results, six exact bf16 partial products per term on the bf16
+ * matrix cores): W is split into bf16 planes in `scratch` first.  tile: 0 = the library's choice, 1 = 64 x 64, 2 = 128 x 128
+ * (N % 128 == 0), + 100 = W's planes are already in scratch (an earlier call with the same W: benchmarks); ksplit > 1: the 128 x 128 kernel's split-K (K / 16 a multiple of ksplit, >= 4 steps per chunk, ldy % 4 == 0).
+ * K % 32 == 0, K >= 128, N % 64 == 0; scratch: device, >= round_up(6 N K, 256) + (ksplit > 1 ? 4 ksplit M N : 0) bytes. */
+mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
+                              int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, int32_t ksplit, void* scratch,
+                              int64_t scratch_bytes, void* stream);
+
 /* The same projection on the bf16 feature path: A [M, lda] and W [N, K] device bf16, bias fp32, fp32
  * accumulation, Y [M, ldy] bf16 (y_f32 = 0) or fp32 (y_f32 = 1); K % 64 == 0, N % 64 == 0, lda % 8 == 0.
  * mel_convert_bf16: count (multiple of 8) fp32 values -> bf16, round to nearest even. */

@@ -124,7 +124,11 @@ static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_
         MEL_LAUNCH((gemm_bf16_kernel<WM, WN, TM, TN, GEMM_MODE_PLAIN>), dim3((int)grid), dim3(64 * WM * WN), 0, s, batch);
 }
 
-// split path: one persistent 64 x 64 kernel, named per call site like the fp32 one
+// split path: a persistent 64 x 64 kernel for small launches, 128 x 128 tiles from MEL_SPLIT_BIG_FROM expected big tiles on
+// (both named per call site like the fp32 one)
+#ifndef MEL_SPLIT_BIG_FROM
+#define MEL_SPLIT_BIG_FROM 192
+#endif
 template <int TAG>
 static void gemm_launch_split_t(const GemmArgs* gs, int count, int mode, hipStream_t s) {
     GemmBatch batch{};
@@ -141,7 +145,38 @@ static void gemm_launch_split_t(const GemmArgs* gs, int count, int mode, hipStre
     else
         MEL_LAUNCH((gemm_split_kernel<GEMM_MODE_PLAIN, TAG>), dim3((int)grid), dim3(256), 0, s, batch);
 }
-static void gemm_launch_split(const GemmArgs* gs, int count, int mode, hipStream_t s, int tag) {
+// 128 x 128 tiles (gemm_split_big_kernel): two workgroups per CU, PLAIN mode, every N a multiple of 128
+template <int TAG>
+static void gemm_launch_split_big_t(const GemmArgs* gs, int count, hipStream_t s) {
+    GemmBatch batch{};
+    batch.count = count;
+    long items = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        items += ((long)((gs[i].M + 127) / 128) * (gs[i].N / 128) * (gs[i].ksplit > 1 ? gs[i].ksplit : 1) + 7) & ~7L;
+    }
+    long grid = 256L * 2;
+    if (grid > items) grid = items;
+    MEL_LAUNCH((gemm_split_big_kernel<TAG>), dim3((int)grid), dim3(256), 0, s, batch);
+}
+static bool split_big_fits(const GemmArgs* gs, int count, int mode) {
+    if (mode != GEMM_MODE_PLAIN) return false;
+    for (int i = 0; i < count; ++i) {
+        const int S = gs[i].ksplit > 1 ? gs[i].ksplit : 1;
+        if (gs[i].N % 128 || gs[i].K % (GEMS2_BK * S) || gs[i].K / GEMS2_BK / S < 4 || gs[i].lda % 4) return false;
+    }
+    return true;
+}
+// big_tiles: expected 128 x 128 tiles of the launch (from the row hints); < 0: the caller forces the 64 x 64 kernel
+static void gemm_launch_split(const GemmArgs* gs, int count, int mode, hipStream_t s, int tag, long big_tiles) {
+    if (big_tiles >= MEL_SPLIT_BIG_FROM && split_big_fits(gs, count, mode)) {
+        switch (tag) {
+            case 2: gemm_launch_split_big_t<2>(gs, count, s); break;
+            case 3: gemm_launch_split_big_t<3>(gs, count, s); break;
+            default: gemm_launch_split_big_t<0>(gs, count, s); break;
+        }
+        return;
+    }
     switch (tag) {
         case 1: gemm_launch_split_t<1>(gs, count, mode, s); break;
         case 2: gemm_launch_split_t<2>(gs, count, mode, s); break;
@@ -166,7 +201,9 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     if (mel_status st = check_gemm_shape(g, what)) return st;
     if (m_hint < 0 || m_hint > g.M) m_hint = g.M;
     if (g.split) {
-        gemm_launch_split(&g, 1, mode, stream, tag);
+        const long big = force_tile == 1 ? -1 : force_tile == 2 ? (1L << 30) : ((m_hint + 127) / 128) * (g.N / 128);
+        if (force_tile == 2 && !split_big_fits(&g, 1, mode)) return fail(MEL_ERR_UNSUPPORTED, "%s: shape does not fit the 128 x 128 split tile", what);
+        gemm_launch_split(&g, 1, mode, stream, tag, big);
         return check_launch(what);
     }
     // encoder (ENC producer): a 64 x 128 tile spans the whole hidden width, so the first layer (VALU work inside the
@@ -217,7 +254,22 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
 // in order and applies scale / bias / ReLU.  Model of the launch in K steps of one workgroup: (workgroups sharing a
 // CU) x (items per workgroup) x (steps per item + 2 for the hand-over), over the 512 slots of the ring kernel.
 int choose_ksplit(const GemmArgs& g, long m_hint, int max_split) {
-    if (g.split || g.K < 512 || g.ldy % 4 || g.N % 64 || g.K % GEMB_BK) return 1;
+    if (g.K < 512 || g.ldy % 4 || g.N % 64 || g.K % GEMB_BK) return 1;
+    if (g.split) {
+        // 128 x 128 split kernel: 512 slots (two workgroups per CU); steps of 16 k, ~4 steps of hand-over per work item
+        if (g.N % 128 || g.lda % 4) return 1;
+        const long tiles = ((m_hint + 127) / 128) * (g.N / 128);
+        const int KT = g.K / GEMS2_BK;
+        int best = 1;
+        long best_cost = 0;
+        for (int S = 1; S <= max_split; ++S) {
+            if (KT % S || KT / S < 4) continue;
+            const long items = tiles * S, slots = items < 512 ? items : 512;
+            const long cost = ((slots + 255) / 256) * ((items + slots - 1) / slots) * (KT / S + 4);
+            if (S == 1 || cost < best_cost) best = S, best_cost = cost;
+        }
+        return best * tiles >= MEL_SPLIT_BIG_FROM ? best : 1;
+    }
     const long tiles = ((m_hint + 63) / 64) * (g.N / 64);
     if (g.bf16) {
         // bf16 one-role kernel: 1 024 slots, latency bound at these sizes - items per slot x (steps per item + 2)
@@ -248,11 +300,14 @@ mel_status launch_gemm_splitk(const GemmArgs& g, int S, float* parts, long part_
                               const char* what, long m_hint, int tag, bool finish = true) {
     if (g.M <= 0) return MEL_OK;
     if (mel_status st = check_gemm_shape(g, what)) return st;
-    if (S < 2 || (g.K / (g.bf16 ? GEMB_BK : GEMM_BK)) % S || g.split || !parts || part_stride < (long)g.M * g.N)
+    if (S < 2 || (g.K / (g.bf16 ? GEMB_BK : g.split ? GEMS2_BK : GEMM_BK)) % S || !parts || part_stride < (long)g.M * g.N)
         return fail(MEL_ERR_INVALID_ARG, "%s: bad split-K request (S=%d)", what, S);
     GemmArgs p = g;
     p.Y = parts, p.ldy = g.N, p.ksplit = S, p.part_stride = part_stride;
-    if (g.bf16) {
+    if (g.split) {
+        if (!split_big_fits(&p, 1, GEMM_MODE_PLAIN)) return fail(MEL_ERR_UNSUPPORTED, "%s: shape does not fit the 128 x 128 split tile", what);
+        gemm_launch_split(&p, 1, GEMM_MODE_PLAIN, stream, tag, 1L << 30);
+    } else if (g.bf16) {
         p.y_f32 = 1;
         gemm_launch_bf16<2, 2, 1, 1>(&p, 1, GEMM_MODE_PLAIN, stream);
     } else {
@@ -287,7 +342,7 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
     if (gs[0].split) {
         for (int i = 1; i < count; ++i)
             if (!gs[i].split) return fail(MEL_ERR_INVALID_ARG, "%s: mixed precisions in one group", what);
-        gemm_launch_split(gs, count, GEMM_MODE_PLAIN, stream, tag);
+        gemm_launch_split(gs, count, GEMM_MODE_PLAIN, stream, tag, big);
         return check_launch(what);
     }
     if (gs[0].bf16) {
@@ -452,7 +507,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     const int hw = head_hidden_width(w->q_head) + head_hidden_width(w->v_head);
     L.hq[0] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
-    L.hpart = c.take<float>(hw > 0 ? (size_t)(w->precision == MEL_PREC_F32_SPLIT ? 1 : HEAD_KSPLIT_MAX) * R * hw : 8);
+    L.hpart = c.take<float>(hw > 0 ? (size_t)HEAD_KSPLIT_MAX * R * hw : 8);
     L.minmax = c.take<float>(64);
     L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
                  : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
@@ -530,7 +585,7 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
 // on every call, which keeps a caller that never prepares correct.  convert = false only lays the pointers out.
 static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjWeights& pw, hipStream_t s, bool convert) {
     pw = ProjWeights{};
-    if (w->precision == MEL_PREC_F32_SPLIT) {        // [rows][3][K] bf16 planes of every projection weight
+    if (w->precision == MEL_PREC_F32_SPLIT) {        // [rows][K / 16][3][16] bf16 planes of every projection weight
         SplitBatch b{};
         size_t off = 0;
         int blocks = 0;
@@ -918,6 +973,14 @@ void mel_debug_gemm_prof(unsigned long long* out8) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
 }
 #endif
+#ifdef MEL_SPLIT_PROF
+void mel_debug_split_prof(unsigned long long* out16) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_split_prof), 16 * sizeof(unsigned long long));
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_prof), z, sizeof(z));
+}
+#endif
 #ifdef MEL_ATT_PROF
 // tuning builds only: read and reset the attention rows kernel's cycle counters (tools/att_prof.py)
 void mel_debug_att_prof(unsigned long long* out8) {
@@ -1159,6 +1222,35 @@ mel_status mel_gemm_f32_splitk(const float* A, int32_t lda, const float* W, cons
     GemmArgs g;
     g.A = A, g.lda = lda, g.W = W, g.bias = bias, g.Y = Y, g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K, g.relu = relu;
     return launch_gemm_splitk(g, ksplit, parts, (long)M * N, static_cast<hipStream_t>(stream), "mel_gemm_f32_splitk", -1, 0);
+}
+
+mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
+                              int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, int32_t ksplit, void* scratch,
+                              int64_t scratch_bytes, void* stream) {
+    if (!A || !W || !Y || !scratch || M <= 0 || M > (1ll << 30) || lda < K || ldy < N || N < 64 || K < 128)
+        return fail(MEL_ERR_INVALID_ARG, "bad split-precision gemm arguments");
+    const int64_t plane_bytes = ((int64_t)6 * N * K + 255) & ~255ll;
+    const int64_t need = plane_bytes + (ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0);
+    if (K % 32 || N % 64 || scratch_bytes < need)
+        return fail(MEL_ERR_UNSUPPORTED, "split-precision gemm: K %% 32 == 0, N %% 64 == 0, scratch >= %lld bytes", (long long)need);
+    clear_stale_error();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SplitBatch b{};
+    b.n = 1, b.src[0] = W, b.dst[0] = static_cast<uint16_t*>(scratch), b.count[0] = N * K, b.K[0] = K, b.start[0] = 0;
+    b.start[1] = (int)(((int64_t)N * K / 4 + 255) / 256);
+    if (tile < 100) {                                   // tile + 100: the planes of an earlier call are still in scratch
+        MEL_LAUNCH(split_weights_kernel, dim3(b.start[1]), dim3(256), 0, s, b);
+        if (mel_status st = check_launch("weights -> bf16 planes")) return st;
+    } else {
+        tile -= 100;
+    }
+    GemmArgs g;
+    g.A = A, g.lda = lda, g.W = static_cast<const float*>(scratch), g.bias = bias, g.Y = Y, g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K;
+    g.relu = relu, g.split = 1;
+    if (ksplit > 1)
+        return launch_gemm_splitk(g, ksplit, reinterpret_cast<float*>(static_cast<char*>(scratch) + plane_bytes), (long)M * N, s,
+                                  "mel_gemm_f32_split", -1, 0);
+    return launch_gemm(g, GEMM_MODE_PLAIN, s, "mel_gemm_f32_split", -1, tile);
 }
 
 mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n, int32_t obs_stride, int32_t in_dim, uint64_t* adj,

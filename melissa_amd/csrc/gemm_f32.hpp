@@ -63,7 +63,7 @@ struct GemmArgs {
     // fp32 when y_f32 is set.  bias / rscale / obs / enc_* are fp32 on both paths.
     int bf16 = 0;
     int y_f32 = 0;
-    // split path (gemm_split.hpp): A / Y fp32 as usual, W / W_hi point at [N][3][K] bf16 planes (hi | mid | lo)
+    // split path (gemm_split.hpp): A / Y fp32 as usual, W / W_hi point at [N][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k)
     int split = 0;
     // split-K (specialised-wavefront kernel only): the K range is cut into `ksplit` equal chunks, chunk s writes its RAW
     // partial products (no scale / bias / ReLU) to Y + s * part_stride; splitk_finish_kernel sums the planes in order

@@ -11,7 +11,8 @@
 //
 // Data flow: activations stay fp32 in HBM (no other kernel changes): the A tile is fetched exactly like the fp32
 // kernel's (same GemmArgs, same row gather / encoder producer) and split in registers on its way into LDS; the
-// weights are split once per forward call into [N][3][K] bf16 planes in the workspace (split_weights_kernel).
+// weights are split once per weight version (mel_prepare_weights) or per forward call into bf16 planes interleaved per
+// 16 k - [N][K / 16][3][16]: the 96 bytes a row contributes to a 16-k step are contiguous (split_weights_kernel).
 // LDS row = 3 planes x 64 B (K step 32) + 16 B pad = 208 B: the 16-byte fragment reads of 8 consecutive rows land on
 // 8 distinct 4-bank groups.  One ds_read_b128 = one MFMA operand; 12 reads feed the 12 MFMAs of a K step.
 // Same persistent tile loop, XCD-aware tile order and next-tile prefetch as gemm_f32_persistent_kernel.
@@ -120,18 +121,28 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
                 enc_features(g, row, c.ac[i].x);
             }
         }
-        {   // weights: [N][3][K] bf16 planes (split_weights_kernel); W / W_hi point at plane 0 of row 0
+        {   // weights: [N][K / 16][3][16] bf16 planes (split_weights_kernel); W / W_hi point at row 0.  This thread's chunk
+            // wch of plane p (k = 8 wch .. + 7 of the 32-k step) sits in 16-k step wch >> 1, half wch & 1
             const int n = c.n0 + wrow;
             const uint16_t* base = (g.W_hi && n >= g.split_n)
                                        ? reinterpret_cast<const uint16_t*>(g.W_hi) + (size_t)(n - g.split_n) * 3 * g.K
                                        : reinterpret_cast<const uint16_t*>(g.W) + (size_t)n * 3 * g.K;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) c.w_src[p] = reinterpret_cast<const u32x4*>(base + (size_t)p * g.K + wch * 8);
+            for (int p = 0; p < 3; ++p)
+                c.w_src[p] = reinterpret_cast<const u32x4*>(base + ((wch >> 1) * 3 + p) * 16 + (wch & 1) * 8);
         }
     };
 
     int t = next_valid(blockIdx.x);
     if (t >= total) return;
+    int nsteps = 0;                           // K steps of this workgroup's whole stream
+    for (int tt = t; tt < total; tt = next_valid(tt + stride)) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (tt >= pre[k]) pi = k;
+        nsteps += batch.p[pi].K / GEMM_BK;
+    }
     if constexpr (MODE == GEMM_MODE_ENC) {
         const GemmArgs& g = batch.p[0];
         float* e = enc_s;
@@ -168,23 +179,26 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
     Meta cm{pf.m0, pf.n0, pf.M, pf.pi, pf.KT}, nm{};
     bool nm_valid = false;
 
-    auto issue = [&](Regs& R) -> bool {       // loads of the next step of the stream; false when the stream is over
-        if (!pf_valid) return false;
+    // loads of the next step of the stream.  UNCONDITIONAL: once the stream is over the last step is simply fetched again
+    // (and filled into a stage nobody reads).  A load that one path through the loop skips makes the compiler's wait-count
+    // bookkeeping assume the worst at the join - "the other register set's loads may not have been issued, so mine are the
+    // youngest" - and every fill then waits for ALL outstanding loads, the ones issued a step ago included: the prefetch
+    // distance collapses to zero (measured on the 128 x 128 kernel: 163 TF with the skip).
+    auto issue = [&](Regs& R) {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) R.a[i] = fetch_a<MODE>(batch.p[0], pf.ac[i], pf_kt * GEMM_BK, kc, enc);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) R.w[p] = pf.w_src[p][pf_kt * 4];
-        if (++pf_kt == pf.KT) {               // cross into this workgroup's next tile
+        for (int p = 0; p < 3; ++p) R.w[p] = pf.w_src[p][pf_kt * 12];          // 192 bytes per row and 32-k step
+        if (pf_valid && ++pf_kt == pf.KT) {   // cross into this workgroup's next tile
             const int tn = next_valid(pf_t + stride);
             if (tn < total) {
                 setup(pf, tn);
                 pf_t = tn, pf_kt = 0;
                 nm = Meta{pf.m0, pf.n0, pf.M, pf.pi, pf.KT}, nm_valid = true;
             } else {
-                pf_valid = false;
+                pf_valid = false, pf_kt = pf.KT - 1;
             }
         }
-        return true;
     };
     auto fill_stage = [&](int stage, const Regs& R) {
 #pragma unroll
@@ -199,11 +213,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
     };
 
     Regs R0, R1;
-    bool v0 = issue(R0);                       // step 0
-    bool v1 = issue(R1);                       // step 1
+    issue(R0);                                 // step 0
+    issue(R1);                                 // step 1
     fill_stage(0, R0);
     __syncthreads();
-    v0 = issue(R0);                            // step 2
+    issue(R0);                                 // step 2
     int stage = 0, ckt = 0;
     f32x16 acc;
 #pragma unroll
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
 
     // one K step: MFMAs on `stage`, then Ra (step s+1) -> the other stage, barrier, then Ra <- loads of step s+3.
     // returns false when the stream is finished
-    auto step = [&](Regs& Ra, bool& va) -> bool {
+    auto step = [&](Regs& Ra) {
         const u32x4* cst = lds + stage * BUF;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -229,26 +243,347 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmBatch batch) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
         }
-        if (va) fill_stage(stage ^ 1, Ra);
+        fill_stage(stage ^ 1, Ra);
         __syncthreads();
         stage ^= 1;
-        va = issue(Ra);
-        if (++ckt < cm.KT) return true;
-        // the tile is complete: epilogue, the fp32 kernel's
-        store_block_f32(batch.p[cm.pi], acc, cm.m0 + wm * 32 + 4 * h, cm.n0 + wn * 32 + r, cm.M);
+        issue(Ra);
+        if (++ckt == cm.KT) {                 // the tile is complete: epilogue, the fp32 kernel's
+            store_block_f32(batch.p[cm.pi], acc, cm.m0 + wm * 32 + 4 * h, cm.n0 + wn * 32 + r, cm.M);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        if (!nm_valid) return false;
-        cm = nm, nm_valid = false, ckt = 0;
-        return true;
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            cm = nm, ckt = 0;
+            if (!nm_valid) cm.KT = 1 << 30;   // (the padding step of an odd stream ends no tile)
+            nm_valid = false;
+        }
     };
-    for (;;) {
-        if (!step(R1, v1)) break;
-        if (!step(R0, v0)) break;
+    // the loop is a plain counted one over PAIRS of steps (an odd stream gets one padding step on stale operands): with
+    // an exit between the two steps the compiler's control-flow restructuring hands the wait-count pass edges that never
+    // run, and the first step of the pair then waits for every outstanding load
+    for (int it = 0; it < (nsteps + 1) >> 1; ++it) {
+        step(R1);
+        step(R0);
     }
 }
 
-// fp32 [rows, K] weight matrices -> [rows][3][K] bf16 planes (hi | mid | lo), all matrices of the model in one launch
+// ---- 128 x 128 tiles ------------------------------------------------------------------------------------------------
+// The 64 x 64 kernel above moves 20 KB from L2 into LDS per 12 MFMAs of each of its waves (384 matrix-pipe cycles): at
+// the pipe's rate that is more than a CU's vector-memory path delivers (64 B / clk), so it runs at ~30 % of the split
+// path's peak.  Here a workgroup of 2 x 2 waves owns 128 x 128 outputs and every wave 2 x 2 accumulator blocks: 24 MFMAs
+// (768 cycles) per wave and 16-k step for 20 KB per workgroup - a quarter of the operand traffic per MFMA - and the 12
+// fragment reads of a step feed 24 MFMAs.  K step 16: an LDS row is 3 planes x 32 B + 16 B pad = 112 B (the 16 lanes of a
+// ds_read_b128 group land on 16 distinct 16-byte slots), a stage 28 KB, two stages 56 KB: two workgroups per CU, so a
+// SIMD holds two waves of different workgroups and one's barrier / epilogue is the other's matrix time.  Same flat
+// stream of K steps across the workgroup's work items with the register prefetch two steps ahead; PLAIN mode only.
+// Split-K (GemmArgs::ksplit, as in gemm_bf16.hpp): work item = (tile, K chunk), raw products to plane ks.
+#ifdef MEL_SPLIT_PROF
+__device__ unsigned long long g_split_prof[16];      // issue-time stamps inside a K step (tools/split_prof.py)
+#endif
+constexpr int GEMS2_ROW = 7;                 // 16-byte chunks per LDS row: 3 planes x 2 chunks + 1 pad
+constexpr int GEMS2_BK = 16;
+
+struct S2TileCtx {
+    const float* a_src[2];             // this thread's 4 floats of K step 0 of its two A rows
+    const u32x4* w_src[3];             // this thread's three 16-byte chunks of the W tile's K step 0
+    int m0, n0, M, pi, KT, ks;
+};
+
+template <int TAG = 0>
+__global__ __launch_bounds__(256, 2) void gemm_split_big_kernel(GemmBatch batch) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int BUF = (BM + BN) * GEMS2_ROW;        // 16-byte chunks per LDS stage
+    __shared__ u32x4 lds[2 * BUF];
+
+    int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP];
+    pre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
+        act[i] = 0, rows[i] = 0;
+        if (i < batch.count) {
+            const GemmArgs& q = batch.p[i];
+            rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
+            act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN) * (q.ksplit > 1 ? q.ksplit : 1);
+        }
+        pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
+    }
+    const int total = pre[GEMM_MAX_GROUP];
+    const int stride = gridDim.x;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int crow = tid >> 2;            // A staging: 4 threads per 64-byte fp32 row slice, 64 rows per pass, 2 passes
+    const int kq = tid & 3;               // this thread's 4 consecutive k of the step
+
+    auto next_valid = [&](int t) {
+        for (; t < total; t += stride) {
+            int pi = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (t >= pre[k]) pi = k;
+            if (t - pre[pi] < act[pi]) return t;
+        }
+        return total;
+    };
+    auto setup = [&](S2TileCtx& c, int t) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (t >= pre[k]) pi = k;
+        const GemmArgs& g = batch.p[pi];
+        const int nbn = g.N / BN;
+        int wg = t - pre[pi];
+        {
+            const int active = act[pi];
+            const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
+            wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+        }
+        const int S = g.ksplit > 1 ? g.ksplit : 1;
+        c.pi = pi, c.M = rows[pi], c.KT = g.K / GEMS2_BK / S, c.ks = (wg / nbn) % S;
+        c.m0 = (wg / (nbn * S)) * BM, c.n0 = (wg % nbn) * BN;
+        const int step0 = c.ks * c.KT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = min(c.m0 + crow + i * 64, c.M - 1);                  // clamped, never predicated
+            const int ar = g.arow ? g.arow[row] : row;
+            c.a_src[i] = g.A + (size_t)ar * g.lda + step0 * GEMS2_BK + kq * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {       // [N][K / 16][3][16] planes: 6 chunks per row and step, 768 per tile and step
+            const int ch = tid + i * 256, wrow = ch / 6, wch = ch - wrow * 6;
+            const int n = c.n0 + wrow;
+            const uint16_t* base = (g.W_hi && n >= g.split_n)
+                                       ? reinterpret_cast<const uint16_t*>(g.W_hi) + (size_t)(n - g.split_n) * 3 * g.K
+                                       : reinterpret_cast<const uint16_t*>(g.W) + (size_t)n * 3 * g.K;
+            c.w_src[i] = reinterpret_cast<const u32x4*>(base + (size_t)step0 * 48 + wch * 8);
+        }
+    };
+
+    int t = next_valid(blockIdx.x);
+    if (t >= total) return;
+    int nsteps = 0;                           // K steps of this workgroup's whole stream
+    for (int tt = t; tt < total; tt = next_valid(tt + stride)) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (tt >= pre[k]) pi = k;
+        nsteps += batch.p[pi].K / GEMS2_BK / (batch.p[pi].ksplit > 1 ? batch.p[pi].ksplit : 1);
+    }
+
+    // LDS addressing: 8-byte units for the A pieces (row * 14 + plane * 4 + kq), 16-byte chunks elsewhere
+    u32x2* lds8 = reinterpret_cast<u32x2*>(lds);
+    const int a_st = crow * (2 * GEMS2_ROW) + kq;                          // + i * 64 rows, + plane * 4
+    int w_st[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int ch = tid + i * 256, wrow = ch / 6;
+        w_st[i] = (BM + wrow) * GEMS2_ROW + (ch - wrow * 6);
+    }
+    const int a_off = (wm * 64 + r) * GEMS2_ROW + h;                       // + i * 32 rows, + plane * 2
+    const int w_off = (BM + wn * 64 + r) * GEMS2_ROW + h;
+
+    struct Regs {
+        f32x4 a[2];
+        u32x4 w[3];
+    };
+    struct Meta {
+        int m0, n0, M, pi, KT, ks;
+    };
+    S2TileCtx pf;                             // where the prefetch stands
+    int pf_t = t, pf_kt = 0;
+    bool pf_valid = true;
+    setup(pf, t);
+    Meta cm{pf.m0, pf.n0, pf.M, pf.pi, pf.KT, pf.ks}, nm{};
+    bool nm_valid = false;
+
+    // loads of the next step of the stream, unconditional (see gemm_split_kernel); in pieces, so that a step can deal them
+    // out between its MFMAs
+    auto issue_a = [&](Regs& R) {
+        const int kk = pf_kt;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) R.a[i] = *reinterpret_cast<const f32x4*>(pf.a_src[i] + kk * GEMS2_BK);
+    };
+    auto issue_w = [&](Regs& R) {
+        const int kk = pf_kt;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) R.w[i] = pf.w_src[i][kk * 6];
+    };
+    auto advance = [&]() {
+        if (pf_valid && ++pf_kt == pf.KT) {   // cross into this workgroup's next work item
+            const int tn = next_valid(pf_t + stride);
+            if (tn < total) {
+                setup(pf, tn);
+                pf_t = tn, pf_kt = 0;
+                nm = Meta{pf.m0, pf.n0, pf.M, pf.pi, pf.KT, pf.ks}, nm_valid = true;
+            } else {
+                pf_valid = false, pf_kt = pf.KT - 1;
+            }
+        }
+    };
+    auto issue = [&](Regs& R) { issue_a(R), issue_w(R), advance(); };
+    auto fill_a = [&](int stage, const Regs& R, int i) {
+        u32x2 hi, mid, lo;
+        split4(R.a[i], hi, mid, lo);
+        u32x2* dst = lds8 + stage * (2 * BUF) + a_st + i * 64 * (2 * GEMS2_ROW);
+        dst[0] = hi, dst[4] = mid, dst[8] = lo;
+    };
+    auto fill_w = [&](int stage, const Regs& R) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lds[stage * BUF + w_st[i]] = R.w[i];
+    };
+    auto fill_stage = [&](int stage, const Regs& R) { fill_a(stage, R, 0), fill_a(stage, R, 1), fill_w(stage, R); };
+
+    Regs R0, R1;
+    issue(R0);                                 // step 0
+    issue(R1);                                 // step 1
+    fill_stage(0, R0);
+    __syncthreads();
+    issue(R0);                                 // step 2
+    int stage = 0, ckt = 0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // one K step: MFMAs on `stage`, then Ra (step s+1) -> the other stage, barrier, then Ra <- loads of step s+3
+#ifdef MEL_SPLIT_PROF
+    unsigned long long pm = 0, pw = 0, pb = 0, pi_ = 0, pe = 0, fine[13] = {0};
+    const unsigned long long pk0 = GEMM_T();
+#endif
+    auto step = [&](Regs& Ra) {
+#ifdef MEL_SPLIT_PROF
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long q0 = GEMM_T();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const u32x4* cst = lds + stage * BUF;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[u][p] = __builtin_bit_cast(bf16x8, cst[a_off + u * 32 * GEMS2_ROW + 2 * p]);
+                b[u][p] = __builtin_bit_cast(bf16x8, cst[w_off + u * 32 * GEMS2_ROW + 2 * p]);
+            }
+        // per block smallest products first (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi), the four blocks interleaved
+        // The rest of the step's work is dealt out between the six groups of four MFMAs, so that a wave's instruction stream
+        // never has a phase without matrix work (cycle stamps of the phase-by-phase version, per K step and wave: fragment
+        // reads + MFMAs 1 109, prefetch wait + split + fill 713, barrier 188, issuing the five loads behind the barrier 603 -
+        // the four waves of a workgroup all queue at the CU's address path at once -, 3 076 in all against 768 of MFMAs):
+        // Ra (step s+1) is split and written to the other stage behind groups 0-2, and as soon as its registers are free
+        // they are reloaded with step s+3 behind groups 3-4.
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#ifdef MEL_SPLIT_PROF
+        unsigned long long ts[13];
+        __builtin_amdgcn_sched_barrier(0);
+        ts[0] = GEMM_T();                      // the 12 fragment reads are issued
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[k]], b[j][PB[k]], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MEL_SPLIT_PROF
+            ts[1 + 2 * k] = GEMM_T();          // MFMA group k is issued
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (k == 0) fill_a(stage ^ 1, Ra, 0);
+            if (k == 1) fill_a(stage ^ 1, Ra, 1);
+            if (k == 2) fill_w(stage ^ 1, Ra);
+            if (k == 3) issue_a(Ra);
+            if (k == 4) issue_w(Ra);
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MEL_SPLIT_PROF
+            ts[2 + 2 * k] = GEMM_T();          // the piece behind group k is issued
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#ifdef MEL_SPLIT_PROF
+        fine[0] += ts[0] - q0;
+#pragma unroll
+        for (int k = 1; k < 13; ++k) fine[k] += ts[k] - ts[k - 1];
+#endif
+#ifdef MEL_SPLIT_PROF
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][1][0]));      // the MFMA chains have retired
+        const unsigned long long q1 = GEMM_T();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long q2 = GEMM_T();
+#endif
+        __syncthreads();
+#ifdef MEL_SPLIT_PROF
+        const unsigned long long q3 = GEMM_T();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        stage ^= 1;
+        advance();
+#ifdef MEL_SPLIT_PROF
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long q4 = GEMM_T();
+        __builtin_amdgcn_sched_barrier(0);
+        pm += q1 - q0, pw += q2 - q1, pb += q3 - q2, pi_ += q4 - q3;
+#endif
+        if (++ckt == cm.KT) {                  // the work item is complete
+            const GemmArgs& g = batch.p[cm.pi];
+            if (g.ksplit > 1) {                // raw partial products into this chunk's fp32 plane
+                float* P = g.Y + (size_t)cm.ks * g.part_stride;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = cm.n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int m = cm.m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (m < cm.M) P[(size_t)m * g.ldy + n] = acc[i][j][e];
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        store_block_f32(g, acc[i][j], cm.m0 + wm * 64 + i * 32 + 4 * h, cm.n0 + wn * 64 + j * 32 + r, cm.M);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            cm = nm, ckt = 0;
+            if (!nm_valid) cm.KT = 1 << 30;    // (the padding step of an odd stream ends no work item)
+            nm_valid = false;
+#ifdef MEL_SPLIT_PROF
+            pe += GEMM_T() - q4;
+#endif
+        }
+    };
+    for (int it = 0; it < (nsteps + 1) >> 1; ++it) {       // counted loop over pairs of steps (see gemm_split_kernel)
+        step(R1);
+        step(R0);
+    }
+#ifdef MEL_SPLIT_PROF
+    // tuning builds (-DMEL_GEMM_PROF=99 -DMEL_SPLIT_PROF, tools/split_prof.py): cycles of wave 0 of every workgroup in [0] stream
+    // bookkeeping, [1] fragment reads + MFMAs with fill / prefetch between them, [2] LDS writes landing, [3] barrier, [4] epilogue, [5] kernel
+    if (tid == 0) {
+        atomicAdd(&g_gemm_prof[0], pi_), atomicAdd(&g_gemm_prof[1], pm), atomicAdd(&g_gemm_prof[2], pw);
+        atomicAdd(&g_gemm_prof[3], pb), atomicAdd(&g_gemm_prof[4], pe), atomicAdd(&g_gemm_prof[5], GEMM_T() - pk0);
+        atomicAdd(&g_gemm_prof[6], 1ull), atomicAdd(&g_gemm_prof[7], (unsigned long long)nsteps);
+#pragma unroll
+        for (int k = 0; k < 13; ++k) atomicAdd(&g_split_prof[k], fine[k]);
+    }
+#endif
+}
+
+// fp32 [rows, K] weight matrices -> [rows][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k), all matrices of the model in one launch
 struct SplitBatch {
     const float* src[CVT_MAX_SEG];
     uint16_t* dst[CVT_MAX_SEG];
@@ -269,10 +604,10 @@ __global__ __launch_bounds__(256) void split_weights_kernel(SplitBatch b) {
     const int row = i / K, k = i - row * K;
     u32x2 hi, mid, lo;
     split4(*reinterpret_cast<const f32x4*>(b.src[s] + i), hi, mid, lo);
-    uint16_t* d = b.dst[s] + (size_t)row * 3 * K + k;
+    uint16_t* d = b.dst[s] + (size_t)row * 3 * K + (k >> 4) * 48 + (k & 15);
     *reinterpret_cast<u32x2*>(d) = hi;
-    *reinterpret_cast<u32x2*>(d + K) = mid;
-    *reinterpret_cast<u32x2*>(d + 2 * K) = lo;
+    *reinterpret_cast<u32x2*>(d + 16) = mid;
+    *reinterpret_cast<u32x2*>(d + 32) = lo;
 }
 
 }  // namespace mel

@@ -188,3 +188,58 @@ def test_prepared_weights_follow_weight_versions(dtype):
         fresh.set_feature_dtype(dtype)
         fresh.conv2.lin_l.weight.mul_(1.5)
         assert not torch.equal(changed, first) and torch.equal(changed, fresh(obs)[0])
+
+
+@pytest.mark.parametrize("m,n,k,tile,ksplit", [
+    (1000, 512, 512, 1, 0), (1000, 512, 512, 2, 0),          # ragged rows (1000 = 7 x 128 + 104)
+    (4820, 256, 1152, 2, 3), (4820, 256, 1152, 2, 0),        # the heads' first layer, split-K and not
+    (129, 128, 128, 2, 0), (1, 128, 128, 2, 0),              # one row beyond a tile; a single row
+    (333, 384, 256, 2, 2), (2048, 640, 160, 1, 0)])
+def test_split_gemm_matches_float64(m, n, k, tile, ksplit):
+    """mel_gemm_f32_split (MEL_PREC_F32_SPLIT's projections on their own): fp32 operands split exactly into three bf16
+    pieces, six partial products per term on the bf16 matrix cores, fp32 accumulation - as close to the float64 product as
+    an fp32 GEMM is.  Both tile shapes (64 x 64, 128 x 128) and the 128 x 128 kernel's split-K."""
+    from melissa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).cuda()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    y = torch.full((m, n), float("nan"), device="cuda")
+    scratch = torch.empty(6 * n * k + 256 + 4 * max(ksplit, 1) * m * n, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.mel_gemm_f32_split(a.data_ptr(), k, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, n, k, 1, tile, ksplit,
+                                      scratch.data_ptr(), scratch.numel(), _lib.current_stream_ptr()))
+    want = torch.relu(torch.addmm(b.double(), a.double(), w.double().t()))
+    err = float((y.double() - want).abs().max())
+    native = float((torch.relu(torch.addmm(b, a, w.t())).double() - want).abs().max())
+    print(f"split gemm {m}x{n}x{k} tile {tile} ksplit {ksplit}: max error {err:.1e} (torch fp32 matmul: {native:.1e})")
+    assert err <= 4e-6 * max(1.0, float(want.abs().max()))
+
+
+def test_split_gemm_rejects_shapes_the_big_tile_cannot_take():
+    from melissa_amd import _lib
+    lib = _lib.load()
+    a = torch.zeros(64, 128, device="cuda"); w = torch.zeros(192, 128, device="cuda"); y = torch.zeros(64, 192, device="cuda")
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    st = lib.mel_gemm_f32_split(a.data_ptr(), 128, w.data_ptr(), None, y.data_ptr(), 192, 64, 192, 128, 0, 2, 0, scratch.data_ptr(),
+                                scratch.numel(), _lib.current_stream_ptr())
+    assert st == _lib.ERR_UNSUPPORTED                                  # N = 192 is no multiple of 128
+    st = lib.mel_gemm_f32_split(a.data_ptr(), 128, w.data_ptr(), None, y.data_ptr(), 192, 64, 192, 128, 0, 1, 0, scratch.data_ptr(),
+                                16, _lib.current_stream_ptr())
+    assert st == _lib.ERR_UNSUPPORTED                                  # scratch too small
+
+
+def test_split_precision_at_the_benchmark_size():
+    """L-DGN N = 50, 1024 envs at MEL_PREC_F32_SPLIT: conv2's projections and the heads' first layer then run on the
+    128 x 128 split kernel (split-K for the heads).  Same bar as everywhere: logits within 1e-4 of the native fp32 path
+    (itself within 1e-4 of the oracle at this size: test_full_size_* in test_gpu_forward.py)."""
+    n, bs = 50, 1024
+    obs = torch.from_numpy(random_obs(n, bs, 3)).cuda()
+    net, _ = make_net("l_dgn", n, seed=2)
+    with torch.no_grad():
+        native = net(obs)[0].clone()
+        net.set_feature_dtype("f32s")
+        got = net(obs)[0].clone()
+    err = float((got - native).abs().max())
+    print(f"l_dgn N=50 bs=1024: split vs native fp32 logits {err:.2e}")
+    assert err <= 1e-5 and not torch.equal(got, native)

@@ -21,13 +21,20 @@ def main():
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--tiles", default="1,2")
     ap.add_argument("--bf16", action="store_true", help="the bf16 feature-path GEMM (mel_gemm_bf16; tiles 1 / 2)")
+    ap.add_argument("--split", action="store_true", help="fp32 via split bf16 operands (mel_gemm_f32_split; tiles 1 / 2, weights pre-split)")
+    ap.add_argument("--ksplit", type=int, default=0, help="with --split: split-K chunks of the 128 x 128 kernel where K allows")
+    ap.add_argument("--lda-pad", type=int, default=0, help="extra floats per A row (row stride K + pad)")
+    ap.add_argument("--shapes", default="", help="comma-separated shape names (default: all)")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda")
     tiles = [int(t) for t in args.tiles.split(",")]
     torch.manual_seed(0)
     for name, M, N, K in SHAPES:
-        A = torch.randn(M, K, device=dev)
+        if args.shapes and name not in args.shapes.split(","):
+            continue
+        lda = K + args.lda_pad
+        A = torch.randn(M, lda, device=dev)[:, :K]
         W = torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)
         Y = torch.empty(M, N, device=dev)
@@ -36,14 +43,24 @@ def main():
             ref = torch.addmm(b, A.float(), W.float().t())
             gemm = lambda t: lib.mel_gemm_bf16(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, 0, t,
                                                _lib.current_stream_ptr())
+        elif args.split:
+            ref = torch.addmm(b.double(), A.double(), W.double().t())
+            ks = args.ksplit if args.ksplit > 1 and (K // 16) % args.ksplit == 0 and K // 16 // args.ksplit >= 4 else 0
+            scratch = torch.empty(6 * N * K + 256 + 4 * max(ks, 1) * M * N, dtype=torch.uint8, device=dev)
+            first = [True]
+            def gemm(t):
+                tt = t if first[0] else t + 100
+                first[0] = False
+                return lib.mel_gemm_f32_split(A.data_ptr(), lda, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, tt,
+                                              ks if t == 2 else 0, scratch.data_ptr(), scratch.numel(), _lib.current_stream_ptr())
         else:
             ref = torch.addmm(b, A, W.t())
-            gemm = lambda t: lib.mel_gemm_f32(A.data_ptr(), K, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
+            gemm = lambda t: lib.mel_gemm_f32(A.data_ptr(), lda, W.data_ptr(), b.data_ptr(), Y.data_ptr(), N, M, N, K, 0, t,
                                               _lib.current_stream_ptr())
         res = {}
         for t in tiles:
             _lib.check(gemm(t))
-            err = (Y.float() - ref).abs().max().item()
+            err = (Y.to(ref.dtype) - ref).abs().max().item()
             res[t] = [err, []]
         for _ in range(args.rounds):
             for t in tiles:

@@ -55,3 +55,10 @@ print(f"  forward + backward {timed(fb):.2f} ms")
 print(f"  optimizer step     {timed(policy.optim.step):.2f} ms")
 with torch.no_grad():
     print(f"  4 collect rounds   {timed(lambda: loop.run(4)):.2f} ms")
+if "--kernels" in sys.argv:                     # per-kernel device time of 10 whole updates (torch profiler, kineto/roctracer)
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(10):
+            L.step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70))
