@@ -342,14 +342,20 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
     dom = max(fl, key=lambda k: stages.get(k, 0.0))
     pmc, pmc_source = pmc_traffic()
     same = (args.mode == "round" and args.model == "l_dgn" and args.nodes == N_NODES and args.envs == ENVS_PER_GPU
-            and args.dtype == "f32")
+            and args.dtype == "f32a")
     key = {"conv1_lin": "conv1 (lin_l+lin_r)", "conv2_lin": "conv2 (lin_l+lin_r)"}.get(dom)
     traffic = pmc.get(key, {}).get("hbm_bytes_corrected") if same else None
     achieved = fl[dom] / (stages[dom] * 1e-6) / 1e12 if stages[dom] > 0 else 0.0
     # f32s: six bf16 MFMAs per product term set -> the matrix-pipe ceiling for fp32-accurate FLOPs is 2.5 PF / 6
-    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "f32s": PEAK_BF16_MFMA_TFLOPS / 6,
+            "f32a": PEAK_BF16_MFMA_TFLOPS / 6}[args.dtype]
     tag = {"conv1_lin": 1, "conv2_lin": 2, "head_hidden": 3}.get(dom, 0)
-    if args.dtype == "f32" and args.mode == "round" and args.model == "l_dgn" and dom != "encoder":
+    split_launch = args.dtype == "f32s" or (args.dtype == "f32a" and dom in ("conv2_lin", "head_hidden") and fl[dom] > 2.5e9)
+    if args.dtype == "f32a":        # per-launch arithmetic: the ceiling is the one of the pipe the dominant launch runs on
+        peak = PEAK_BF16_MFMA_TFLOPS / 6 if split_launch else PEAK_F32_MFMA_TFLOPS
+    if args.dtype == "f32a" and split_launch and args.mode == "round" and args.model == "l_dgn":
+        kname = f"mel::gemm_split_big_kernel<{tag}> ({dom})"                        # as rocprofv3 summaries name it
+    elif args.dtype in ("f32", "f32a") and args.mode == "round" and args.model == "l_dgn" and dom != "encoder":
         kname = f"mel::gemm_f32_persistent_kernel<2, 2, 1, 1, 0, {tag}> ({dom})"   # as rocprofv3 summaries name it
     else:
         kname = f"gemm_{args.dtype} ({dom})"
@@ -359,6 +365,11 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": pmc_source if same else "none: PMC passes exist for the default workload only",
                 "avg_launch_us": round(stages[dom], 2), "algorithmic_flops_per_launch": fl[dom],
+                "arithmetic": ("fp32-accurate product on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 pieces, "
+                               "six exact partial products per term, fp32 accumulate; `achieved` counts the ALGORITHMIC (fp32) FLOPs, "
+                               "`peak` is the bf16 dense MFMA peak 2 500 TF / 6 products; issued bf16 MFMA rate = 6 x achieved"
+                               if split_launch else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)") if args.dtype != "bf16"
+                              else "bf16 MFMA, fp32 accumulate",
                 "rows_per_launch": {"sum_U1": float(mean_tot[0]), "sum_U2": float(mean_tot[1]), "agent_rows": float(mean_tot[2]),
                                     "feature_table_rows": ft["table_rows"], "envs_with_foreign_features": ft["bad_envs"]},
                 "whole_step": {"algorithmic_flops": whole_flops, "stage_sum_us": round(step_us, 2),
@@ -488,7 +499,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--streams", type=int, default=1,
                     help="round mode: sub-batches of the GPU's envs on separate HIP streams")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"],
+    ap.add_argument("--dtype", default="f32a", choices=["f32", "bf16", "f32s", "f32a"],
                     help="f32 (default): the reference's arithmetic, logits within 1e-4.  bf16: BASELINE's 'bf16 feature "
                          "path' (feature rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -562,7 +573,7 @@ def main():
 
     # ---- extra legs: other BASELINE configurations, timed like the headline -----------------------------------------------
     legs = None
-    default_cfg = (args.dtype == "f32" and args.mode == "round" and args.streams == 1 and args.model == "l_dgn"
+    default_cfg = (args.dtype == "f32a" and args.mode == "round" and args.streams == 1 and args.model == "l_dgn"
                    and args.nodes == N_NODES)
     if default_cfg and not args.no_extra_legs:
         del loop, venv
@@ -584,6 +595,9 @@ def main():
                                                  "2 000 feature tuples: a function of the weights only) prepared ONCE per weight "
                                                  "version (mel_prepare_feature_tables) instead of evaluated inside every step as the "
                                                  "headline does; bit-identical logits", prepared_tables=True),
+            "exact_fp32_mfma_only": dict(note="every projection on the exact-fp32 matrix instruction (MEL_PREC_F32; the headline "
+                                              "precision mode MEL_PREC_F32_AUTO sends conv2 and the heads' first layer to the split-bf16 "
+                                              "kernels at this size): round 2's earlier headline", dtype="f32"),
             "f32_via_split_bf16_mfma": dict(note="fp32-accurate projections on the bf16 matrix cores (every operand split exactly into three "
                                                  "bf16 pieces, six partial products; logits 3-7e-8 from the oracle like the native path)",
                                             dtype="f32s"),
@@ -611,13 +625,21 @@ def main():
     if rank != 0:
         return
     value = decisions / dt
-    prec = dict(f32="fp32", bf16="bf16 feature path", f32s="fp32 via split-bf16 MFMA")[args.dtype]
+    prec = dict(f32="fp32", bf16="bf16 feature path", f32s="fp32 via split-bf16 MFMA",
+                f32a="fp32, arithmetic per launch (large projections via split-bf16 MFMA, the rest exact fp32 MFMA)")[args.dtype]
     line = {
         "metric": "env-steps/s (agent-decisions/s) L-DGN 50-node" if args.model == "l_dgn" and args.nodes == 50
                   else f"env-steps/s (agent-decisions/s) {args.model} {args.nodes}-node",
         "value": value, "unit": "agent-decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": "f32" if args.dtype == "f32a" else args.dtype, "data": "synthetic",
+        "precision_mode": {"f32a": "MEL_PREC_F32_AUTO: fp32 operands, fp32 results, fp32 accumulation everywhere (logits within 1e-4 of the "
+                                   "oracle, measured 1e-7); the arithmetic of each dense projection is chosen per launch by its size - the "
+                                   "exact-fp32 matrix instruction, or for the large launches (here conv2 and the heads' first layer) exact "
+                                   "bf16 x 3 operand splitting on the bf16 matrix pipe with six exact partial products per term",
+                           "f32": "MEL_PREC_F32: every projection on the exact-fp32 matrix instruction",
+                           "f32s": "MEL_PREC_F32_SPLIT: every projection by exact bf16 x 3 operand splitting on the bf16 matrix pipe",
+                           "bf16": "MEL_PREC_BF16: bf16 feature rows and projection weights, fp32 accumulate"}[args.dtype],
         "config": {"workload": f"{args.model.upper().replace('_', '-')} {args.nodes}-node, {args.envs} vectorised envs per GPU, {prec}, "
                                f"dynamic graph, eps=0.001, "
                                + ("round-batched loop (one env round per step)" if args.mode == "round"

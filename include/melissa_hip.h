@@ -107,7 +107,7 @@ typedef struct mel_weights {
     mel_gatv2 conv2;       /* unused for HL-DGN                                      */
     mel_mlp   q_head;      /* latent -> ... -> n_actions                             */
     mel_mlp   v_head;      /* latent -> ... -> 1                                     */
-    int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4), MEL_PREC_BF16 or MEL_PREC_F32_SPLIT */
+    int32_t precision;     /* MEL_PREC_F32 (reference arithmetic, logits <= 1e-4), MEL_PREC_BF16, MEL_PREC_F32_SPLIT or MEL_PREC_F32_AUTO */
     int32_t flags;         /* MEL_FWD_PLAN_READY: the plan masks of this call were written by mel_env_round (plan_* sink);
                             * MEL_FWD_INTEGER_FEATURES: see below */
     const void* prepared;  /* optional (MEL_PREC_BF16 / MEL_PREC_F32_SPLIT): device buffer filled by mel_prepare_weights for THESE
@@ -144,6 +144,13 @@ typedef struct mel_weights {
  * fp32, accumulated in fp32).  As close to the exact dot product as a native fp32 GEMM (csrc/gemm_split.hpp); the
  * reference's parity bar (logits <= 1e-4) holds with the same margin as MEL_PREC_F32. */
 #define MEL_PREC_F32_SPLIT 2
+/* MEL_PREC_F32_AUTO: fp32 features and fp32-accurate results like the two above, with the arithmetic chosen PER LAUNCH: the
+ * large projections of a forward (conv2's lin_l + lin_r and the heads' first layer once their row lists fill the chip with
+ * 128 x 128 tiles: from a few thousand rows on) take the split kernels of MEL_PREC_F32_SPLIT, everything else - small batches
+ * entirely - the exact-fp32 matrix instruction of MEL_PREC_F32.  The choice depends on the expected row counts only, never on
+ * the data.  Weights: the fp32 parameters plus their bf16 planes (prepared or converted per call exactly as for
+ * MEL_PREC_F32_SPLIT, same buffer size).  L-DGN 50-node, 1024 envs: 0.211 -> 0.18 ms per round step. */
+#define MEL_PREC_F32_AUTO 3
 
 /* Convert the projection weights once per weight VERSION instead of once per call (bf16 feature path: bf16 copies; split
  * path: three bf16 planes per weight).  The caller owns the buffer (mel_prepared_weights_bytes; 0 for MEL_PREC_F32), calls

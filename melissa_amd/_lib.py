@@ -41,7 +41,7 @@ EXPORTS = ("mel_wait_counter", "mel_feature_tables_bytes", "mel_prepare_feature_
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
            "mel_prof_read", "mel_last_error", "mel_version")
-PREC_F32, PREC_BF16, PREC_F32_SPLIT = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_F32_SPLIT, PREC_F32_AUTO = 0, 1, 2, 3
 FWD_PLAN_READY = 1          # mel_weights.flags: the plan masks of this call were written by mel_env_round
 FWD_INTEGER_FEATURES = 2    # mel_weights.flags: node features are the env's integers -> node-feature table (melissa_hip.h)
 HEURISTICS = {None: 0, "simple_broadcast": 1, "broadcast_if_any_interested": 2, "silent": 3}

@@ -339,6 +339,21 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
         n128 = n128 && gs[i].N % 128 == 0;
         long_k = long_k && gs[i].K >= 512;
     }
+    if (!gs[0].split && !gs[0].bf16 && big >= MEL_SPLIT_BIG_FROM) {
+        // MEL_PREC_F32_AUTO: every problem carries the bf16 planes of its weights and the launch is large enough for the
+        // 128 x 128 split kernel to win (conv2 in the L-DGN step: 52 against 83 us) - same fp32-accurate results
+        GemmArgs t[GEMM_MAX_GROUP];
+        bool alt = true;
+        for (int i = 0; i < count; ++i) {
+            t[i] = gs[i];
+            alt = alt && gs[i].Ws && !gs[i].split && !gs[i].bf16 && (!gs[i].W_hi || gs[i].Ws_hi);
+            t[i].W = gs[i].Ws, t[i].W_hi = gs[i].W_hi ? gs[i].Ws_hi : nullptr, t[i].split = 1;
+        }
+        if (alt && split_big_fits(t, count, GEMM_MODE_PLAIN)) {
+            gemm_launch_split(t, count, GEMM_MODE_PLAIN, stream, tag, big);
+            return check_launch(what);
+        }
+    }
     if (gs[0].split) {
         for (int i = 1; i < count; ++i)
             if (!gs[i].split) return fail(MEL_ERR_INVALID_ARG, "%s: mixed precisions in one group", what);
@@ -424,8 +439,10 @@ struct ProjWeights {
     const float* c2l; const float* c2r; const float* c2v;
     const float* q[MEL_MAX_HEAD_LAYERS];
     const float* v[MEL_MAX_HEAD_LAYERS];
+    const ProjWeights* alt;        // MEL_PREC_F32_AUTO: the same matrices as bf16 planes (the slots above hold the fp32 ones)
 };
 
+static bool has_planes(const mel_weights* w) { return w->precision == MEL_PREC_F32_SPLIT || w->precision == MEL_PREC_F32_AUTO; }
 static size_t lin_elems(const mel_linear& l) { return l.weight ? (size_t)l.in_dim * l.out_dim : 0; }
 
 // visits every projection weight: f(const mel_linear&, const float** slot)
@@ -510,7 +527,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.hpart = c.take<float>(hw > 0 ? (size_t)HEAD_KSPLIT_MAX * R * hw : 8);
     L.minmax = c.take<float>(64);
     L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
-                 : (w->precision == MEL_PREC_F32_SPLIT) ? 3 * projection_elems(w) : 0;
+                 : has_planes(w) ? 3 * projection_elems(w) : 0;
     if (w->prepared) L.wb_elems = 0;             // the caller holds the converted weights (mel_prepare_weights)
     L.wb = c.take<uint16_t>(L.wb_elems ? L.wb_elems : 8);
     L.bytes = c.off;
@@ -524,7 +541,7 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
     if (bs <= 0 || bs > (1 << 24)) return fail(MEL_ERR_INVALID_ARG, "bs=%ld out of range", (long)bs);
     if (n < 1 || n > MEL_MAX_NODES) return fail(MEL_ERR_INVALID_ARG, "n_nodes=%d outside [1, %d]", n, MEL_MAX_NODES);
     if (w->in_dim < 1 || w->in_dim > 8) return fail(MEL_ERR_UNSUPPORTED, "in_dim=%d outside [1, 8]", w->in_dim);
-    if (w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_SPLIT) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
+    if (w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_AUTO) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
     const int expected = n * (w->in_dim + 3);
     if (index_col) {
         if (obs_stride - 1 != expected)      // networks/common.py:24-29
@@ -583,14 +600,22 @@ static mel_status validate(const mel_weights* w, int model, int64_t bs, int n, i
 // split: bf16 copies (planes) - taken from the caller's PREPARED buffer (mel_prepare_weights: converted once per weight
 // version, nothing launched here) or, when mel_weights.prepared is null, converted into `dst` (the workspace) by one launch
 // on every call, which keeps a caller that never prepares correct.  convert = false only lays the pointers out.
-static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjWeights& pw, hipStream_t s, bool convert) {
-    pw = ProjWeights{};
-    if (w->precision == MEL_PREC_F32_SPLIT) {        // [rows][K / 16][3][16] bf16 planes of every projection weight
+static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjWeights& pw, ProjWeights& alt, hipStream_t s,
+                                      bool convert) {
+    pw = ProjWeights{}, alt = ProjWeights{};
+    if (w->precision == MEL_PREC_F32_SPLIT || w->precision == MEL_PREC_F32_AUTO) {
+        // [rows][K / 16][3][16] bf16 planes of every projection weight; AUTO: beside the fp32 matrices themselves
+        const bool both = w->precision == MEL_PREC_F32_AUTO;
+        ProjWeights& planes = both ? alt : pw;
+        if (both) {
+            for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) { *slot = l.weight; });
+            pw.alt = &alt;
+        }
         SplitBatch b{};
         size_t off = 0;
         int blocks = 0;
         bool bad = false;
-        for_each_projection(w, pw, [&](const mel_linear& l, const float** slot) {
+        for_each_projection(w, planes, [&](const mel_linear& l, const float** slot) {
             const size_t cnt = lin_elems(l);
             if (b.n >= CVT_MAX_SEG || cnt % 8 != 0 || l.in_dim % 32 != 0 || !l.weight) { bad = true; return; }
             b.src[b.n] = l.weight, b.dst[b.n] = dst + off, b.count[b.n] = (int)cnt, b.K[b.n] = l.in_dim, b.start[b.n] = blocks;
@@ -599,6 +624,10 @@ static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjW
             off += 3 * ((cnt + 7) & ~(size_t)7);
             ++b.n;
         });
+        if (bad && both) {                       // AUTO: shapes the split kernels cannot take simply stay on the exact-fp32 path
+            alt = ProjWeights{}, pw.alt = nullptr;
+            return MEL_OK;
+        }
         if (bad) return fail(MEL_ERR_UNSUPPORTED, "split path: a projection weight is null or its shape is unsupported");
         if (!convert) return MEL_OK;
         b.start[b.n] = blocks;
@@ -629,12 +658,12 @@ static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjW
     return check_launch("weights -> bf16");
 }
 static size_t prepared_elems(const mel_weights* w) {
-    return w->precision == MEL_PREC_BF16 ? projection_elems(w) : w->precision == MEL_PREC_F32_SPLIT ? 3 * projection_elems(w) : 0;
+    return w->precision == MEL_PREC_BF16 ? projection_elems(w) : has_planes(w) ? 3 * projection_elems(w) : 0;
 }
-static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, hipStream_t s) {
+static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, ProjWeights& alt, hipStream_t s) {
     if (w->prepared && w->precision != MEL_PREC_F32)
-        return resolve_projections(w, static_cast<uint16_t*>(const_cast<void*>(w->prepared)), pw, s, false);
-    return resolve_projections(w, L.wb, pw, s, true);
+        return resolve_projections(w, static_cast<uint16_t*>(const_cast<void*>(w->prepared)), pw, alt, s, false);
+    return resolve_projections(w, L.wb, pw, alt, s, true);
 }
 
 // dueling heads: hidden layers through the GEMM (Q | V stacked along n), last layer + combine in the tail.
@@ -662,7 +691,18 @@ static mel_status run_heads(const mel_weights* w, const ProjWeights& pw, const F
         g.Y = L.hpart, g.ldy = 2 * HF_W, g.M = (int)rows, g.M_dev = rows_dev, g.N = 2 * HF_W, g.K = q.in_dim;
         g.bf16 = bf, g.split = sp, g.y_f32 = 1;
         const long hint = rows_hint < 0 || rows_hint > rows ? rows : rows_hint;
-        const int S = choose_ksplit(g, hint, HEAD_KSPLIT_MAX);
+        int S = choose_ksplit(g, hint, HEAD_KSPLIT_MAX);
+        if (pw.alt && pw.alt->q[0] && pw.alt->v[0]) {     // MEL_PREC_F32_AUTO: the split kernel when its work items fill the chip
+            GemmArgs t = g;
+            t.W = pw.alt->q[0], t.W_hi = pw.alt->v[0], t.split = 1;
+            const int St = choose_ksplit(t, hint, HEAD_KSPLIT_MAX);
+            const long tiles = ((hint + 127) / 128) * (t.N / 128);
+            t.ksplit = St > 1 ? St : 0;
+            if ((St > 1 || tiles >= MEL_SPLIT_BIG_FROM) && split_big_fits(&t, 1, GEMM_MODE_PLAIN)) {
+                t.ksplit = 0;
+                g = t, S = St;
+            }
+        }
         if (q.in_dim == v.in_dim && q.out_dim == HF_W && v.out_dim == HF_W && q1.in_dim == HF_W &&
             q1.out_dim == HF_W && v1.in_dim == HF_W && v1.out_dim == HF_W && w->q_head.layer[2].out_dim <= HF_MAX_ACTIONS &&
             w->v_head.layer[2].out_dim == 1 && q1.weight && v1.weight) {
@@ -815,8 +855,8 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const bool single = agent_mask == nullptr;
     const int bf = w->precision == MEL_PREC_BF16;
     const int sp = w->precision == MEL_PREC_F32_SPLIT;
-    ProjWeights pw;
-    if (mel_status st = resolve_projections(w, L, pw, s)) return st;
+    ProjWeights pw, pw_alt;
+    if (mel_status st = resolve_projections(w, L, pw, pw_alt, s)) return st;
     // round-batched loop, measured on the bench workload (per env, N = 20 / 50): |L| = 3.1 / 4.7, |U1| = 5.8 / 10.4,
     // |U2| = 7.6 / 15.8 - linear fits below
     const long hintL = single ? bs : (n < 10 ? bs : bs * (long)(36 + n) / 18);
@@ -918,6 +958,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         if (tconv) g[0].W_hi = pw.c2v, g[0].bias_hi = w->conv2.lin_v.bias, g[0].split_n = hc;
         g[1].A = L.h1, g[1].lda = hc, g[1].arow = L.plan.arow_g, g[1].rscale = L.plan.dm_g;
         g[1].W = pw.c2r, g[1].bias = w->conv2.lin_r.bias;
+        if (pw.alt) g[0].Ws = pw.alt->c2l, g[0].Ws_hi = tconv ? pw.alt->c2v : nullptr, g[1].Ws = pw.alt->c2r;
         g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;
         const long hints[2] = {hint1, hintL};
         StageScope t(MEL_STAGE_CONV2_LIN, s);
@@ -1009,7 +1050,7 @@ size_t mel_abi_sizeof(int32_t which) {
 const char* mel_version(void) { return "melissa_hip 0.5 (gfx950)"; }
 
 size_t mel_prepared_weights_bytes(const mel_weights* w) {
-    if (!w || w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_SPLIT) return 0;
+    if (!w || w->precision < MEL_PREC_F32 || w->precision > MEL_PREC_F32_AUTO) return 0;
     return prepared_elems(w) * sizeof(uint16_t);
 }
 
@@ -1029,21 +1070,21 @@ mel_status mel_prepare_feature_tables(const mel_weights* w, int32_t n_nodes, voi
         return fail(MEL_ERR_INVALID_ARG, "bf16 / split precision: prepare the weights first (mel_prepare_weights)");
     clear_stale_error();
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ProjWeights pw;
+    ProjWeights pw, pw_alt;
     FwdLayout none{};
-    if (mel_status st = resolve_projections(w, none, pw, s)) return st;
+    if (mel_status st = resolve_projections(w, none, pw, pw_alt, s)) return st;
     return run_feature_tables(w, pw, n_nodes, carve_tables(w, n_nodes, tables, nullptr), s);
 }
 
 mel_status mel_prepare_weights(const mel_weights* w, void* prepared, size_t bytes, void* stream) {
     if (!w) return fail(MEL_ERR_INVALID_ARG, "weights pointer is null");
     if (w->precision == MEL_PREC_F32) return MEL_OK;                 // the fp32 path reads the parameters themselves
-    if (w->precision != MEL_PREC_BF16 && w->precision != MEL_PREC_F32_SPLIT) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
+    if (w->precision != MEL_PREC_BF16 && !has_planes(w)) return fail(MEL_ERR_INVALID_ARG, "precision=%d", w->precision);
     const size_t need = prepared_elems(w) * sizeof(uint16_t);
     if (!prepared || bytes < need) return fail(MEL_ERR_WORKSPACE, "prepared-weights buffer %zu < %zu bytes", bytes, need);
     clear_stale_error();
-    ProjWeights pw;
-    return resolve_projections(w, static_cast<uint16_t*>(prepared), pw, static_cast<hipStream_t>(stream), true);
+    ProjWeights pw, pw_alt;
+    return resolve_projections(w, static_cast<uint16_t*>(prepared), pw, pw_alt, static_cast<hipStream_t>(stream), true);
 }
 
 size_t mel_workspace_bytes(const mel_weights* w, int64_t bs, int32_t n_nodes) {
@@ -1110,8 +1151,8 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     const int M = (int)(bs * n);
     const int bf = w->precision == MEL_PREC_BF16;
     const int sp = w->precision == MEL_PREC_F32_SPLIT;
-    ProjWeights pw;
-    if (mel_status st = resolve_projections(w, L, pw, s)) return st;
+    ProjWeights pw, pw_alt;
+    if (mel_status st = resolve_projections(w, L, pw, pw_alt, s)) return st;
     const int T = n * FEATURE_TUPLES_PER_DEGREE;      // node-feature table (plan_masks.hpp): every node is a row here
     const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && M >= 2L * T;
 

@@ -65,6 +65,10 @@ struct GemmArgs {
     int y_f32 = 0;
     // split path (gemm_split.hpp): A / Y fp32 as usual, W / W_hi point at [N][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k)
     int split = 0;
+    // MEL_PREC_F32_AUTO: W / W_hi are the fp32 matrices as usual and Ws / Ws_hi their bf16 planes; the launcher takes the split
+    // kernel when the launch is large enough for it to win and the exact-fp32 kernel otherwise
+    const float* Ws = nullptr;
+    const float* Ws_hi = nullptr;
     // split-K (specialised-wavefront kernel only): the K range is cut into `ksplit` equal chunks, chunk s writes its RAW
     // partial products (no scale / bias / ReLU) to Y + s * part_stride; splitk_finish_kernel sums the planes in order
     int ksplit = 0;

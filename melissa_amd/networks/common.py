@@ -138,12 +138,14 @@ class HipForwardMixin:
 
     # "f32": the reference's arithmetic (logits within 1e-4).  "bf16": BASELINE's "bf16 feature path" - feature
     # rows and projection weights in bf16, fp32 accumulation / softmax / logits.  "f32s": fp32 features and
-    # fp32-accurate projections evaluated on the bf16 matrix cores by operand splitting (MEL_PREC_F32_SPLIT).
-    feature_dtype = "f32"
+    # fp32-accurate projections evaluated on the bf16 matrix cores by operand splitting (MEL_PREC_F32_SPLIT).  "f32a":
+    # fp32-accurate like both, the arithmetic chosen per launch by size (MEL_PREC_F32_AUTO): the split kernels for the large
+    # projections of a big batch, the exact-fp32 matrix instruction for everything else.
+    feature_dtype = "f32a"
 
     def set_feature_dtype(self, name: str):
-        if name not in ("f32", "bf16", "f32s"):
-            raise ValueError(f"feature_dtype must be 'f32', 'bf16' or 'f32s', got {name!r}")
+        if name not in ("f32", "bf16", "f32s", "f32a"):
+            raise ValueError(f"feature_dtype must be 'f32', 'bf16', 'f32s' or 'f32a', got {name!r}")
         self.feature_dtype = name
         self._w_cache = None
         return self
@@ -217,7 +219,8 @@ class HipForwardMixin:
             _mlp(w.q_head, [self.out_linear])
             _mlp(w.v_head, [self.out_linear])     # ignored by the kernels when dueling == 0
             w.v_head.layer[0].out_dim = 1
-        w.precision = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f32s": _lib.PREC_F32_SPLIT}[self.feature_dtype]
+        w.precision = {"f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "f32s": _lib.PREC_F32_SPLIT,
+                       "f32a": _lib.PREC_F32_AUTO}[self.feature_dtype]
         self._w_cache = (key, w)
         return w
 

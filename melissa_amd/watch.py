@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--envs", type=int, default=1)
     ap.add_argument("--episodes", type=int, default=10)
     ap.add_argument("--load", default=None)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s", "f32a"])
     a = ap.parse_args()
     print(json.dumps(watch(a.model, a.nodes, a.envs, a.episodes, a.load, feature_dtype=a.dtype)))
 

@@ -155,7 +155,7 @@ def test_bf16_round_forward_matches_fp32_round_forward():
     check_against_fp32(got, want, f"round forward, {rows} agent rows")
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32s"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32s", "f32a"])
 def test_prepared_weights_follow_weight_versions(dtype):
     """The converted projection weights are prepared once per weight VERSION (mel_prepare_weights into a caller-owned
     buffer), not per call: a forward after an in-place parameter change (optimizer step, load_state_dict) must see the new
@@ -237,9 +237,33 @@ def test_split_precision_at_the_benchmark_size():
     obs = torch.from_numpy(random_obs(n, bs, 3)).cuda()
     net, _ = make_net("l_dgn", n, seed=2)
     with torch.no_grad():
+        net.set_feature_dtype("f32")
         native = net(obs)[0].clone()
         net.set_feature_dtype("f32s")
         got = net(obs)[0].clone()
     err = float((got - native).abs().max())
     print(f"l_dgn N=50 bs=1024: split vs native fp32 logits {err:.2e}")
     assert err <= 1e-5 and not torch.equal(got, native)
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "dgn_r", "hl_dgn"])
+def test_default_precision_chooses_per_launch(model):
+    """The networks' default precision "f32a" (MEL_PREC_F32_AUTO): fp32-accurate results with the arithmetic chosen per launch
+    by the expected row counts.  A small batch runs entirely on the exact-fp32 matrix instruction (bit-identical to "f32");
+    at the benchmark's size conv2 and the heads' first layer take the split-bf16 kernels (L-DGN / DGN-R; HL-DGN has no conv2 and
+    one head row per env) - different summation, same bar: within 1e-5 of the exact-fp32 path, which the full-size tests of
+    test_gpu_forward.py hold within 1e-4 of the oracle."""
+    n = 50
+    net, _ = make_net(model, n, seed=4)
+    assert net.feature_dtype == "f32a"
+    for bs, switched in ((16, False), (1024, model != "hl_dgn")):
+        obs = torch.from_numpy(random_obs(n, bs, 5)).cuda()
+        with torch.no_grad():
+            net.set_feature_dtype("f32a")
+            auto = net(obs)[0].clone()
+            net.set_feature_dtype("f32")
+            exact = net(obs)[0].clone()
+        err = float((auto - exact).abs().max())
+        print(f"{model} bs={bs}: auto vs exact fp32 {err:.2e}")
+        assert err <= 1e-5
+        assert torch.equal(auto, exact) != switched

@@ -35,7 +35,7 @@ def make(model, n, seed=9):
     return net, sd
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "f32s"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f32s", "f32a"])
 @pytest.mark.parametrize("model", ["l_dgn", "dgn_r", "hl_dgn"])
 @pytest.mark.parametrize("n,bs", [(20, 512), (50, 700), (100, 640)])
 def test_table_path_is_bit_identical_to_row_lists(model, n, bs, dtype):

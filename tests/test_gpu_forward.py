@@ -160,8 +160,9 @@ def test_full_size_linearity_property():
     m[:, :, 2:7] = rng.randint(0, 3, size=(bs, n, 5))
     m[:, :, 7] = 1
     obs[:, -1] = rng.randint(0, n, size=bs)
-    for model in ("l_dgn", "hl_dgn"):
+    for model, dtype in (("l_dgn", "f32"), ("hl_dgn", "f32"), ("l_dgn", "f32a")):
         net, _ = make_net(model, n, seed=9)
+        net.set_feature_dtype(dtype)
         t = torch.from_numpy(obs).cuda()
         with torch.no_grad():
             a = net(t)[0].clone()
@@ -171,7 +172,10 @@ def test_full_size_linearity_property():
             d = net(t[:77])[0]
         assert torch.equal(a, b)
         assert torch.equal(a[perm], c)
-        assert torch.equal(a[:77], d)
+        if dtype == "f32":
+            assert torch.equal(a[:77], d)
+        else:       # "f32a" picks each launch's arithmetic by its size: 1024 rows and 77 rows take different (fp32-accurate) kernels
+            assert float((a[:77] - d).abs().max()) <= 1e-5
         assert torch.isfinite(a).all()
 
 

@@ -115,13 +115,57 @@ def oracle_round(pz, act_of_agent):
 def test_round_loop_matches_oracle(n, dynamic, supply):
     """``supply`` "stream": the episodes come from the device sampler through a 5-slot ring (3 slots at N = 50; refilled every 2 rounds - every round -
     on a side stream), so every env's k-th reset - far beyond the first ring - must equal the oracle env's k-th reset."""
+    round_loop_vs_oracle(n, dynamic, supply)
+
+
+def test_round_forward_at_the_split_kernels_batch_matches_oracle():
+    """768 envs of 50 nodes: from a few thousand agent rows per round on, the default precision (MEL_PREC_F32_AUTO) sends conv2's
+    projections and the heads' first layer to the 128 x 128 split-bf16 kernels - the launches the benchmark's step spends most
+    of its time in.  Every logit of those rounds against the oracle (<= 1e-4), every chosen action against the oracle's argmax
+    wherever its margin exceeds the tolerance.  (The env half does not depend on the batch size: the per-env comparisons of
+    test_round_loop_matches_oracle cover it.)"""
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.policy import DQNPolicy
+    from oracle import net_oracle as no
+    n, B = 50, 768
+    venv = HipGraphVectorEnv(B, n, graph_pool=synthetic_graph_pool(n, 16, first_seed=50), dynamic_graph=True, device="cuda",
+                             max_moves=48, seed=123, construct_like_reference=False)
+    net, sd = make_ldgn(n)
+    assert net.feature_dtype == "f32a"
+    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=5)
+    torch.set_num_threads(16)
+    big_rounds = 0
+    for it in range(12):
+        live = loop.live.cpu().numpy().view(np.uint64).reshape(B, -1)[:, 0].copy()
+        mat = venv.obs_matrix().cpu().numpy().copy()
+        loop.step()
+        torch.cuda.synchronize()
+        envs, agents = np.nonzero((live[:, None] >> np.arange(n, dtype=np.uint64)[None, :]) & np.uint64(1))
+        assert int(loop.offsets[-1]) == len(envs)
+        if len(envs) < 3072 or big_rounds >= 3:      # (ceil(U1 / 128) + ceil(R / 128)) * 4 >= 192 big tiles needs U1 >= R >= 3072
+            continue
+        big_rounds += 1
+        obs_rows = np.concatenate([mat[envs], agents[:, None].astype(np.float32)], axis=1)
+        want = no.ldgn_forward(sd, obs_rows, n).numpy()
+        got = loop.logits[:len(envs)].cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+        act = loop.act[:len(envs)].cpu().numpy()
+        srt = np.sort(want, axis=1)
+        clear = srt[:, -1] - srt[:, -2] > 2 * TOL
+        np.testing.assert_array_equal(act[clear], want.argmax(axis=1)[clear])
+        print(f"round {it}: {len(envs)} agent rows, max |logit error| {np.abs(got - want).max():.2e}")
+    assert big_rounds >= 2 and loop.counters()["errors"] == 0
+
+
+def round_loop_vs_oracle(n, dynamic, supply, B=6, K=40):
     from melissa_amd import _lib as L
     from melissa_amd.collect import RoundLoop, sample_episode_table
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
     from melissa_amd.policy import DQNPolicy
     from oracle import env_oracle as eo
     from oracle import net_oracle as no
-    B, seed, K = 6, 77, 40
+    seed = 77
     graphs = synthetic_graph_pool(n, 3, first_seed=50)
     venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=dynamic, device="cuda", max_moves=48,
                              construct_like_reference=False)

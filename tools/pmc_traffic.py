@@ -16,8 +16,12 @@ from melissa_amd import build  # noqa: E402  (source hash of the library the pas
                                 #              from a file whose hash matches the library it is timing)
 
 # launches of the round step by kernel name (the call site is part of it: TAG 1 = conv1, 2 = conv2, 3 = heads)
-LAUNCHES = {"conv1 (lin_l+lin_r, feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 0>", "conv2 (lin_l+lin_r)": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
-         "head0 (Q|V, split-K)": "gemm_f32_ring_kernel<3,", "head finish": "head_finish_kernel",
+# (default precision MEL_PREC_F32_AUTO: conv2 and the heads' first layer run the 128 x 128 split-bf16 kernel at this size;
+#  the exact-fp32 names stay in the list for builds / workloads that launch those)
+LAUNCHES = {"conv1 (lin_l+lin_r, feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 0>", "conv2 (lin_l+lin_r)": "gemm_split_big_kernel<2>",
+         "conv2 (lin_l+lin_r), exact fp32": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
+         "head0 (Q|V, split-K)": "gemm_split_big_kernel<3>", "head0 (Q|V, split-K), exact fp32": "gemm_f32_ring_kernel<3,",
+         "head finish": "head_finish_kernel",
          "conv1 attention": "gat_attend_rows_kernel<8, 0,", "conv2 attention": "gat_attend_rows_kernel<8, 2,",
          "env round": "env_round_kernel", "encoder (feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 1>",
          "plan lists": "plan_lists_kernel"}
@@ -36,7 +40,7 @@ def main():
                       "--no-cpu-baseline --no-profile --no-graph",
            "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
                          "MI355X_MICROARCH.md section HBM)",
-           "workload": "L-DGN 50-node, 1024 envs, round loop, fp32", "source_hash": build.source_hash(), "per_launch": {}}
+           "workload": "L-DGN 50-node, 1024 envs, round loop, fp32 (MEL_PREC_F32_AUTO)", "source_hash": build.source_hash(), "per_launch": {}}
     for name, needle in LAUNCHES.items():
         f, w = mean_counter(sys.argv[1], "FETCH_SIZE", needle), mean_counter(sys.argv[2], "WRITE_SIZE", needle)
         if f == 0 and w == 0:

@@ -20,7 +20,7 @@ for name, cases in PARTS.items():
         continue
     for n, dyn, supply in cases:
         t0 = time.time()
-        t.test_round_loop_matches_oracle(n, dyn, supply)
+        t.round_loop_vs_oracle(n, dyn, supply)
         print(f"l_dgn round loop n={n} dynamic={dyn} episodes={supply}: bit-exact env state + logits within 1e-4 of the oracle "
               f"({time.time() - t0:.1f} s)", flush=True)
 if part in ("all", "hldgn"):
