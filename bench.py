@@ -374,7 +374,11 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
                                     "feature_table_rows": ft["table_rows"], "envs_with_foreign_features": ft["bad_envs"]},
                 "whole_step": {"algorithmic_flops": whole_flops, "stage_sum_us": round(step_us, 2),
                                "achieved": round(whole_flops / (step_us * 1e-6) / 1e12, 3) if step_us > 0 else None,
-                               "frac": round(whole_flops / (step_us * 1e-6) / 1e12 / peak, 4) if step_us > 0 else None}}
+                               # per-launch precision: the step mixes both matrix pipes, so its algorithmic (fp32) FLOP rate is
+                               # quoted against the exact-fp32 MFMA peak - what the step would be bound by without the split launches
+                               "peak": PEAK_F32_MFMA_TFLOPS if args.dtype == "f32a" else peak,
+                               "frac": round(whole_flops / (step_us * 1e-6) / 1e12 /
+                                             (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32a" else peak), 4) if step_us > 0 else None}}
 
     # HBM-side rooflines of the non-contraction kernels: COMPULSORY bytes per launch - every row the launch
     # needs read once, every row it produces written once - over the launch's average duration, against the HBM peak.  They
