@@ -460,6 +460,14 @@ def learner_leg(args, device, rank, world, parallel, updates=30, rounds_per_upda
     with torch.no_grad():
         loop.run(8)
     learner.step()                                             # warm-up update (lazy init of the autograd kernels, RCCL)
+    captured = False
+    if world == 1:                    # one rank: the update replayed from HIP graphs (melissa_amd.replay.CapturedUpdate); with
+        try:                          # several ranks the eager launches until the captured form has run over RCCL
+            learner.capture()
+            captured = True
+        except Exception as exc:      # noqa: BLE001 - the leg then times the eager update
+            learner.captured = None
+            print(f"[bench] update not captured: {exc!r}", file=sys.stderr)
     torch.cuda.synchronize()
     parallel.barrier()
     c0 = loop.counters()
@@ -487,6 +495,7 @@ def learner_leg(args, device, rank, world, parallel, updates=30, rounds_per_upda
     return {"workload": f"HL-DGN {args.nodes}-node, {envs} envs per GPU, fp32: {rounds_per_update} rounds + 1 DQN update (batch 32 per "
                         f"rank, n-step 4) per iteration, flat-gradient all-reduce over {world} rank(s)",
             "updates": updates, "updates_per_s": updates / dt, "value": dec / dt, "unit": "agent-decisions/s",
+            "update_replayed_from_hip_graphs": captured,
             "grad_elements": reducer.numel, "grad_bytes": reducer.numel * 4, "allreduce_us": allreduce_us,
             "backend": (dist.get_backend() if world > 1 else None)}
 

@@ -52,9 +52,20 @@ class FlatGradAllReducer:
         ref = self.params[0]
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=ref.device)
 
+    @staticmethod
+    def active() -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
     def __call__(self, model=None):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self.active():
             return
+        self.pack()
+        self.reduce()
+        self.unpack()
+
+    # the three phases on their own: a captured update (melissa_amd.replay.CapturedUpdate) replays pack and unpack from HIP
+    # graphs and issues the collective between them eagerly
+    def pack(self):
         off = 0
         for p in self.params:
             n = p.numel()
@@ -63,8 +74,12 @@ class FlatGradAllReducer:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
+
+    def reduce(self):
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
+
+    def unpack(self):
         off = 0
         for p in self.params:
             n = p.numel()

@@ -116,7 +116,17 @@ class DQNPolicy(nn.Module):
         between backward and the optimizer step (the RCCL gradient all-reduce plugs in here)."""
         if self._target and self._iter % self._freq == 0:
             self.sync_weight()
-        self.optim.zero_grad()
+        loss = self.loss_backward(batch)
+        if grad_hook is not None:
+            grad_hook(self.model)
+        self.optim.step()
+        self._iter += 1
+        return {"loss": float(loss)}
+
+    def loss_backward(self, batch) -> torch.Tensor:
+        """zero_grad + forward + loss + backward of one update; returns the detached loss (a device tensor: no host
+        synchronisation here, so that a captured update - melissa_amd.replay.CapturedUpdate - can contain it)."""
+        self.optim.zero_grad(set_to_none=True)
         with torch.enable_grad():
             logits, _ = self.model(batch["obs"])
             act = torch.as_tensor(batch["act"], device=logits.device, dtype=torch.long)
@@ -125,11 +135,7 @@ class DQNPolicy(nn.Module):
             td = returns - q
             loss = torch.nn.functional.huber_loss(q, returns) if self._clip_loss_grad else td.pow(2).mean()
             loss.backward()
-        if grad_hook is not None:
-            grad_hook(self.model)
-        self.optim.step()
-        self._iter += 1
-        return {"loss": float(loss.detach())}
+        return loss.detach()
 
 
 class DGNPolicy(DQNPolicy):

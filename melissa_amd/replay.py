@@ -158,8 +158,10 @@ class DQNLearner:
         self.batch_size, self.n_step, self.gamma, self.grad_hook = batch_size, n_step, gamma, grad_hook
         self.gen = torch.Generator(device=replay.obs.device)
         self.gen.manual_seed(seed)
+        self.captured = None
 
-    def step(self) -> dict:
+    def sample_batch(self) -> dict:
+        """Sample + n-step targets: dict(obs, act, returns) of device tensors, no host synchronisation."""
         b = self.replay.sample(self.batch_size, self.n_step, self.gamma, self.gen)
         with torch.no_grad():
             target_net = self.policy.model_old if getattr(self.policy, "_target", False) else self.policy.model
@@ -170,8 +172,109 @@ class DQNLearner:
             else:
                 best = q_next.max(dim=1).values
             returns = b["ret"] + b["boot_w"] * best
-        self.last_batch = dict(obs=b["obs"], act=b["act"], returns=returns)        # what the update regressed on (tests)
+        return dict(obs=b["obs"], act=b["act"], returns=returns)
+
+    def step(self) -> dict:
+        if self.captured is not None:
+            return self.captured.step()
+        self.last_batch = self.sample_batch()                                      # what the update regressed on (tests)
         return self.policy.learn(dict(self.last_batch), grad_hook=self.grad_hook)
+
+    def capture(self) -> "CapturedUpdate":
+        """From now on ``step`` replays the update from HIP graphs (see :class:`CapturedUpdate`)."""
+        self.captured = CapturedUpdate(self)
+        return self.captured
+
+
+class CapturedUpdate:
+    """One DQN update replayed from HIP graphs instead of issued launch by launch from Python.
+
+    An update is a few hundred small launches (replay sampling, the target forward, forward + backward, Adam) behind
+    ~3 ms of Python; the device needs a third of that.  All shapes of a DQN update are static (batch x (8 N + 1)
+    observations), so after two eager warm-up updates the whole chain is captured once:
+
+        graph A   sample -> n-step targets (target network, HIP forward) -> zero_grad -> forward -> loss -> backward
+                  [-> gradients packed into the reducer's flat buffer]
+        eager     [one all-reduce of the flat buffer + division: RCCL stays outside the capture]
+        graph B   [flat buffer unpacked into the gradients ->] optimizer step
+
+    (one graph when there is no collective).  What stays in Python per update: the target network's periodic weight sync
+    and invalidating the networks' per-weight-version caches (prepared bf16 planes / feature tables are keyed on torch's
+    parameter version counters, which a replay does not bump).  The optimizer must be a torch optimizer with a
+    ``capturable`` flag (Adam / AdamW / ...): it is switched on here and the step counters moved to the device.
+    ``step`` returns the loss as a device tensor (``float()`` it to synchronise); ``last_batch`` aliases the graph's static
+    tensors (valid until the next replay)."""
+
+    def __init__(self, learner: "DQNLearner", warmup: int = 2):
+        self.learner = L = learner
+        policy = L.policy
+        dev = L.replay.obs.device
+        if dev.type != "cuda":
+            raise ValueError("CapturedUpdate needs a ROCm / CUDA device")
+        opt = policy.optim
+        for group in opt.param_groups:
+            if "capturable" not in group:
+                raise ValueError(f"{type(opt).__name__} has no capturable mode; cannot capture its step")
+            group["capturable"] = True
+        for st in opt.state.values():
+            if "step" in st and torch.is_tensor(st["step"]) and not st["step"].is_cuda:
+                st["step"] = st["step"].to(dev)
+        hook = L.grad_hook
+        self.collective = hook is not None and getattr(hook, "active", lambda: True)()
+        if self.collective and not all(hasattr(hook, m) for m in ("pack", "reduce", "unpack")):
+            raise ValueError("a captured update needs a grad_hook with pack / reduce / unpack phases (FlatGradAllReducer)")
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up off the capture stream (lazy inits, optimizer state)
+            for _ in range(warmup):
+                self._sync_target()
+                batch = L.sample_batch()
+                policy.loss_backward(batch)
+                if self.collective:
+                    hook.pack(), hook.reduce(), hook.unpack()
+                opt.step()
+                policy._iter += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_a.register_generator_state(L.gen)
+        with torch.cuda.graph(self.graph_a):
+            self.batch = L.sample_batch()
+            self.loss = policy.loss_backward(self.batch)
+            if self.collective:
+                hook.pack()
+            else:
+                opt.step()
+        self.graph_b = None
+        if self.collective:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+                hook.unpack()
+                opt.step()
+        L.last_batch = self.batch
+
+    def _sync_target(self):
+        policy = self.learner.policy
+        if policy._target and policy._iter % policy._freq == 0:
+            policy.sync_weight()
+
+    def step(self) -> dict:
+        policy = self.learner.policy
+        self._sync_target()
+        self.graph_a.replay()
+        if self.collective:
+            self.learner.grad_hook.reduce()
+            self.graph_b.replay()
+        policy._iter += 1
+        # the replay changed the parameters behind torch's version counters: mark the per-weight-version caches stale (the
+        # prepared planes keep their buffer - launches captured elsewhere hold its address - and are converted again by the
+        # next forward)
+        net = policy.model
+        if getattr(net, "_prepared", None) is not None:
+            net._prepared = (("stale",), net._prepared[1])
+        if getattr(net, "_tables", None) is not None:
+            net._tables = None
+        return {"loss": self.loss.clone()}                     # (self.loss is the graph's static tensor: the next replay overwrites it)
 
 
 class DGNLearner(DQNLearner):

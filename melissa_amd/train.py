@@ -37,12 +37,15 @@ def build_network(name: str, n_nodes: int, device, hidden=128, heads=4):
 
 def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4, batch_size=32, n_step=4,
           gamma=0.99, lr=1e-3, target_update_freq=500, eps=0.1, replay_rounds=64, seed=9, backend=None, log=print,
-          probe=None, graphs=16, ring=16):
+          probe=None, graphs=16, ring=16, capture_updates=None):
     """``probe(update_index, net, learner, phase)`` (optional) is called with phase "before" / "after" around every
     update - tests use it to re-derive an update's loss from the sampled batch with the oracle.
     ``graphs``: size of the synthetic training-graph dataset (the reference trains on 50 000 graphs per size, README.md:92-93;
     pools >= 4096 go through the on-disk packed cache, ``melissa_amd.env.cached_graph_pool``).  Episodes come from the
-    device episode stream: every reset draws a new (graph, source, interested set, movement seed) like World.reset."""
+    device episode stream: every reset draws a new (graph, source, interested set, movement seed) like World.reset.
+    ``capture_updates``: replay the DQN update from HIP graphs (``DQNLearner.capture``; L-DGN / HL-DGN - a DGN-R batch has a
+    data-dependent number of sibling rows).  None = on one rank without a probe; with several ranks the collective stays
+    eager between two graphs and the mode is opt-in (True) until it has run over RCCL."""
     rank, local_rank, world = parallel.init_distributed(backend)
     device = torch.device("cuda", local_rank if backend != "gloo" else 0)
     torch.cuda.set_device(device)
@@ -63,6 +66,11 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
                          grad_hook=parallel.FlatGradAllReducer(net), seed=seed + rank)
     with torch.no_grad():
         loop.run(max(n_step + 1, 8))                           # pre-fill (l_dgn.py:201)
+    if capture_updates is None:
+        capture_updates = world == 1 and probe is None
+    captured = bool(capture_updates) and model != "dgn_r" and device.type == "cuda"
+    if captured:
+        learner.capture()                                      # (two warm-up updates, then the graphs)
     t0 = time.perf_counter()
     losses = []
     for _ in range(updates):
@@ -75,11 +83,12 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
             probe(len(losses) - 1, net, learner, "after")
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    losses = [float(x) for x in losses]                        # (device tensors when the update is replayed from graphs)
     c = loop.counters()
     checksum = float(torch.cat([p.detach().flatten() for p in net.parameters()]).double().sum())
     out = dict(rank=rank, world=world, model=model, updates=updates, seconds=dt, loss_first=losses[0],
                loss_last=losses[-1], decisions=c["decisions"], episodes=c["episodes"], errors=c["errors"],
-               param_checksum=checksum)
+               param_checksum=checksum, updates_from_hip_graphs=captured)
     # replicas must be identical after averaged-gradient steps
     same = parallel.all_reduce_max(checksum, device) == parallel.all_reduce_max(-checksum, device) * -1
     out["replicas_identical"] = bool(same)
@@ -100,6 +109,8 @@ def main():
     ap.add_argument("--backend", default=None)
     ap.add_argument("--graphs", type=int, default=16, help="training-graph dataset size (50000 = the reference's)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start (one per GPU) when not under torch.distributed.run")
+    ap.add_argument("--capture-updates", choices=["auto", "on", "off"], default="auto",
+                    help="replay the DQN update from HIP graphs (auto: on one rank)")
     a = ap.parse_args()
     import os
     import sys
@@ -108,7 +119,8 @@ def main():
     if rc is not None:
         raise SystemExit(rc)
     train(model=a.model, n_nodes=a.nodes, envs=a.envs, updates=a.updates, rounds_per_update=a.rounds_per_update,
-          batch_size=a.batch_size, backend=a.backend, graphs=a.graphs)
+          batch_size=a.batch_size, backend=a.backend, graphs=a.graphs,
+          capture_updates={"auto": None, "on": True, "off": False}[a.capture_updates])
 
 
 if __name__ == "__main__":

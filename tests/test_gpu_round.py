@@ -557,3 +557,69 @@ def test_hldgn_fused_selection_equals_the_separate_launch(dueling, n):
                                               rounds.data_ptr(), want.data_ptr(), _lib.current_stream_ptr()))
         assert torch.equal(act, want)
         assert torch.equal(act.view(bs, n).cpu() >= 0, torch.from_numpy(member))      # exactly the member agents got an action
+
+
+@pytest.mark.parametrize("collective", [False, True], ids=["one_graph", "pack_reduce_unpack"])
+@pytest.mark.parametrize("model", ["hl_dgn", "l_dgn"])
+def test_captured_update_equals_the_eager_update(model, collective):
+    """DQNLearner.capture(): the update replayed from HIP graphs (sample -> n-step targets -> forward / backward ->
+    [pack | eager reduce | unpack] -> Adam) must move the parameters exactly like an eager update on the same batch from the same
+    weights and optimizer state - for several consecutive replays (Adam's step counter lives on the device and advances in the
+    graph), across a target-network sync, and the collect loop must see the new weights afterwards (its prepared bf16 planes are
+    keyed on torch's version counters, which a replay does not bump)."""
+    import copy
+    from melissa_amd import parallel
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from melissa_amd.replay import DQNLearner, RoundReplay
+    n, envs = 20, 64
+
+    def make_policy():
+        torch.manual_seed(3)
+        if model == "hl_dgn":
+            net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda")
+        else:
+            net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda")
+        return net, DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-3), estimation_step=4, target_update_freq=3)
+
+    net, policy = make_policy()
+    venv = HipGraphVectorEnv(envs, n, graph_pool=synthetic_graph_pool(n, 8, 0), dynamic_graph=True, device="cuda", max_moves=48,
+                             seed=11, construct_like_reference=False)
+    replay = RoundReplay(envs, n, 16, "cuda")
+    loop = RoundLoop(venv, policy, seed=11, eps=0.1, replay=replay)
+    with torch.no_grad():
+        loop.run(20)
+
+    class LocalReducer(parallel.FlatGradAllReducer):        # the three phases with the collective of a one-rank world
+        active = staticmethod(lambda: True)
+
+        def reduce(self):
+            self.flat.mul_(1.0)
+
+    hook = LocalReducer(net) if collective else None
+    learner = DQNLearner(policy, replay, batch_size=32, n_step=4, gamma=0.99, grad_hook=hook, seed=2)
+    learner.capture()
+    twin_net, twin = make_policy()
+    for k in range(5):                                       # covers two target syncs (every 3 updates; 2 warm-up updates ran)
+        twin_net.load_state_dict(net.state_dict())
+        twin.model_old.load_state_dict(policy.model_old.state_dict())
+        twin.optim.load_state_dict(copy.deepcopy(policy.optim.state_dict()))
+        twin._iter = policy._iter
+        out = learner.step()
+        batch = {key: v.clone() for key, v in learner.last_batch.items()}
+        want = twin.learn(batch)
+        assert abs(float(out["loss"]) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
+        for (name, p), q in zip(net.named_parameters(), twin_net.parameters()):
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-6, (k, name)          # (datt / dbias: fp32 atomics, order of arrival)
+        for p, q in zip(policy.model_old.parameters(), twin.model_old.parameters()):
+            assert torch.equal(p, q)
+    with torch.no_grad():                                    # the collect loop picks the updated weights up
+        loop.run(6)
+        obs = venv.obs_matrix()[:8]
+        idx = torch.zeros(8, 1, device="cuda")
+        got = net.hip_forward(torch.cat([obs, idx], 1))
+        twin_net.load_state_dict(net.state_dict())
+        assert torch.equal(got, twin_net.hip_forward(torch.cat([obs, idx], 1)))
+    assert loop.counters()["errors"] == 0

@@ -55,6 +55,9 @@ print(f"  forward + backward {timed(fb):.2f} ms")
 print(f"  optimizer step     {timed(policy.optim.step):.2f} ms")
 with torch.no_grad():
     print(f"  4 collect rounds   {timed(lambda: loop.run(4)):.2f} ms")
+if model != "dgn_r":                            # the same update replayed from HIP graphs (DQNLearner.capture)
+    L.capture()
+    print(f"  whole update, replayed from HIP graphs {timed(L.step):.2f} ms")
 if "--kernels" in sys.argv:                     # per-kernel device time of 10 whole updates (torch profiler, kineto/roctracer)
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
