@@ -1,5 +1,6 @@
+"""Eager against HIP-graph-replayed DQN updates (DQNLearner.capture) at the learner leg's size: python tools/captured_update_check.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from melissa_amd.collect import RoundLoop
 from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
