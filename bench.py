@@ -295,6 +295,23 @@ def pmc_traffic():
     return {}, "none: no PMC pass committed"
 
 
+def profiler_average_us(pmc_source, kernel):
+    """Average duration of ``kernel`` in the rocprofv3 --kernel-trace --stats summary committed beside the PMC file whose source
+    hash matched (tools/refresh_profiles.sh writes both in one go): the profiler's view of the same launch, all launches of the
+    profiled command - HIP-graph replays, warm-up and the stage timer's eager pass alike."""
+    if not pmc_source.startswith("profiles/"):
+        return None
+    path = os.path.join(ROOT, pmc_source.split(" ")[0].replace("_pmc_traffic.json", "_round_kernel_stats.csv"))
+    needle = kernel.split(" (")[0].replace("mel::", "")
+    try:
+        for row in open(path):
+            if needle in row and row.startswith('"'):
+                return float(row.split('",')[1].split(",")[2]) / 1e3          # "Name",Calls,TotalDurationNs,AverageNs,...
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
     """Per-stage HIP-event timing of the same step in a separate, untimed pass (eager launches of ONE launch chain, each
     launch group bracketed by an event pair on its stream) -> stage_us, the MFMA roofline of the dominant GEMM launch,
@@ -365,6 +382,7 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_source": pmc_source if same else "none: PMC passes exist for the default workload only",
                 "avg_launch_us": round(stages[dom], 2), "algorithmic_flops_per_launch": fl[dom],
+                "profiler_avg_launch_us": None, "frac_by_profiler_avg": None,
                 "arithmetic": ("fp32-accurate product on the bf16 matrix pipe: every fp32 operand split exactly into three bf16 pieces, "
                                "six exact partial products per term, fp32 accumulate; `achieved` counts the ALGORITHMIC (fp32) FLOPs, "
                                "`peak` is the bf16 dense MFMA peak 2 500 TF / 6 products; issued bf16 MFMA rate = 6 x achieved"
@@ -379,6 +397,12 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
                                "peak": PEAK_F32_MFMA_TFLOPS if args.dtype == "f32a" else peak,
                                "frac": round(whole_flops / (step_us * 1e-6) / 1e12 /
                                              (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32a" else peak), 4) if step_us > 0 else None}}
+
+    if same:
+        prof_us = profiler_average_us(pmc_source, kname)
+        if prof_us:
+            roofline["profiler_avg_launch_us"] = round(prof_us, 2)
+            roofline["frac_by_profiler_avg"] = round(fl[dom] / (prof_us * 1e-6) / 1e12 / peak, 4)
 
     # HBM-side rooflines of the non-contraction kernels: COMPULSORY bytes per launch - every row the launch
     # needs read once, every row it produces written once - over the launch's average duration, against the HBM peak.  They
