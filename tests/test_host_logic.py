@@ -334,3 +334,29 @@ def test_packed_graph_pool_round_trip(tmp_path):
     a = cached_graph_pool(20, 12, 0, cache_dir=str(tmp_path))
     b = cached_graph_pool(20, 12, 0, cache_dir=str(tmp_path))          # second call reads the .npz
     assert len(a) == len(b) == 12 and all(np.array_equal(x.one_hop, y.one_hop) for x, y in zip(a, b))
+
+
+def test_captured_update_refuses_what_it_cannot_capture():
+    """DQNLearner.capture() (HIP-graph replay of the update) needs a GPU replay and an optimizer with a capturable mode; the
+    flat-gradient reducer exposes the three phases a captured update replays / issues separately."""
+    import torch
+    from melissa_amd import parallel
+    from melissa_amd.networks import LDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from melissa_amd.replay import DQNLearner, RoundReplay
+    net = LDGNNetwork(5, 128, 2, 4, 12, dueling_param=({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]}), device="cpu",
+                      backend="torch")
+    policy = DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-3))
+    learner = DQNLearner(policy, RoundReplay(4, 12, 8, "cpu"))
+    with pytest.raises(ValueError, match="ROCm / CUDA device"):
+        learner.capture()
+    assert learner.captured is None
+    red = parallel.FlatGradAllReducer(net)
+    assert not red.active()                                        # no process group: __call__ is a no-op
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 2.0)
+    red.pack()
+    assert float(red.flat.min()) == 2.0 == float(red.flat.max())
+    red.flat.mul_(0.5)
+    red.unpack()
+    assert all(float(p.grad.min()) == 1.0 == float(p.grad.max()) for p in net.parameters())
