@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <unistd.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -31,8 +32,32 @@ __device__ __forceinline__ void fill_lds(u32x4* lds) {
     __syncthreads();
 }
 
-template <int SHAPE>
-__global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
+// SK (32x32x16 loop only): 0 inner loop; 1 + one barrier per step; 2 + the step's LDS fill (two f32x4 split into bf16 pieces:
+// 6 ds_write_b64, and 3 ds_write_b128) into the other stage; 3 + the step's 5 global loads (A streamed from a 256 MB
+// buffer, W re-read from a small one), consumed by the fill two steps later
+__device__ __forceinline__ uint32_t pk(float lo, float hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
+}
+__device__ __forceinline__ void split4(const f32x4 x, uint2& hi, uint2& mid, uint2& lo) {
+    uint32_t h[2], m[2], l[2];
+    float r[4];
+    for (int p = 0; p < 2; ++p) {
+        h[p] = pk(x[2 * p], x[2 * p + 1]);
+        r[2 * p] = x[2 * p] - __builtin_bit_cast(float, h[p] << 16), r[2 * p + 1] = x[2 * p + 1] - __builtin_bit_cast(float, h[p] & 0xffff0000u);
+        m[p] = pk(r[2 * p], r[2 * p + 1]);
+        r[2 * p] -= __builtin_bit_cast(float, m[p] << 16), r[2 * p + 1] -= __builtin_bit_cast(float, m[p] & 0xffff0000u);
+        l[p] = pk(r[2 * p], r[2 * p + 1]);
+    }
+    hi = uint2{h[0], h[1]}, mid = uint2{m[0], m[1]}, lo = uint2{l[0], l[1]};
+}
+
+template <int SHAPE, int SK = 0>
+__global__ __launch_bounds__(256, 2) void probe(float* out, int iters, const float* __restrict__ gA = nullptr,
+                                                const u32x4* __restrict__ gW = nullptr, int lda = 1024, int ksteps = 64,
+                                                int panels = 512) {
     __shared__ u32x4 lds[2 * BUF];           // 57 344 bytes: two workgroups per CU, like the kernel
     fill_lds(lds);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wm = w >> 1, wn = w & 1;
@@ -42,8 +67,24 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
         const int a_off = (wm * 64 + r) * ROW + h, w_off = (128 + wn * 64 + r) * ROW + h;
         f32x16 acc[2][2];
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        // staging coordinates of the real kernel: A 4 threads per row slice (64 rows per pass, 2 passes), W 3 chunks per thread
+        const int crow = threadIdx.x >> 2, kq = threadIdx.x & 3;
+        uint2* lds8 = reinterpret_cast<uint2*>(lds);
+        const int a_st = crow * (2 * ROW) + kq;
+        int w_st[3];
+        for (int i = 0; i < 3; ++i) { const int ch = threadIdx.x + i * 256, wr = ch / 6; w_st[i] = (128 + wr) * ROW + (ch - wr * 6); }
+        f32x4 ra[2][2] = {{{.3f, -.2f, .11f, .7f}, {.5f, .21f, -.4f, .9f}}, {{.13f, .2f, -.31f, .17f}, {-.5f, .6f, .44f, .19f}}};
+        u32x4 rw[2][3];
+        for (int s2 = 0; s2 < 2; ++s2) for (int i = 0; i < 3; ++i) rw[s2][i] = lds[(threadIdx.x + i * 256) % BUF];
+        const float* pa[2] = {nullptr, nullptr};
+        const u32x4* pw[3] = {nullptr, nullptr, nullptr};
+        if constexpr (SK >= 3) {
+            for (int i = 0; i < 2; ++i) pa[i] = gA + ((size_t)(blockIdx.x % panels) * 128 + crow + i * 64) * lda + kq * 4;
+            for (int i = 0; i < 3; ++i) { const int ch = threadIdx.x + i * 256, wr = ch / 6; pw[i] = gW + (size_t)wr * 384 + (ch - wr * 6); }
+        }
         for (int it = 0; it < iters; ++it) {
-            const u32x4* cst = lds + (it & 1) * BUF;
+            const int stage = it & 1, set = it & 1;
+            const u32x4* cst = lds + stage * BUF;
             bf16x8 a[2][3], b[2][3];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -54,12 +95,31 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
                 }
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 6; ++k) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[k]], b[j][PB[k]], acc[i][j], 0, 0, 0);
+                if constexpr (SK >= 2) {                   // the fill and the loads dealt out between the MFMA groups, as in the kernel
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k < 2) {
+                        uint2 hi, mid, lo;
+                        split4(ra[set][k], hi, mid, lo);
+                        uint2* dst = lds8 + (stage ^ 1) * (2 * BUF) + a_st + k * 64 * (2 * ROW);
+                        dst[0] = hi, dst[4] = mid, dst[8] = lo;
+                    }
+                    if (k == 2)
+                        for (int i = 0; i < 3; ++i) lds[(stage ^ 1) * BUF + w_st[i]] = rw[set][i];
+                    if constexpr (SK >= 3) {
+                        const int kk = it % ksteps;          // steps of 16 k per row panel
+                        if (k == 3) for (int i = 0; i < 2; ++i) ra[set][i] = *reinterpret_cast<const f32x4*>(pa[i] + kk * 16);
+                        if (k == 4) for (int i = 0; i < 3; ++i) rw[set][i] = pw[i][kk * 6];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (SK >= 1) __syncthreads();
         }
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
     } else {
@@ -95,6 +155,88 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
     if (sum == 12345.678f) out[0] = sum;     // keep the chain alive
 }
 
+// SK 4: the same step with SPECIALISED wavefronts - a 512-thread workgroup whose waves 0-3 only read fragments and multiply
+// while waves 4-7 only load, split and fill (one barrier per step hands a stage over): a load that waits at the CU's address
+// path then blocks a loader's instruction stream, not a stream with MFMAs in it.  Two workgroups per CU (16 waves, <= 128 VGPRs).
+__global__ __launch_bounds__(512, 2) void probe_roles(float* out, int iters, const float* __restrict__ gA, const u32x4* __restrict__ gW,
+                                                      int lda, int ksteps, int panels) {
+    __shared__ u32x4 lds[2 * BUF];
+    for (int i = threadIdx.x; i < 2 * BUF; i += 512) {
+        const uint32_t s = (uint32_t)i * 2654435761u;
+        const uint32_t w0 = 0x3E003E00u ^ (s & 0x807F807Fu), w1 = 0x3D803F00u ^ ((s >> 3) & 0x807F807Fu);
+        lds[i] = u32x4{w0, w1, w1 ^ 0x00100010u, w0 ^ 0x00080008u};
+    }
+    __syncthreads();
+    const int role = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    float sum = 0.f;
+    if (role == 0) {
+        const int r = lane & 31, h = lane >> 5;
+        const int a_off = (wm * 64 + r) * ROW + h, w_off = (128 + wn * 64 + r) * ROW + h;
+        f32x16 acc[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            const u32x4* cst = lds + (it & 1) * BUF;
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[u][p] = __builtin_bit_cast(bf16x8, cst[a_off + u * 32 * ROW + 2 * p]);
+                    b[u][p] = __builtin_bit_cast(bf16x8, cst[w_off + u * 32 * ROW + 2 * p]);
+                }
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[k]], b[j][PB[k]], acc[i][j], 0, 0, 0);
+            __syncthreads();
+        }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+    } else {
+        const int crow = tid >> 2, kq = tid & 3;
+        uint2* lds8 = reinterpret_cast<uint2*>(lds);
+        const int a_st = crow * (2 * ROW) + kq;
+        int w_st[3];
+        const float* pa[2];
+        const u32x4* pw[3];
+        for (int i = 0; i < 3; ++i) {
+            const int ch = tid + i * 256, wr = ch / 6;
+            w_st[i] = (128 + wr) * ROW + (ch - wr * 6);
+            pw[i] = gW + (size_t)wr * 384 + (ch - wr * 6);
+        }
+        for (int i = 0; i < 2; ++i) pa[i] = gA + ((size_t)(blockIdx.x % panels) * 128 + crow + i * 64) * lda + kq * 4;
+        f32x4 ra[2][2] = {{{.3f, -.2f, .11f, .7f}, {.5f, .21f, -.4f, .9f}}, {{.13f, .2f, -.31f, .17f}, {-.5f, .6f, .44f, .19f}}};
+        u32x4 rw[2][3];
+        for (int s2 = 0; s2 < 2; ++s2) for (int i = 0; i < 3; ++i) rw[s2][i] = lds[(tid + i * 256) % BUF];
+        auto half = [&](f32x4 (&a2)[2], u32x4 (&w3)[3], int stage, int kk) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                uint2 hi, mid, lo;
+                split4(a2[k], hi, mid, lo);
+                uint2* dst = lds8 + (stage ^ 1) * (2 * BUF) + a_st + k * 64 * (2 * ROW);
+                dst[0] = hi, dst[4] = mid, dst[8] = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) lds[(stage ^ 1) * BUF + w_st[i]] = w3[i];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a2[i] = *reinterpret_cast<const f32x4*>(pa[i] + kk * 16);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w3[i] = pw[i][kk * 6];
+            __syncthreads();
+        };
+        for (int it = 0; it < iters; it += 2) {            // two explicit register sets (no dynamic indexing: that went to scratch)
+            half(ra[0], rw[0], 0, it % ksteps);
+            half(ra[1], rw[1], 1, (it + 1) % ksteps);
+        }
+        sum = ra[0][0][0] + ra[1][1][1] + __builtin_bit_cast(float, rw[0][0][0]) + __builtin_bit_cast(float, rw[1][2][1]);
+    }
+    if (sum == 12345.678f) out[0] = sum;
+}
+
 static void smi(const char* tag) {
     FILE* p = popen("rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'sclk|Package Power'", "r");
     if (!p) return;
@@ -103,17 +245,21 @@ static void smi(const char* tag) {
     pclose(p);
 }
 
-template <int SHAPE>
-static void run(const char* name, float* out) {
+static float* g_a = nullptr;
+static u32x4* g_w = nullptr;
+template <int SHAPE, int SK = 0>
+static void run(const char* name, float* out, int lda = 1024, int ksteps = 64, int panels = 512) {
     const int grid = 512, warm = 2000;
-    hipLaunchKernelGGL(probe<SHAPE>, dim3(grid), dim3(256), 0, 0, out, warm);
+    hipLaunchKernelGGL((probe<SHAPE, SK>), dim3(grid), dim3(256), 0, 0, out, warm, g_a, g_w, lda, ksteps, panels);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    const int iters = 400000;                // ~1.5 - 2.5 s
+    const int iters = SK >= 3 ? 600000 : 1500000;       // ~1 - 1.5 s
     hipEventRecord(e0);
-    hipLaunchKernelGGL(probe<SHAPE>, dim3(grid), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL((probe<SHAPE, SK>), dim3(grid), dim3(256), 0, 0, out, iters, g_a, g_w, lda, ksteps, panels);
     hipEventRecord(e1);
+    hipStreamQuery(0);
+    usleep(500000);                          // let the clock settle before sampling
     smi(name);                               // sampled while the kernel runs (the launch is asynchronous)
     hipEventSynchronize(e1);
     float ms = 0;
@@ -123,12 +269,45 @@ static void run(const char* name, float* out) {
            flop / (ms * 1e-3) / 1e12, flop / 6 / (ms * 1e-3) / 1e12);
 }
 
+static void run_roles(const char* name, float* out, int lda, int ksteps, int panels) {
+    const int grid = 512;
+    hipLaunchKernelGGL(probe_roles, dim3(grid), dim3(512), 0, 0, out, 2000, g_a, g_w, lda, ksteps, panels);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    const int iters = 1200000;
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(probe_roles, dim3(grid), dim3(512), 0, 0, out, iters, g_a, g_w, lda, ksteps, panels);
+    hipEventRecord(e1);
+    hipStreamQuery(0);
+    usleep(500000);
+    smi(name);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 2.0 * 64 * 64 * 16 * 6 * 4.0 * grid * (double)iters;
+    printf("%s: %.1f ms, %.0f TFLOP/s issued on the bf16 pipe = %.0f TF of fp32-accurate FLOPs (six products per term)\n", name, ms,
+           flop / (ms * 1e-3) / 1e12, flop / 6 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
     float* out;
     hipMalloc(&out, 64);
+    hipMalloc(&g_a, (size_t)512 * 128 * 1024 * 4);          // 512 row panels of 128 x 1024 floats = 256 MB
+    hipMemset(g_a, 0x3c, (size_t)512 * 128 * 1024 * 4);
+    hipMalloc(&g_w, (size_t)128 * 384 * 16);                // 128 W rows x 64 steps x 96 bytes
+    hipMemset(g_w, 0x3d, (size_t)128 * 384 * 16);
     smi("idle");
-    run<0>("32x32x16, 6 products, 12 fragment reads", out);
-    run<1>("16x16x32, 3 dual products, 20 fragment reads", out);
-    run<0>("32x32x16 again", out);
+    run<0, 0>("32x32x16, 6 products, 12 fragment reads", out);
+    run<1, 0>("16x16x32, 3 dual products, 20 fragment reads", out);
+    run<0, 1>("32x32x16 + a barrier per step", out);
+    run<0, 2>("32x32x16 + barrier + split and LDS fill", out);
+    run<0, 3>("32x32x16 + barrier + fill + the 5 global loads of a step (A rows 4 KB apart, 512 panels = 256 MB)", out);
+    run<0, 3>("same, A rows 2 KB apart as in conv2 (512 panels = 128 MB)", out, 512, 32, 512);
+    run<0, 3>("same, A rows 2 112 bytes apart", out, 528, 32, 512);
+    run<0, 3>("same, 2 KB rows, 128 panels shared by four workgroups each (conv2's four column tiles; 32 MB)", out, 512, 32, 128);
+    run<0, 3>("same, 16 panels (4 MB: cache resident)", out, 512, 32, 16);
+    run_roles("specialised wavefronts (4 MFMA waves + 4 loader waves per workgroup, two workgroups per CU), 128 shared panels", out, 512, 32, 128);
+    run_roles("specialised wavefronts, 512 panels (128 MB streamed)", out, 512, 32, 512);
     return 0;
 }
