@@ -8,8 +8,12 @@
 // the step 69 us against 52.6.  Known differences from the probe that have not been taken apart yet: the 128-VGPR cap of
 // four waves per SIMD (124 bytes of scratch, all in the per-tile code: epilogue and tile set-up), the epilogue running in
 // the MFMA waves while the loaders sit at the step barrier, the tile-crossing set-up inside the loaders' stream.  First
-// things to try: launch_bounds(512, 2) with one workgroup per CU (174 VGPRs, no scratch), the epilogue handed to the loader
-// waves through LDS (as gemm_ring.hpp does), cycle stamps per role (tools/split_prof.py's scheme).
+// things to try: the epilogue handed to the loader waves through LDS (as gemm_ring.hpp does), cycle stamps per role
+// (tools/split_prof.py's scheme).  Already tried, on the last GPU minutes of the round: launch_bounds(512, 2) with ONE
+// workgroup per CU (174 VGPRs, no scratch; grid 256): 125 TF at M = 65 536, and the same with the loads FOUR steps ahead
+// of their fill (four register sets, the version below): 134 TF, conv2's lin_l shape 61 us - neither the register cap nor
+// the prefetch distance is what separates this kernel from the probe's 273-287 TF.  (In the probe every workgroup cycles
+// over its own 256 KB panel, which stays in L2 / MALL; here A streams from HBM - worth measuring first.)
 //
 // ---- 128 x 128 tiles, specialised wavefronts -------------------------------------------------------------------------
 // gemm_split_big_kernel with its work dealt to two kinds of wavefront: a 512-thread workgroup whose waves 0-3 (2 x 2, one
@@ -20,7 +24,7 @@
 // MFMAs 303, + barrier 299, + split and fill 260, + the step's five loads 144-164 (189 cache resident) - and 273-287 with
 // the loads in loader waves.  <= 128 VGPRs: two workgroups (16 waves) per CU.
 template <int TAG = 0>
-__global__ __launch_bounds__(512, 4) void gemm_split_roles_kernel(GemmBatch batch) {
+__global__ __launch_bounds__(512, 2) void gemm_split_roles_kernel(GemmBatch batch) {
     constexpr int BM = 128, BN = 128;
     constexpr int BUF = (BM + BN) * GEMS2_ROW;        // 16-byte chunks per LDS stage
     __shared__ u32x4 lds[2 * BUF];
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(512, 4) void gemm_split_roles_kernel(GemmBatch batc
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
-        if (nsteps & 1) __syncthreads();      // the loaders' padding step
+        for (int pad = (4 - (nsteps & 3)) & 3; pad > 0; --pad) __syncthreads();      // the loaders' padding steps
         return;
     }
 
@@ -224,22 +228,27 @@ __global__ __launch_bounds__(512, 4) void gemm_split_roles_kernel(GemmBatch batc
 #pragma unroll
         for (int i = 0; i < 3; ++i) lds[stage * BUF + w_st[i]] = R.w[i];
     };
-    Regs R0, R1;
+    // FOUR register sets: a step of this kernel is short, so the loads run four steps ahead of their fill
+    Regs R0, R1, R2, R3;
     issue(R0);                                 // step 0
     issue(R1);                                 // step 1
+    issue(R2);                                 // step 2
+    issue(R3);                                 // step 3
     fill_stage(0, R0);
     __syncthreads();                           // stage 0 is ready
-    issue(R0);                                 // step 2
+    issue(R0);                                 // step 4
     int stage = 0;
-    // during step s (the MFMA waves are on `stage`): Ra (step s+1) -> the other stage, then Ra <- loads of step s+3
+    // during step s (the MFMA waves are on `stage`): Ra (step s+1) -> the other stage, then Ra <- loads of step s+5
     auto step = [&](Regs& Ra) {
         fill_stage(stage ^ 1, Ra);
         issue(Ra);
         __syncthreads();
         stage ^= 1;
     };
-    for (int it = 0; it < (nsteps + 1) >> 1; ++it) {       // counted loop over pairs of steps (see gemm_split_kernel)
+    for (int it = 0; it < (nsteps + 3) >> 2; ++it) {       // counted loop over quads of steps (see gemm_split_kernel)
         step(R1);
+        step(R2);
+        step(R3);
         step(R0);
     }
 }
