@@ -12,8 +12,12 @@
 // (tools/split_prof.py's scheme).  Already tried, on the last GPU minutes of the round: launch_bounds(512, 2) with ONE
 // workgroup per CU (174 VGPRs, no scratch; grid 256): 125 TF at M = 65 536, and the same with the loads FOUR steps ahead
 // of their fill (four register sets, the version below): 134 TF, conv2's lin_l shape 61 us - neither the register cap nor
-// the prefetch distance is what separates this kernel from the probe's 273-287 TF.  (In the probe every workgroup cycles
-// over its own 256 KB panel, which stays in L2 / MALL; here A streams from HBM - worth measuring first.)
+// the prefetch distance is what separates this kernel from the probe's 255-287 TF.  Nor is HBM streaming: with a NEW A panel
+// per 32 steps out of 2 GB (every A byte from HBM once - harsher than conv2, where four column tiles share a panel) the
+// probe's roles step still runs at 209 TF.  What the probe does not have is the EPILOGUE: ~10 000 cycles per tile in the MFMA
+// waves (tools/split_prof.py on the one-role kernel) against 32 steps x ~850 cycles - 209 / 1.37 = 152 TF, which is what this
+// kernel measures.  So: the epilogue out of the MFMA waves (accumulators dropped into an LDS hand-over buffer and stored by
+// the loader waves, gemm_ring.hpp's scheme) or overlapped with the next tile's first steps (a second accumulator set).
 //
 // ---- 128 x 128 tiles, specialised wavefronts -------------------------------------------------------------------------
 // gemm_split_big_kernel with its work dealt to two kinds of wavefront: a 512-thread workgroup whose waves 0-3 (2 x 2, one

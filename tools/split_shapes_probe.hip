@@ -228,7 +228,12 @@ __global__ __launch_bounds__(512, 2) void probe_roles(float* out, int iters, con
             for (int i = 0; i < 3; ++i) w3[i] = pw[i][kk * 6];
             __syncthreads();
         };
+        const size_t panel_floats = (size_t)128 * lda;
         for (int it = 0; it < iters; it += 2) {            // two explicit register sets (no dynamic indexing: that went to scratch)
+            if (panels > 4096 && it % ksteps == 0) {       // streaming mode: a new panel per tile, like the kernel's row panels
+                const size_t pnl = ((size_t)blockIdx.x + (size_t)(it / ksteps) * gridDim.x) % panels;
+                for (int i = 0; i < 2; ++i) pa[i] = gA + pnl * panel_floats + (size_t)(crow + i * 64) * lda + kq * 4;
+            }
             half(ra[0], rw[0], 0, it % ksteps);
             half(ra[1], rw[1], 1, (it + 1) % ksteps);
         }
@@ -254,12 +259,12 @@ static void run(const char* name, float* out, int lda = 1024, int ksteps = 64, i
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    const int iters = SK >= 3 ? 600000 : 1500000;       // ~1 - 1.5 s
+    const int iters = SK >= 3 ? 300000 : 600000;        // ~0.5 s
     hipEventRecord(e0);
     hipLaunchKernelGGL((probe<SHAPE, SK>), dim3(grid), dim3(256), 0, 0, out, iters, g_a, g_w, lda, ksteps, panels);
     hipEventRecord(e1);
     hipStreamQuery(0);
-    usleep(500000);                          // let the clock settle before sampling
+    usleep(250000);                          // let the clock settle before sampling
     smi(name);                               // sampled while the kernel runs (the launch is asynchronous)
     hipEventSynchronize(e1);
     float ms = 0;
@@ -275,12 +280,12 @@ static void run_roles(const char* name, float* out, int lda, int ksteps, int pan
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    const int iters = 1200000;
+    const int iters = 600000;
     hipEventRecord(e0);
     hipLaunchKernelGGL(probe_roles, dim3(grid), dim3(512), 0, 0, out, iters, g_a, g_w, lda, ksteps, panels);
     hipEventRecord(e1);
     hipStreamQuery(0);
-    usleep(500000);
+    usleep(250000);
     smi(name);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -293,8 +298,8 @@ static void run_roles(const char* name, float* out, int lda, int ksteps, int pan
 int main() {
     float* out;
     hipMalloc(&out, 64);
-    hipMalloc(&g_a, (size_t)512 * 128 * 1024 * 4);          // 512 row panels of 128 x 1024 floats = 256 MB
-    hipMemset(g_a, 0x3c, (size_t)512 * 128 * 1024 * 4);
+    hipMalloc(&g_a, (size_t)8192 * 128 * 512 * 4);          // 8 192 row panels of 128 x 512 floats = 2 GB (>= 512 panels of 128 x 1024)
+    hipMemset(g_a, 0x3c, (size_t)8192 * 128 * 512 * 4);
     hipMalloc(&g_w, (size_t)128 * 384 * 16);                // 128 W rows x 64 steps x 96 bytes
     hipMemset(g_w, 0x3d, (size_t)128 * 384 * 16);
     smi("idle");
@@ -309,5 +314,6 @@ int main() {
     run<0, 3>("same, 16 panels (4 MB: cache resident)", out, 512, 32, 16);
     run_roles("specialised wavefronts (4 MFMA waves + 4 loader waves per workgroup, two workgroups per CU), 128 shared panels", out, 512, 32, 128);
     run_roles("specialised wavefronts, 512 panels (128 MB streamed)", out, 512, 32, 512);
+    run_roles("specialised wavefronts, a NEW panel per 32 steps out of 8 192 (2 GB: every A byte from HBM once)", out, 512, 32, 8192);
     return 0;
 }
