@@ -337,3 +337,24 @@ def dqn_act(logits, mask=None):
         m = torch.as_tensor(mask, dtype=q.dtype)
         q = q + (1 - m) * (q.min() - q.max() - 1.0)
     return q.argmax(dim=1)
+
+
+def dqn_exploration_noise(act, eps, rand_u, rand_q, mask=None):
+    """[3P] tianshou 1.0.0 ``DQNPolicy.exploration_noise``, reached through
+    ``MultiAgentSharedPolicy.exploration_noise`` (policies/multi_agent_managers/shared_policy.py:81-91):
+
+        rand_mask = np.random.rand(bs) < eps;  q = np.random.rand(bs, n_act) (+ mask)
+        act[rand_mask] = q.argmax(1)[rand_mask]
+
+    The two uniform draws are arguments (``rand_u`` [bs], ``rand_q`` [bs, n_act]) so that a caller can feed the
+    stream the product used; eps == 0 leaves ``act`` alone, as the reference's ``np.isclose(eps, 0)`` guard does."""
+    act = np.array(act, dtype=np.int64, copy=True)
+    if np.isclose(eps, 0.0):
+        return act
+    rand_mask = np.asarray(rand_u) < eps
+    q = np.array(rand_q, dtype=np.float64, copy=True)
+    if mask is not None:
+        q += np.asarray(mask, dtype=np.float64)
+    rand_act = q.argmax(axis=1)
+    act[rand_mask] = rand_act[rand_mask]
+    return act

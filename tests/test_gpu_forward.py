@@ -14,6 +14,13 @@ TOL = 1e-4
 DUEL = lambda: ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})
 
 
+def golden_named(tag):
+    """The committed golden ``net_golden_<tag>.npz`` - by NAME (a position in the sorted list changes whenever a golden is added)."""
+    hits = [p for p in GOLDENS if os.path.basename(p) == f"net_golden_{tag}.npz"]
+    assert len(hits) == 1, f"golden {tag} missing from tests/golden ({[os.path.basename(p) for p in GOLDENS]})"
+    return hits[0]
+
+
 def make_net(model, n, seed, agg="max", dueling=True):
     from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
     from oracle import net_oracle as no
@@ -219,10 +226,9 @@ def test_non_dueling_head_and_select_action():
     from melissa_amd.networks import HLDGNNetwork
     from oracle import net_oracle as no
     n = 20
-    g = np.load(GOLDENS[1] if "n20" in GOLDENS[1] else GOLDENS[0])
-    obs = g["obs"] if int(g["n"]) == n else None
-    if obs is None:
-        pytest.skip("n20 golden missing")
+    g = np.load(golden_named("n20"))
+    obs = g["obs"]
+    assert int(g["n"]) == n
     sd = no.init_weights("hl_dgn", seed=0, random_conv_bias=True, dueling=False)
     net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=None, device="cuda", backend="hip")
     net.load_state_dict(sd)
@@ -248,6 +254,130 @@ def test_non_dueling_head_and_select_action():
     base = got.argmax(1)
     expect = torch.where(ru < 0.5, rq.argmax(1), base)
     assert act.cpu().tolist() == expect.cpu().tolist()
+
+
+def _distinct_uniforms(rng, bs, na):
+    """fp32 uniforms on a 2^-16 grid, distinct inside a row, so that ``q + mask`` is exact in fp32 and in the oracle's float64
+    alike and no row has a tie (the reference draws float64; a tie there has probability ~0)."""
+    base = rng.randint(0, 1 << 16, size=(bs, na)).astype(np.float64) / (1 << 16)
+    return (base + np.arange(na)[None, :] / float(1 << 20)).astype(np.float32)
+
+
+@pytest.mark.parametrize("bs,na", [(1, 2), (257, 2), (1000, 4), (4097, 8)])
+def test_select_action_mask_and_eps_match_oracle(bs, na):
+    """N10: [3P] tianshou DQNPolicy.forward (mask illegal actions with the batch-wide min - max - 1, argmax) and
+    exploration_noise (eps-greedy over ``rand + mask``), reached through shared_policy.py:154 and :81-91 - mel_select_action
+    against oracle.dqn_act + oracle.dqn_exploration_noise on the same logits, masks and uniform draws.  Masks: random per
+    action, rows with a single legal action, rows with NO legal action (the env's dead-agent mask [0, 0], graph.py:190-192)."""
+    import ctypes as C
+    from melissa_amd import _lib
+    from oracle import net_oracle as no
+    lib = _lib.load()
+    rng = np.random.RandomState(1000 + bs + na)
+    logits_np = rng.standard_normal((bs, na)).astype(np.float32)
+    logits_np[rng.uniform(size=bs) < 0.1] = 0.25            # ties: argmax takes the first maximum
+    mask_np = (rng.uniform(size=(bs, na)) < 0.6).astype(np.uint8)
+    mask_np[::5] = 0                                       # no legal action
+    mask_np[1::5] = 0
+    mask_np[1::5, (np.arange(len(mask_np[1::5])) % na)] = 0
+    one = np.arange(bs)[1::5]
+    mask_np[one, one % na] = 1                             # exactly one legal action
+    mask_np[2::5] = 1                                      # all legal
+    logits = torch.from_numpy(logits_np).cuda()
+    mask = torch.from_numpy(mask_np).cuda()
+    act = torch.empty(bs, dtype=torch.int32, device="cuda")
+    scratch = torch.empty(64, dtype=torch.float32, device="cuda")
+    ru_np = rng.uniform(size=bs).astype(np.float32)
+    rq_np = _distinct_uniforms(rng, bs, na)
+    ru, rq = torch.from_numpy(ru_np).cuda(), torch.from_numpy(rq_np).cuda()
+    for use_mask in (True, False):
+        m_dev = mask.data_ptr() if use_mask else None
+        m_np = mask_np if use_mask else None
+        greedy = no.dqn_act(torch.from_numpy(logits_np), m_np).numpy()
+        _lib.check(lib.mel_select_action(logits.data_ptr(), m_dev, bs, na, C.c_float(0.0), None, None, act.data_ptr(),
+                                         scratch.data_ptr(), _lib.current_stream_ptr()))
+        np.testing.assert_array_equal(act.cpu().numpy(), greedy)
+        if use_mask:                                       # an illegal action is never taken where a legal one exists
+            legal_rows = mask_np.any(axis=1)
+            assert (mask_np[np.arange(bs), greedy][legal_rows] == 1).all()
+        for eps in (0.3, 1.0):
+            want = no.dqn_exploration_noise(greedy, eps, ru_np, rq_np, m_np)
+            _lib.check(lib.mel_select_action(logits.data_ptr(), m_dev, bs, na, C.c_float(eps), ru.data_ptr(), rq.data_ptr(),
+                                             act.data_ptr(), scratch.data_ptr(), _lib.current_stream_ptr()))
+            np.testing.assert_array_equal(act.cpu().numpy(), want)
+            if bs > 100:
+                assert (want != greedy).any()              # the noise really replaced actions
+
+
+def _mix32(x):
+    """The library's documented exploration stream (include/melissa_hip.h, mel_select_action_rows): lowbias32."""
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & 0xFFFFFFFF
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & 0xFFFFFFFF
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def exploration_stream(seed, step, keys, na):
+    """(rand_u [rows], rand_q [rows, na]) of the counter-based stream for the given row keys."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    base = _mix32(np.uint64(seed) ^ _mix32((np.uint64(step) * np.uint64(0x9E3779B9) + keys) & 0xFFFFFFFF))
+    u01 = lambda h: (h >> np.uint64(8)).astype(np.float64) / 16777216.0
+    rq = np.stack([u01(_mix32((base + np.uint64(0x85EBCA6B) * np.uint64(a + 1)) & 0xFFFFFFFF)) for a in range(na)], axis=1)
+    return u01(base), rq
+
+
+@pytest.mark.parametrize("model", ["l_dgn", "dgn_r"])
+def test_fused_selection_follows_the_oracle_rule_on_the_documented_stream(model):
+    """The argmax / eps-greedy fused into the launch that produces the logits (head_finish_kernel, mel_select of
+    mel_ldgn_forward_agents) and the separate mel_select_action_rows: both must equal oracle.dqn_act +
+    oracle.dqn_exploration_noise fed with the library's documented counter-based stream (restated above)."""
+    import ctypes as C
+    from melissa_amd import _lib
+    from melissa_amd.env.episodes import add_agent, agent_masks
+    from oracle import net_oracle as no
+    n, bs = 20, 200
+    g = np.load(golden_named("n20"))
+    rng = np.random.RandomState(77)
+    mat = np.repeat(g["obs"][:, :-1], -(-bs // g["obs"].shape[0]), axis=0)[:bs].copy()
+    mat.reshape(bs, n, 8)[:, :, 0:2] += rng.uniform(-0.05, 0.05, size=(bs, n, 2)).astype(np.float32)
+    member = rng.uniform(size=(bs, n)) < 0.25
+    member[::9] = False
+    masks = agent_masks(bs, n)
+    for b, a in zip(*np.nonzero(member)):
+        add_agent(masks, int(b), int(a))
+    rows = int(member.sum())
+    net, sd = make_net(model, n, seed=3)
+    obs = torch.from_numpy(mat).cuda()
+    am = torch.from_numpy(masks.view(np.int64)).cuda()
+    rounds = torch.tensor([41], dtype=torch.int32, device="cuda")
+    lib = _lib.load()
+    envs, agents = np.nonzero(member)
+    for eps in (0.0, 0.35, 1.0):
+        act = torch.full((bs * n,), -7, dtype=torch.int32, device="cuda")
+        sel = _lib.MelSelect()
+        sel.act, sel.eps, sel.seed, sel.step_dev = act.data_ptr(), eps, 991, rounds.data_ptr()
+        with torch.no_grad():
+            logits, offsets = net.hip_forward_agents(obs, am, bs * n, select=sel)
+        torch.cuda.synchronize()
+        assert int(offsets[-1]) == rows
+        got_logits = logits[:rows].cpu().numpy()
+        fwd = no.ldgn_forward if model == "l_dgn" else no.dgnr_forward
+        want_logits = fwd(sd, np.concatenate([mat[envs], agents[:, None].astype(np.float32)], axis=1), n).numpy()
+        np.testing.assert_allclose(got_logits, want_logits, atol=TOL, rtol=0)
+        greedy = no.dqn_act(torch.from_numpy(got_logits)).numpy()
+        ru, rq = exploration_stream(991, 41, np.arange(rows), 2)
+        want = no.dqn_exploration_noise(greedy, eps, ru, rq)
+        np.testing.assert_array_equal(act[:rows].cpu().numpy(), want)
+        assert (act[rows:] == -7).all()
+        sep = torch.full((rows,), -7, dtype=torch.int32, device="cuda")
+        _lib.check(lib.mel_select_action_rows(logits.data_ptr(), None, rows, None, 2, C.c_float(eps), 991, 0, rounds.data_ptr(),
+                                              sep.data_ptr(), _lib.current_stream_ptr()))
+        np.testing.assert_array_equal(sep.cpu().numpy(), want)
+        if eps == 0.35:
+            assert 0.15 < (ru < eps).mean() < 0.55 and (want != greedy).any()
 
 
 @pytest.mark.parametrize("model", ["l_dgn", "hl_dgn", "dgn_r"])

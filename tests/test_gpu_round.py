@@ -118,17 +118,17 @@ def test_round_loop_matches_oracle(n, dynamic, supply):
     round_loop_vs_oracle(n, dynamic, supply)
 
 
-def test_round_forward_at_the_split_kernels_batch_matches_oracle():
-    """768 envs of 50 nodes: from a few thousand agent rows per round on, the default precision (MEL_PREC_F32_AUTO) sends conv2's
-    projections and the heads' first layer to the 128 x 128 split-bf16 kernels - the launches the benchmark's step spends most
-    of its time in.  Every logit of those rounds against the oracle (<= 1e-4), every chosen action against the oracle's argmax
-    wherever its margin exceeds the tolerance.  (The env half does not depend on the batch size: the per-env comparisons of
-    test_round_loop_matches_oracle cover it.)"""
+def test_round_forward_at_the_benchmark_batch_matches_oracle():
+    """1024 envs of 50 nodes - the benchmark's own batch (BASELINE.json configs[2], bench.py's default): from a few thousand agent
+    rows per round on, the default precision (MEL_PREC_F32_AUTO) sends conv2's projections and the heads' first layer to the
+    128 x 128 split-bf16 kernels - the launches the benchmark's step spends most of its time in.  Every logit of those rounds
+    against the oracle (<= 1e-4), every chosen action against the oracle's argmax wherever its margin exceeds the tolerance.
+    (The env half does not depend on the batch size: the per-env comparisons of test_round_loop_matches_oracle cover it.)"""
     from melissa_amd.collect import RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
     from melissa_amd.policy import DQNPolicy
     from oracle import net_oracle as no
-    n, B = 50, 768
+    n, B = 50, 1024
     venv = HipGraphVectorEnv(B, n, graph_pool=synthetic_graph_pool(n, 16, first_seed=50), dynamic_graph=True, device="cuda",
                              max_moves=48, seed=123, construct_like_reference=False)
     net, sd = make_ldgn(n)
@@ -327,6 +327,46 @@ def test_replay_sampling_and_dqn_learner():
     after = torch.cat([p.detach().flatten() for p in net.parameters()])
     assert all(np.isfinite(l) for l in losses) and not torch.equal(before, after)
     assert any(k.startswith("model_old.") for k in policy.state_dict())
+
+
+def test_hldgn_round_forward_at_the_per_gpu_share_matches_oracle():
+    """HL-DGN, 50 nodes, 512 envs - one GPU's share of BASELINE.json configs[3] (4096 envs over 8 GPUs): every env's logits of
+    several rounds of the device-resident loop against the oracle (<= 1e-4), every live agent's action against the oracle's
+    argmax of its env's row wherever the margin exceeds the tolerance."""
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import HLDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from oracle import net_oracle as no
+    n, B = 50, 512
+    venv = HipGraphVectorEnv(B, n, graph_pool=synthetic_graph_pool(n, 16, first_seed=50), dynamic_graph=True, device="cuda",
+                             max_moves=48, seed=321, construct_like_reference=False)
+    sd = no.init_weights("hl_dgn", seed=9, random_conv_bias=True)
+    net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda", backend="hip")
+    net.load_state_dict(sd)
+    loop = RoundLoop(venv, DQNPolicy(net), eps=0.0, seed=5)
+    torch.set_num_threads(16)
+    checked = 0
+    for it in range(9):
+        live = loop.live.cpu().numpy().view(np.uint64).reshape(B, -1)[:, 0].copy()
+        mat = venv.obs_matrix().cpu().numpy().copy()
+        loop.step()
+        torch.cuda.synchronize()
+        if it % 3 != 2:
+            continue
+        checked += 1
+        want = no.hldgn_forward(sd, np.concatenate([mat, np.zeros((B, 1), np.float32)], axis=1), n, aggregator="max").numpy()
+        got = loop.logits.cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=TOL, rtol=0)
+        act = loop.act.cpu().numpy().reshape(B, n)
+        srt = np.sort(want, axis=1)
+        clear = srt[:, -1] - srt[:, -2] > 2 * TOL
+        member = ((live[:, None] >> np.arange(n, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+        best = np.broadcast_to(want.argmax(axis=1)[:, None], (B, n))
+        sel = member & clear[:, None]
+        np.testing.assert_array_equal(act[sel], best[sel])
+        print(f"round {it}: {int(member.sum())} live agents, max |logit error| {np.abs(got - want).max():.2e}")
+    assert checked == 3 and loop.counters()["errors"] == 0
 
 
 @pytest.mark.parametrize("n", [20, 50, 100])

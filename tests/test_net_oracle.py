@@ -81,3 +81,20 @@ def test_dqn_act_masking():
     logits = torch.tensor([[0.3, 0.1], [0.0, 0.2], [0.5, 0.4]])
     assert no.dqn_act(logits).tolist() == [0, 1, 0]
     assert no.dqn_act(logits, [[1, 1], [1, 0], [0, 1]]).tolist() == [0, 0, 1]
+
+
+def test_dqn_act_and_exploration_noise_known_answers():
+    """[3P] DQNPolicy.forward masking and exploration_noise on hand-computed cases."""
+    logits = torch.tensor([[1.0, 2.0], [3.0, -1.0], [0.5, 0.5], [-4.0, 7.0]])
+    mask = np.array([[1, 0], [1, 1], [0, 1], [0, 0]])
+    # row 0: the better action is illegal; row 2: tie broken by the mask; row 3: nothing legal -> both shifted alike
+    assert no.dqn_act(logits, mask).tolist() == [0, 0, 1, 1]
+    assert no.dqn_act(logits).tolist() == [1, 0, 0, 1]
+    greedy = np.array([0, 0, 1, 1])
+    ru = np.array([0.1, 0.9, 0.29, 0.31])
+    rq = np.array([[0.2, 0.9], [0.9, 0.1], [0.8, 0.3], [0.6, 0.7]])
+    # eps 0.3: rows 0 and 2 explore; row 0's random favourite (1) is illegal -> 0.2 + 1 beats 0.9 + 0; row 2 -> 0.3 + 1
+    assert no.dqn_exploration_noise(greedy, 0.3, ru, rq, mask).tolist() == [0, 0, 1, 1]
+    assert no.dqn_exploration_noise(greedy, 0.3, ru, rq).tolist() == [1, 0, 0, 1]
+    assert no.dqn_exploration_noise(greedy, 1.0, ru, rq).tolist() == [1, 0, 0, 1]
+    assert no.dqn_exploration_noise(greedy, 0.0, ru, rq).tolist() == greedy.tolist()
