@@ -572,6 +572,8 @@ def main():
 
     import torch
     from melissa_amd import _lib, parallel
+    if not args.rehearse_on_one_gpu:
+        launch.check_rank_device()            # a rank whose LOCAL_RANK names a GPU it cannot see leaves with code 2
     rank, local_rank, world = parallel.init_distributed("gloo" if args.rehearse_on_one_gpu else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s)")

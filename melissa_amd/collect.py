@@ -201,6 +201,9 @@ class RoundLoop:
                 with torch.cuda.graph(self.graph):    # launches land on the capture stream (torch's current one)
                     self._launch()
                 return                                # capture does not execute: the next call replays
+            # a replay runs no Python: whatever changed the weights since the last step (an optimizer step, a checkpoint load)
+            # is picked up here - the converted projection weights the captured launches read are brought up to date first
+            self.policy.model.ensure_prepared(self.venv.device)
             self.graph.replay()
         else:
             self._launch()

@@ -28,6 +28,8 @@ struct AttArgs {
     // ATT_ROWS
     float* out;             // [rows, ldo] relu(out + bias)
     int ldo;
+    const float* out_scale; // optional [rows]: row r of `out` is stored times out_scale[r] (the decision-maker mask of
+                            // l_dgn.py:128 - the x_2 snapshot in xcat is taken before it, l_dgn.py:127)
     float* xcat;            // [R, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
     int ld_cat, hidden;
     const float* h0;        // encoder rows (packed by smask), [*, hidden]
@@ -334,7 +336,15 @@ __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttA
         if constexpr (MODE == ATT_SINGLE) {
             store_row<VPL, BF>(a.xcat, (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
         } else {
-            store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, o);
+            if (a.out_scale) {
+                const float dmv = a.out_scale[r];
+                Vec<VPL> om;
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) om.v[i] = o.v[i] * dmv;
+                store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, om);
+            } else {
+                store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, o);
+            }
             if (d.cat_row >= 0) {
                 const size_t cat = (size_t)d.cat_row * a.ld_cat;
                 // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)

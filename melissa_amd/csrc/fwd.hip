@@ -944,19 +944,20 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = ft.h0;
+        a.out_scale = L.plan.dm1;       // the decision-maker mask (l_dgn.py:128) is applied as h1 is stored; x_2 is taken before it
         a.fid = table ? L.plan.fid : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
     }
-    {   // conv2.lin_l on the U1 rows + conv2.lin_r on the agent rows, one grouped launch; the decision-maker
-        // mask (l_dgn.py:128) rides along as a row scale
+    {   // conv2.lin_l on the U1 rows + conv2.lin_r on the agent rows, one grouped launch (h1 rows are already masked by the
+        // decision-maker flag, l_dgn.py:128: the conv1 attention applied it as it stored them)
         GemmArgs g[2];
         g[0].bf16 = g[1].bf16 = bf, g[0].split = g[1].split = sp;
-        g[0].A = L.h1, g[0].lda = hc, g[0].rscale = L.plan.dm1;
+        g[0].A = L.h1, g[0].lda = hc;
         g[0].W = pw.c2l, g[0].bias = w->conv2.lin_l.bias;
         g[0].Y = L.xl2, g[0].ldy = srcw, g[0].M = U1, g[0].M_dev = n1, g[0].N = srcw, g[0].K = hc;
         if (tconv) g[0].W_hi = pw.c2v, g[0].bias_hi = w->conv2.lin_v.bias, g[0].split_n = hc;
-        g[1].A = L.h1, g[1].lda = hc, g[1].arow = L.plan.arow_g, g[1].rscale = L.plan.dm_g;
+        g[1].A = L.h1, g[1].lda = hc, g[1].arow = L.plan.arow_g;
         g[1].W = pw.c2r, g[1].bias = w->conv2.lin_r.bias;
         if (pw.alt) g[0].Ws = pw.alt->c2l, g[0].Ws_hi = tconv ? pw.alt->c2v : nullptr, g[1].Ws = pw.alt->c2r;
         g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;

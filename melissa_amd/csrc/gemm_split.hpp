@@ -583,6 +583,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_big_kernel(GemmBatch batch)
 #endif
 }
 
+// Round 3 built three more forms of this kernel - specialised wavefronts (4 MFMA waves + one or two teams of loader waves, 3- /
+// 4-stage LDS rings), a 128 x 256 tile, three workgroups per CU - all bit-identical to it and none faster; they are parked with
+// their probes and the reason (the CU's vector-memory path delivers ~17 B / clk while its matrix pipe is saturated: this tile
+// needs 26) in tools/experiments/gemm_split_variants.hpp.
+
 // fp32 [rows, K] weight matrices -> [rows][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k), all matrices of the model in one launch
 struct SplitBatch {
     const float* src[CVT_MAX_SEG];

@@ -3,7 +3,8 @@
 ``bench.py --gpus N`` (and ``python -m melissa_amd.train --gpus N``) must work without an external launcher: the
 parent - which has not touched the GPU (no HIP call, no ``torch.cuda.is_available()``) - starts N fresh children of
 the same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's stdout and
-returns the worst exit code.  Nothing here imports torch: it has to stay cheap and GPU-free.
+returns the worst exit code.  The parent's code path imports neither torch nor any HIP binding (tests/test_launch.py runs it
+with both made un-importable): devices are counted from the KFD topology in sysfs.
 
 The reference has no launcher (it is single-process apart from tianshou's SubprocVectorEnv, l_dgn.py:137-146); this is
 the process model SURVEY.md 8(e) prescribes: env shards are independent, one rank per GPU.
@@ -24,11 +25,81 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def visible_gpus() -> int:
-    """Number of GPUs this process may use, without initialising the HIP runtime (``device_count`` only reads the
-    topology; it honours HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES)."""
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"
+
+
+def _kfd_gpus(nodes_dir: str = KFD_NODES, dev_dir: str = "/dev/dri") -> int:
+    """GPUs of the KFD topology this process can open: nodes with SIMDs (CPU nodes have ``simd_count 0``) whose render node
+    exists and is readable + writable (a container that is given one GPU sees the other nodes in sysfs but not their device
+    files).  Plain file reads: no HIP / ROCr / torch call."""
+    try:
+        names = sorted(os.listdir(nodes_dir), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return 0
+    count = 0
+    for name in names:
+        props = {}
+        try:
+            with open(os.path.join(nodes_dir, name, "properties")) as f:
+                for line in f:
+                    parts = line.split()
+                    if len(parts) == 2:
+                        props[parts[0]] = parts[1]
+        except OSError:
+            continue                                      # a node this process may not read is a node it may not use
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1"))
+        if minor >= 0 and not os.access(os.path.join(dev_dir, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
+        count += 1
+    return count
+
+
+def _apply_visible_list(available: int, value: str | None) -> int:
+    """HIP / ROCr semantics of a ``*_VISIBLE_DEVICES`` list: entries are taken in order up to the first invalid one; an
+    entry is an index into the ``available`` devices or a ``GPU-<uuid>`` (counted as one device)."""
+    if value is None:
+        return available
+    count = 0
+    seen = set()
+    for item in value.split(","):
+        item = item.strip()
+        if not item:
+            break
+        if item.isdigit():
+            if int(item) >= available or int(item) in seen:
+                break
+            seen.add(int(item))
+        elif not item.upper().startswith("GPU-"):
+            break
+        count += 1
+    return min(count, available)
+
+
+def visible_gpus(env: dict | None = None, nodes_dir: str = KFD_NODES, dev_dir: str = "/dev/dri") -> int:
+    """Number of GPUs this process may use, WITHOUT touching a GPU API: the KFD topology in sysfs, filtered by
+    ROCR_VISIBLE_DEVICES (applied by the ROCr runtime) and then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (applied by HIP to
+    what ROCr left).  ``torch.cuda.device_count()`` is GPU-free only while its amdsmi path works and falls back to
+    ``hipGetDeviceCount`` - which initialises the runtime in the launcher parent - otherwise; the ranks re-check with it
+    themselves (``check_rank_device``), where initialising the runtime is what they are about to do anyway."""
+    env = os.environ if env is None else env
+    nodes_dir, dev_dir = env.get("MEL_KFD_NODES", nodes_dir), env.get("MEL_DRI_DIR", dev_dir)      # (tests point these at a fake tree)
+    n = _kfd_gpus(nodes_dir, dev_dir)
+    n = _apply_visible_list(n, env.get("ROCR_VISIBLE_DEVICES"))
+    hip = env.get("HIP_VISIBLE_DEVICES", env.get("CUDA_VISIBLE_DEVICES"))
+    return _apply_visible_list(n, hip)
+
+
+def check_rank_device() -> None:
+    """Called by a RANK (never by the launcher parent) before it binds its device: exit 2 when LOCAL_RANK names a GPU this
+    process cannot see - the sysfs count of the parent is a pre-flight check, this is the authoritative one."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    return int(torch.cuda.device_count())
+    have = int(torch.cuda.device_count())
+    if local >= have:
+        sys.stderr.write(f"rank with LOCAL_RANK={local} but only {have} GPU(s) visible to it\n")
+        raise SystemExit(2)
 
 
 def _pump(stream, sink, prefix="", other=None):

@@ -166,7 +166,8 @@ class HipForwardMixin:
         cached = getattr(self, "_tables", None)
         if cached is None or cached[0] != key or cached[1].device != device:
             need = int(lib.mel_feature_tables_bytes(C.byref(w), self.agents_num))
-            buf = torch.empty(max(need, 16), dtype=torch.uint8, device=device)
+            buf = cached[1] if cached is not None and cached[1].device == device and cached[1].numel() >= max(need, 16) else \
+                torch.empty(max(need, 16), dtype=torch.uint8, device=device)       # same buffer: captured launches hold its address
             w.tables, w.tables_nodes = None, 0
             _lib.check(lib.mel_prepare_feature_tables(C.byref(w), self.agents_num, buf.data_ptr(), buf.numel(),
                                                       _lib.current_stream_ptr(device)), "mel_prepare_feature_tables")
@@ -195,6 +196,39 @@ class HipForwardMixin:
                    "mel_prepare_weights")
         w.prepared = buf.data_ptr()
         self._prepared = ((self._param_key(), version), buf)
+
+    def ensure_prepared(self, device=None) -> None:
+        """Bring the per-weight-version caches (converted projection weights, prepared feature tables) up to date NOW, eagerly
+        on the current stream and INTO THE SAME BUFFERS - for callers whose launches were captured into a HIP graph: a replay
+        runs no Python, so nothing reconverts the planes the captured launches read unless the caller asks before replaying
+        (``RoundLoop`` in graph mode, ``replay.CapturedUpdate`` after a target-network sync).  Cheap when nothing changed."""
+        if self.feature_dtype == "f32" and not self.prepared_tables:
+            return
+        # fast path (a couple of microseconds: this runs before every graph replay): nothing bumped a version counter, nobody
+        # marked the caches stale, same precision
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            plist = self._plist = list(self.parameters())
+        vsum = 0
+        for p in plist:
+            vsum += p._version
+        stamp = (vsum, self.feature_dtype, self.prepared_tables, id(getattr(self, "_prepared", None)), id(getattr(self, "_tables", None)))
+        if getattr(self, "_ensure_stamp", None) == stamp:
+            return
+        device = device if device is not None else plist[0].device
+        w = self._weights()
+        self._refresh_prepared(w, device)
+        self._refresh_tables(w, device)
+        self._ensure_stamp = (vsum, self.feature_dtype, self.prepared_tables, id(getattr(self, "_prepared", None)),
+                              id(getattr(self, "_tables", None)))
+
+    def mark_weights_changed(self) -> None:
+        """The parameters were changed behind torch's version counters (an optimizer step replayed from a HIP graph): the next
+        ``ensure_prepared`` / forward converts them again (same buffers: captured launches hold their addresses)."""
+        if getattr(self, "_prepared", None) is not None:
+            self._prepared = (("stale",), self._prepared[1])
+        if getattr(self, "_tables", None) is not None:
+            self._tables = (("stale",), self._tables[1])
 
     def _weights(self) -> _lib.MelWeights:
         key = self._param_key()

@@ -257,10 +257,15 @@ class CapturedUpdate:
         policy = self.learner.policy
         if policy._target and policy._iter % policy._freq == 0:
             policy.sync_weight()
+            # the target network only ever runs INSIDE graph A, whose launches read its converted projection weights from the
+            # buffer captured with them: reconvert the new weights into that buffer now (no Python runs during a replay)
+            policy.model_old.ensure_prepared(self.learner.replay.obs.device)
 
     def step(self) -> dict:
         policy = self.learner.policy
         self._sync_target()
+        if policy._is_double:                  # graph A also evaluates the ONLINE network through the HIP forward
+            policy.model.ensure_prepared(self.learner.replay.obs.device)
         self.graph_a.replay()
         if self.collective:
             self.learner.grad_hook.reduce()
@@ -269,11 +274,7 @@ class CapturedUpdate:
         # the replay changed the parameters behind torch's version counters: mark the per-weight-version caches stale (the
         # prepared planes keep their buffer - launches captured elsewhere hold its address - and are converted again by the
         # next forward)
-        net = policy.model
-        if getattr(net, "_prepared", None) is not None:
-            net._prepared = (("stale",), net._prepared[1])
-        if getattr(net, "_tables", None) is not None:
-            net._tables = None
+        policy.model.mark_weights_changed()
         return {"loss": self.loss.clone()}                     # (self.loss is the graph's static tensor: the next replay overwrites it)
 
 

@@ -14,17 +14,13 @@ import argparse
 import json
 import time
 
-import torch
-
-from . import parallel
-from .collect import RoundLoop
-from .env import HipGraphVectorEnv, synthetic_graph_pool
-from .networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
-from .policy import DGNPolicy, DQNPolicy
-from .replay import DGNLearner, DQNLearner, RoundReplay
+# torch and the package's GPU-facing modules are imported inside the functions that need them: ``python -m melissa_amd.train
+# --gpus N`` runs this module top to bottom in the LAUNCHER PARENT, which must stay GPU-free (melissa_amd/launch.py) - it
+# parses its arguments, starts the ranks and never gets as far as ``train()``.
 
 
 def build_network(name: str, n_nodes: int, device, hidden=128, heads=4):
+    from .networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
     duel = ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})          # common.py:41-42
     if name == "l_dgn":
         return LDGNNetwork(5, hidden, 2, heads, n_nodes, dueling_param=duel, device=device)
@@ -46,6 +42,14 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     ``capture_updates``: replay the DQN update from HIP graphs (``DQNLearner.capture``; L-DGN / HL-DGN - a DGN-R batch has a
     data-dependent number of sibling rows).  None = on one rank without a probe; with several ranks the collective stays
     eager between two graphs and the mode is opt-in (True) until it has run over RCCL."""
+    import torch
+    from . import launch, parallel
+    from .collect import RoundLoop
+    from .env import HipGraphVectorEnv, synthetic_graph_pool
+    from .policy import DGNPolicy, DQNPolicy
+    from .replay import DGNLearner, DQNLearner, RoundReplay
+    if backend != "gloo":
+        launch.check_rank_device()                             # exit 2 when LOCAL_RANK names a GPU this rank cannot see
     rank, local_rank, world = parallel.init_distributed(backend)
     device = torch.device("cuda", local_rank if backend != "gloo" else 0)
     torch.cuda.set_device(device)

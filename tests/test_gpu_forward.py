@@ -336,7 +336,7 @@ def test_fused_selection_follows_the_oracle_rule_on_the_documented_stream(model)
     oracle.dqn_exploration_noise fed with the library's documented counter-based stream (restated above)."""
     import ctypes as C
     from melissa_amd import _lib
-    from melissa_amd.env.episodes import add_agent, agent_masks
+    from tests.test_gpu_round import add_agent, agent_masks
     from oracle import net_oracle as no
     n, bs = 20, 200
     g = np.load(golden_named("n20"))
