@@ -14,6 +14,8 @@ of the reference's per-reset pickle.load + RNG draws).  Replay-buffer routing
 """
 from __future__ import annotations
 
+import dataclasses
+
 import numpy as np
 import torch
 
@@ -274,6 +276,99 @@ class MultiStreamRoundLoop:
         return out
 
 
+@dataclasses.dataclass
+class SequenceSummaryStats:
+    """[3P] tianshou 1.0.0 ``SequenceSummaryStats``: mean / std / max / min of a sequence (what ``returns_stat`` / ``lens_stat`` /
+    ``info.stats[key]`` of the reference's collect result hold, collector.py:14-36)."""
+    mean: float
+    std: float
+    max: float
+    min: float
+
+    @classmethod
+    def from_sequence(cls, sequence) -> "SequenceSummaryStats":
+        a = np.asarray(sequence, dtype=np.float64)
+        return cls(mean=float(a.mean()), std=float(a.std()), max=float(a.max()), min=float(a.min()))
+
+
+@dataclasses.dataclass
+class DictOfSequenceSummaryStats:
+    """collector.py:14-30: ``stats[key]`` summarises the values of ``logger_stats[key]`` (graph.py:166-178)."""
+    stats: dict
+
+    @classmethod
+    def from_dict(cls, stats: dict) -> "DictOfSequenceSummaryStats":
+        return cls(stats={k: SequenceSummaryStats.from_sequence(v) for k, v in stats.items() if len(v)})
+
+
+@dataclasses.dataclass
+class CollectStatsWithInfo:
+    """The reference collectors' return value, field for field (collector.py:33-36 on top of [3P] tianshou ``CollectStats``;
+    built at multi_agent_collector.py:341-353).  ``returns[i]`` is episode i's reward sum as the env reports it at the
+    episode's last step (``logger_stats['episode_rewards_sum']``, graph.py:166-178); ``info.stats[key]`` summarises the
+    episodes' final ``logger_stats`` (the reference pools the ``logger_stats`` of EVERY collected step: same keys, a mean over
+    more samples).  ``episode_info``: the per-episode values behind ``info``.  The mapping protocol (``result["n/ep"]`` ...)
+    is the Tianshou-0.x spelling of the same numbers, kept for callers written against it."""
+    n_collected_episodes: int = 0
+    n_collected_steps: int = 0
+    collect_time: float = 0.0
+    collect_speed: float = 0.0
+    returns: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0))
+    returns_stat: "SequenceSummaryStats | None" = None
+    lens: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(0, int))
+    lens_stat: "SequenceSummaryStats | None" = None
+    info: "DictOfSequenceSummaryStats | None" = None
+    episode_info: dict = dataclasses.field(default_factory=dict)
+
+    _ALIASES = {"n/ep": "n_collected_episodes", "n/st": "n_collected_steps"}
+
+    def __getitem__(self, key):
+        if key in self._ALIASES:
+            return getattr(self, self._ALIASES[key])
+        if key in ("rew", "len"):
+            stat = self.returns_stat if key == "rew" else self.lens_stat
+            if stat is None:
+                raise KeyError(key)
+            return stat.mean
+        if key != "info" and self.info is not None and key in self.info.stats:
+            return self.info.stats[key].mean
+        if key.startswith("_") or not hasattr(self, key):
+            raise KeyError(key)
+        return getattr(self, key)
+
+    def __contains__(self, key):
+        try:
+            self[key]
+            return True
+        except KeyError:
+            return False
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        names = [f.name for f in dataclasses.fields(self)] + ["n/ep", "n/st"]
+        if self.returns_stat is not None:
+            names += ["rew", "len"]
+        return names + (list(self.info.stats) if self.info is not None else [])
+
+    def __iter__(self):
+        return iter(self.keys())
+
+
+def result_from_episode_log(stats: np.ndarray, meta: np.ndarray, total: int, steps: int, dt: float) -> CollectStatsWithInfo:
+    """The collect result from the device's episode log (``HipGraphVectorEnv.read_episode_log``: one row per finished episode
+    = the ``logger_stats`` of its last step and (env, pool episode, num_moves)), ``steps`` collected decisions, ``dt`` seconds."""
+    episode_info = {k: stats[:, i].copy() for i, k in enumerate(_lib.LOGGER_KEYS)}
+    returns = episode_info["episode_rewards_sum"].copy()
+    lens = meta[:, 2].astype(int)
+    return CollectStatsWithInfo(
+        n_collected_episodes=total, n_collected_steps=steps, collect_time=dt, collect_speed=steps / dt,
+        returns=returns, returns_stat=SequenceSummaryStats.from_sequence(returns) if len(returns) else None,
+        lens=lens, lens_stat=SequenceSummaryStats.from_sequence(lens) if len(lens) else None,
+        info=DictOfSequenceSummaryStats.from_dict(episode_info), episode_info=episode_info)
+
+
 class Collector:
     """The collect() surface of the reference's collectors (multi_agent_collector.py:89-353: ``collect(n_step=...)`` /
     ``collect(n_episode=...)`` returning counts, speed and the episodes' ``logger_stats``) on top of the device-resident
@@ -291,7 +386,7 @@ class Collector:
         self._decisions = self.loop.counters()["decisions"]
         self.collect_step, self.collect_episode, self.collect_time = 0, 0, 0.0
 
-    def collect(self, n_step: int | None = None, n_episode: int | None = None) -> dict:
+    def collect(self, n_step: int | None = None, n_episode: int | None = None) -> CollectStatsWithInfo:
         import time
         if (n_step is None) == (n_episode is None):
             raise ValueError("give exactly one of n_step / n_episode")        # the reference asserts the same
@@ -312,9 +407,85 @@ class Collector:
         self.collect_step += steps
         self.collect_episode += total
         self.collect_time += dt
-        out = {"n/ep": total, "n/st": steps, "collect_time": dt, "collect_speed": steps / dt,
-               "lens": meta[:, 2].copy(), "episode_info": {k: stats[:, i].copy() for i, k in enumerate(_lib.LOGGER_KEYS)}}
-        if len(stats):
-            out.update({k: float(stats[:, i].mean()) for i, k in enumerate(_lib.LOGGER_KEYS)})
-            out["len"] = float(meta[:, 2].mean())
-        return out
+        return result_from_episode_log(stats, meta, total, steps, dt)
+
+    def set_eps(self, eps: float) -> None:
+        """Exploration rate of the following collects.  The rate is an argument of the selection fused into the forward's last
+        launch: in HIP-graph mode a new value means a new capture (taken by the next round)."""
+        eps = float(eps)
+        if eps != self.loop.eps:
+            self.loop.eps = eps
+            self.loop._select.eps = eps
+            self.loop.graph = None
+
+
+class MultiAgentCollector(Collector):
+    """``MultiAgentCollector(agents_num, policy=..., env=..., buffer=None, exploration_noise=False)`` with
+    ``collect(n_step | n_episode, random, render, no_grad)`` -> :class:`CollectStatsWithInfo` - the reference's constructor and
+    call (multi_agent_collector.py:31-42, 89-118; call sites l_dgn.py:119-127, 185-201) in front of the device-resident
+    :class:`RoundLoop`.  One line changes in the reference's scripts: the import.
+
+    * ``env``: a :class:`melissa_amd.env.HipGraphVectorEnv` (the vector env of the scripts' ``DummyVectorEnv([...])``);
+      ``agents_num`` must be its node count.
+    * ``buffer``: a :class:`melissa_amd.replay.RoundReplay` or None.  The reference routes every agent's transition into one of
+      ``env_num * agents_num`` sub-buffers and holds it back until the agent's next observation arrives
+      (multi_agent_collector.py:229-271); here a whole env round is one record and ``RoundReplay.export_transitions()``
+      yields the same transitions with the reference's ``buffer_id = env * agents_num + agent``.
+    * ``exploration_noise``: eps-greedy with ``policy.eps`` (set by ``policy.set_eps`` in the scripts' ``train_fn``) when True,
+      greedy when False - [3P] ``DQNPolicy.exploration_noise`` through shared_policy.py:81-91, drawn on the device.
+    * ``random=True``: uniformly random actions (eps = 1), as ``self._action_space[i].sample()`` does.
+    * ``render``: not offered (the reference's matplotlib view, graph.py:466-484, is out of scope): a truthy value raises.
+    * ``no_grad``: accepted and ignored - the collect path never builds an autograd graph (the HIP forward has none)."""
+
+    def __init__(self, agents_num, policy=None, env=None, buffer=None, exploration_noise: bool = False, preprocess_fn=None,
+                 seed: int = 0, episodes_per_env: int = 16, chunk: int = 8, use_graph: bool = True, log_capacity: int = 65536):
+        if policy is None or env is None:
+            raise TypeError("MultiAgentCollector needs policy= and env=")
+        if preprocess_fn is not None:
+            raise NotImplementedError("preprocess_fn: the rounds never leave the device; nothing to hook per step")
+        if int(agents_num) != env.n:
+            raise ValueError(f"agents_num={agents_num} but the env has {env.n} agents")
+        self.agents_num = int(agents_num)
+        self.exploration_noise = bool(exploration_noise)
+        self.env, self.buffer = env, buffer
+        policy = getattr(policy, "policy", policy)          # a MultiAgentSharedPolicy manager wraps the one shared policy
+        eps = float(getattr(policy, "eps", 0.0)) if exploration_noise else 0.0
+        super().__init__(policy, env, episodes_per_env=episodes_per_env, seed=seed, eps=eps, replay=buffer,
+                         log_capacity=log_capacity, chunk=chunk, use_graph=use_graph)
+
+    @property
+    def env_num(self) -> int:
+        return self.venv.env_num
+
+    def reset(self, reset_buffer: bool = True, gym_reset_kwargs=None) -> None:
+        """[3P] ``Collector.reset``: statistics (and the buffer's write cursors) back to zero; the envs keep running - every
+        episode end already draws a fresh episode on the device."""
+        self.reset_stat()
+        if reset_buffer:
+            self.reset_buffer()
+
+    def reset_stat(self) -> None:
+        self.collect_step, self.collect_episode, self.collect_time = 0, 0, 0.0
+
+    def reset_buffer(self, keep_statistics: bool = False) -> None:
+        if self.buffer is not None:
+            self.buffer.cursor.zero_()
+            self.buffer.episode.fill_(-1)
+
+    def reset_env(self, gym_reset_kwargs=None) -> None:
+        """(the reference resets all envs after an n_episode collect; the device envs reset themselves at every episode end)"""
+
+    def collect(self, n_step: int | None = None, n_episode: int | None = None, random: bool = False, render=False,
+                no_grad: bool = False, gym_render_kwargs=None) -> CollectStatsWithInfo:
+        if render:
+            raise NotImplementedError("render: the reference's matplotlib view (graph.py:466-484) is out of scope")
+        if n_step is not None and n_episode is not None:
+            raise AssertionError(f"Only one of n_step or n_episode is allowed in Collector.collect, got n_step={n_step}, "
+                                 f"n_episode={n_episode}.")
+        if n_step is None and n_episode is None:
+            raise TypeError("Please specify at least one (either n_step or n_episode) in AsyncCollector.collect().")
+        if (n_step is not None and n_step <= 0) or (n_episode is not None and n_episode <= 0):
+            raise AssertionError("n_step / n_episode must be positive")
+        eps = 1.0 if random else (float(getattr(self.policy, "eps", 0.0)) if self.exploration_noise else 0.0)
+        self.set_eps(eps)
+        return super().collect(n_step=n_step, n_episode=n_episode)

@@ -122,7 +122,8 @@ def spawn_ranks(argv, n_ranks: int, python: str | None = None, extra_env: dict |
     Rank 0's JSON lines are relayed to ``stdout`` unchanged (the bench's one JSON line; anything else it prints goes to
     ``stderr``); the other ranks' stdout and every
     rank's stderr go to ``stderr`` with a ``[rank r]`` prefix.  If a rank exits non-zero the others are terminated
-    (exactly the PIDs started here).  Returns the largest exit code (signals count as 128 + signo)."""
+    (exactly the PIDs started here).  Returns the largest exit code of the ranks that ended by themselves (signals count as
+    128 + signo; the SIGTERM this function sends to the survivors of a failed run does not)."""
     stdout = stdout or sys.stdout
     stderr = stderr or sys.stderr
     port = free_port()
@@ -146,6 +147,7 @@ def spawn_ranks(argv, n_ranks: int, python: str | None = None, extra_env: dict |
             pumps.append(t)
     worst = 0
     live = set(range(n_ranks))
+    stopped = set()                                        # ranks THIS function terminated: their SIGTERM is not a result
     while live:
         for r in sorted(live):
             rc = procs[r].poll()
@@ -153,10 +155,12 @@ def spawn_ranks(argv, n_ranks: int, python: str | None = None, extra_env: dict |
                 continue
             live.discard(r)
             rc = 128 - rc if rc < 0 else rc
-            worst = max(worst, rc)
+            if r not in stopped or rc not in (0, 143):
+                worst = max(worst, rc)
             if rc != 0:                                    # one rank failed: the others would hang in a collective
                 for q in sorted(live):
                     procs[q].terminate()
+                    stopped.add(q)
         time.sleep(poll_s)
     for t in pumps:
         t.join(timeout=5)

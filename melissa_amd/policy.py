@@ -203,11 +203,22 @@ class MultiAgentSharedPolicy(nn.Module):
     """One shared policy for every agent id (shared_policy.py:14-31): ``forward`` returns the actions
     in the batch's original order, exactly what the reference's split / stitch produces."""
 
-    def __init__(self, policy: DQNPolicy, agents, **_):
+    def __init__(self, policy: DQNPolicy, env=None, agents=None, **_):
+        """``env``: as in the reference (shared_policy.py:23-30: a PettingZooEnv whose ``agents`` / ``agent_idx`` are taken) - here
+        a :class:`melissa_amd.env.HipGraphVectorEnv` (agents are named by their id, core.py:46) or anything with ``agents``;
+        a plain list of agent names is accepted too."""
         super().__init__()
         self.policy = policy
+        if agents is not None:
+            pass
+        elif hasattr(env, "agents"):
+            agents = env.agents
+        elif hasattr(env, "n") and hasattr(env, "env_num"):
+            agents = [str(i) for i in range(env.n)]
+        else:
+            agents = env
         self.agents = list(agents)
-        self.agent_idx = {a: i for i, a in enumerate(self.agents)}
+        self.agent_idx = getattr(env, "agent_idx", None) or {a: i for i, a in enumerate(self.agents)}
 
     def forward(self, batch, state=None, **kwargs) -> Batch:
         out = self.policy(batch, state=state, **kwargs)

@@ -172,7 +172,8 @@ class DQNLearner:
             else:
                 best = q_next.max(dim=1).values
             returns = b["ret"] + b["boot_w"] * best
-        return dict(obs=b["obs"], act=b["act"], returns=returns)
+        # (boot_obs / ret / boot_w: what `returns` was built from - tests recompute it through the target network)
+        return dict(obs=b["obs"], act=b["act"], returns=returns, boot_obs=b["boot_obs"], ret=b["ret"], boot_w=b["boot_w"])
 
     def step(self) -> dict:
         if self.captured is not None:

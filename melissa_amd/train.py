@@ -40,8 +40,8 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     pools >= 4096 go through the on-disk packed cache, ``melissa_amd.env.cached_graph_pool``).  Episodes come from the
     device episode stream: every reset draws a new (graph, source, interested set, movement seed) like World.reset.
     ``capture_updates``: replay the DQN update from HIP graphs (``DQNLearner.capture``; L-DGN / HL-DGN - a DGN-R batch has a
-    data-dependent number of sibling rows).  None = on one rank without a probe; with several ranks the collective stays
-    eager between two graphs and the mode is opt-in (True) until it has run over RCCL."""
+    data-dependent number of sibling rows).  None = on unless a probe is attached; with several ranks the collective stays
+    eager between two graphs.  The capture takes two extra (real, untimed) updates first: ``warmup_updates`` in the result."""
     import torch
     from . import launch, parallel
     from .collect import RoundLoop
@@ -71,10 +71,14 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     with torch.no_grad():
         loop.run(max(n_step + 1, 8))                           # pre-fill (l_dgn.py:201)
     if capture_updates is None:
-        capture_updates = world == 1 and probe is None
+        # on by default, with any number of ranks: the collective stays EAGER between two graphs (pack | all-reduce | unpack +
+        # step), so RCCL never enters a capture; rehearsed with two ranks on one GPU (tests/test_gpu_round.py)
+        capture_updates = probe is None
     captured = bool(capture_updates) and model != "dgn_r" and device.type == "cuda"
+    warmup_updates = 0
     if captured:
         learner.capture()                                      # (two warm-up updates, then the graphs)
+        warmup_updates = 2
     t0 = time.perf_counter()
     losses = []
     for _ in range(updates):
@@ -92,7 +96,11 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     checksum = float(torch.cat([p.detach().flatten() for p in net.parameters()]).double().sum())
     out = dict(rank=rank, world=world, model=model, updates=updates, seconds=dt, loss_first=losses[0],
                loss_last=losses[-1], decisions=c["decisions"], episodes=c["episodes"], errors=c["errors"],
-               param_checksum=checksum, updates_from_hip_graphs=captured)
+               param_checksum=checksum, updates_from_hip_graphs=captured,
+               # the capture's warm-up updates are REAL optimizer steps taken before the timed loop (they advance the policy's
+               # iteration counter and the replay sampler's generator): a run with capture on has taken `updates +
+               # warmup_updates` steps, `seconds` covers `updates` of them
+               warmup_updates=warmup_updates)
     # replicas must be identical after averaged-gradient steps
     same = parallel.all_reduce_max(checksum, device) == parallel.all_reduce_max(-checksum, device) * -1
     out["replicas_identical"] = bool(same)
@@ -114,7 +122,8 @@ def main():
     ap.add_argument("--graphs", type=int, default=16, help="training-graph dataset size (50000 = the reference's)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start (one per GPU) when not under torch.distributed.run")
     ap.add_argument("--capture-updates", choices=["auto", "on", "off"], default="auto",
-                    help="replay the DQN update from HIP graphs (auto: on one rank)")
+                    help="replay the DQN update from HIP graphs (auto: on; the capture runs 2 extra untimed warm-up updates first, "
+                         "reported as warmup_updates - compare on / off runs at equal total updates)")
     a = ap.parse_args()
     import os
     import sys

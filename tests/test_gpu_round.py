@@ -194,6 +194,8 @@ def round_loop_vs_oracle(n, dynamic, supply, B=6, K=40):
         refs.append(pz)
     sets = lambda: venv.node_sets().cpu().numpy().view(np.uint64)
     checked_rows = recorded_rounds = 0
+    running = [0.0] * B                       # this episode's reward sum per env, added up here from the oracle's reward vectors
+    ep_returns = [[] for _ in range(B)]
     for it in range(K):
         live = loop.live.cpu().numpy().view(np.uint64).copy()
         for b, pz in enumerate(refs):
@@ -216,7 +218,14 @@ def round_loop_vs_oracle(n, dynamic, supply, B=6, K=40):
             np.testing.assert_array_equal(mat[b].reshape(n, 8), pz.env.obs_matrix)
             acts = {a: act[offsets[b] + k] for k, a in enumerate(a for a in range(n) if (set_int(live[b]) >> a) & 1)}
             ep_before = pz.env_episode = getattr(pz, "env_episode", 0)
+            done_before = len(getattr(pz, "finished", []))
             outcome = oracle_round(pz, acts)
+            if outcome is not None:            # the world step paid every acting agent (graph.py:373-389), in id order
+                for a_id in sorted(acts):
+                    running[b] += outcome["rew"][a_id]
+            if len(getattr(pz, "finished", [])) > done_before:
+                ep_returns[b].append(running[b])
+                running[b] = 0.0
             if set_int(live[b]):                               # the replay record of this round
                 slot = (int(cursor[b]) - 1) % replay.K
                 assert outcome is not None
@@ -254,6 +263,17 @@ def round_loop_vs_oracle(n, dynamic, supply, B=6, K=40):
         for k, (want, moves) in zip(mine, pz.finished):
             np.testing.assert_array_equal(stats[k], [float(want[key]) for key in L.LOGGER_KEYS])
             assert meta[k, 2] == moves
+    # the collectors' result built from that log (collect.result_from_episode_log, what MultiAgentCollector.collect returns):
+    # `returns` = the oracle's per-episode reward sums, `lens` = its episode lengths, in the reference's field names
+    from melissa_amd.collect import result_from_episode_log
+    res = result_from_episode_log(stats, meta, total, steps=c["decisions"], dt=1.0)
+    assert res.n_collected_episodes == total and res.n_collected_steps == c["decisions"] and len(res.returns) == total
+    for b, pz in enumerate(refs):
+        mine = [k for k in range(total) if meta[k, 0] == b]
+        np.testing.assert_allclose(res.returns[mine], ep_returns[b], rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(res.returns[mine], [w["episode_rewards_sum"] for w, _ in pz.finished])
+        np.testing.assert_array_equal(res.lens[mine], [m for _, m in pz.finished])
+    assert res.returns_stat.mean == pytest.approx(float(np.mean(res.returns))) and res.info.stats["coverage"].max <= 1.0
 
 
 
@@ -518,6 +538,42 @@ def test_collector_surface_counts_and_episode_stats(n, B):
     assert col.collect_step >= 2000 and col.collect_episode >= 50
 
 
+def test_multi_agent_collector_is_called_like_the_reference():
+    """l_dgn.py:119-127 / 185-201: ``MultiAgentCollector(agents_num=..., policy=masp_policy, env=envs, buffer=...,
+    exploration_noise=...)``, ``.reset()``, ``.collect(n_step=...)`` / ``.collect(n_episode=...)`` -> the reference's result fields."""
+    from melissa_amd.collect import MultiAgentCollector
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.policy import DQNPolicy, MultiAgentSharedPolicy
+    from melissa_amd.replay import RoundReplay
+    n, B = 20, 32
+    net, _ = make_ldgn(n)
+    policy = DQNPolicy(net)
+    venv = HipGraphVectorEnv(B, n, graph_pool=synthetic_graph_pool(n, 4, first_seed=50), dynamic_graph=True, device="cuda",
+                             max_moves=48, seed=5, construct_like_reference=False)
+    masp = MultiAgentSharedPolicy(policy, venv)              # shared_policy.py:23-30: (policy, env)
+    assert masp.agents == [str(i) for i in range(n)]
+    buf = RoundReplay(B, n, 16, "cuda")
+    policy.set_eps(0.3)
+    train = MultiAgentCollector(agents_num=n, policy=masp, env=venv, buffer=buf, exploration_noise=True)
+    train.reset()
+    res = train.collect(n_step=32 * 8)
+    assert res.n_collected_steps >= 256 and res.collect_speed > 0 and res.collect_time > 0
+    assert len(res.returns) == res.n_collected_episodes == len(res.lens)
+    assert int(buf.cursor.max()) > 0                          # the rounds were recorded
+    policy.set_eps(0.0)
+    res = train.collect(n_episode=40)
+    assert res.n_collected_episodes >= 40 and res.returns_stat.min <= res.returns_stat.mean <= res.returns_stat.max
+    assert set(res.info.stats) == set(L.LOGGER_KEYS) and 0.0 < res.info.stats["coverage"].mean <= 1.0
+    rnd = train.collect(n_step=64, random=True)               # uniformly random actions
+    assert rnd.n_collected_steps >= 64
+    with pytest.raises(AssertionError):
+        train.collect(n_step=10, n_episode=2)
+    with pytest.raises(TypeError):
+        train.collect()
+    with pytest.raises(ValueError):
+        MultiAgentCollector(agents_num=n + 1, policy=masp, env=venv)
+
+
 @pytest.mark.parametrize("n", [50, 100])
 def test_decision_loop_runs_clean_and_matches_round_loop_counts(n):
     """The AEC-order loop (one agent decision per env per step, the reference collector's granularity) and the round loop are
@@ -597,6 +653,47 @@ def test_hldgn_fused_selection_equals_the_separate_launch(dueling, n):
                                               rounds.data_ptr(), want.data_ptr(), _lib.current_stream_ptr()))
         assert torch.equal(act, want)
         assert torch.equal(act.view(bs, n).cpu() >= 0, torch.from_numpy(member))      # exactly the member agents got an action
+
+
+@pytest.mark.parametrize("dtype", ["f32s", "bf16"])
+def test_captured_update_targets_follow_the_target_network_sync(dtype):
+    """The target network only ever runs INSIDE the captured graph, and on the split / bf16 precisions its launches read CONVERTED
+    projection weights from a buffer captured with them.  After every sync_weight() those planes must be reconverted (eagerly,
+    into the same buffer - a replay runs no Python): the graph's `returns` must equal ret + boot_w * max_a Q_target(boot_obs)
+    recomputed eagerly through model_old after each update, across several target syncs."""
+    from melissa_amd.collect import RoundLoop
+    from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
+    from melissa_amd.networks import HLDGNNetwork
+    from melissa_amd.policy import DQNPolicy
+    from melissa_amd.replay import DQNLearner, RoundReplay
+    n, envs = 20, 64
+    torch.manual_seed(3)
+    net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda")
+    net.set_feature_dtype(dtype)
+    policy = DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-2), estimation_step=4, target_update_freq=2)
+    policy.model_old.set_feature_dtype(dtype)
+    venv = HipGraphVectorEnv(envs, n, graph_pool=synthetic_graph_pool(n, 8, 0), dynamic_graph=True, device="cuda", max_moves=48,
+                             seed=11, construct_like_reference=False)
+    replay = RoundReplay(envs, n, 16, "cuda")
+    loop = RoundLoop(venv, policy, seed=11, eps=0.1, replay=replay)
+    with torch.no_grad():
+        loop.run(20)
+    learner = DQNLearner(policy, replay, batch_size=32, n_step=4, gamma=0.99, seed=2)
+    learner.capture()
+    moved = 0.0
+    for k in range(7):                                        # target syncs at iterations 2, 4, 6, 8 (two warm-up updates ran)
+        before = [p.detach().clone() for p in policy.model_old.parameters()]
+        learner.step()
+        torch.cuda.synchronize()
+        b = {key: v.clone() for key, v in learner.last_batch.items()}
+        moved = max(moved, max(float((p.detach() - q).abs().max()) for p, q in zip(policy.model_old.parameters(), before)))
+        fresh = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda")
+        fresh.set_feature_dtype(dtype)
+        fresh.load_state_dict(policy.model_old.state_dict())  # a network that converts these very weights now
+        with torch.no_grad():
+            want = b["ret"] + b["boot_w"] * fresh.hip_forward(b["boot_obs"]).max(dim=1).values
+        assert torch.equal(b["returns"], want), (k, float((b["returns"] - want).abs().max()))
+    assert moved > 1e-4                                       # the target weights really changed in between
 
 
 @pytest.mark.parametrize("collective", [False, True], ids=["one_graph", "pack_reduce_unpack"])

@@ -360,3 +360,39 @@ def test_captured_update_refuses_what_it_cannot_capture():
     red.flat.mul_(0.5)
     red.unpack()
     assert all(float(p.grad.min()) == 1.0 == float(p.grad.max()) for p in net.parameters())
+
+
+def test_collect_result_has_the_reference_field_set():
+    """The names the reference's collectors return (collector.py:14-36 ``DictOfSequenceSummaryStats`` / ``CollectStatsWithInfo``
+    on top of [3P] tianshou 1.0.0 ``CollectStats``; filled at multi_agent_collector.py:341-353) and the constructor / call
+    keywords of ``MultiAgentCollector`` (multi_agent_collector.py:31-42, 89-97; call sites l_dgn.py:119-127, 185-201)."""
+    import dataclasses
+    import inspect
+    from melissa_amd import _lib
+    from melissa_amd.collect import (CollectStatsWithInfo, DictOfSequenceSummaryStats, MultiAgentCollector, SequenceSummaryStats,
+                                     result_from_episode_log)
+    reference_fields = ["n_collected_episodes", "n_collected_steps", "collect_time", "collect_speed", "returns", "returns_stat",
+                        "lens", "lens_stat", "info"]                       # multi_agent_collector.py:341-353, in that order
+    names = [f.name for f in dataclasses.fields(CollectStatsWithInfo)]
+    assert names[:len(reference_fields)] == reference_fields
+    assert [f.name for f in dataclasses.fields(SequenceSummaryStats)] == ["mean", "std", "max", "min"]       # [3P] tianshou 1.0.0
+    assert [f.name for f in dataclasses.fields(DictOfSequenceSummaryStats)] == ["stats"]                     # collector.py:17
+    ctor = inspect.signature(MultiAgentCollector.__init__).parameters
+    assert list(ctor)[:6] == ["self", "agents_num", "policy", "env", "buffer", "exploration_noise"]
+    assert ctor["buffer"].default is None and ctor["exploration_noise"].default is False
+    call = inspect.signature(MultiAgentCollector.collect).parameters
+    assert list(call)[:7] == ["self", "n_step", "n_episode", "random", "render", "no_grad", "gym_render_kwargs"]
+    assert call["random"].default is False and call["no_grad"].default is False
+    # two finished episodes, as the device log hands them over
+    stats = np.zeros((2, len(_lib.LOGGER_KEYS)))
+    stats[:, _lib.LOGGER_KEYS.index("episode_rewards_sum")] = [1.5, -0.5]
+    stats[:, _lib.LOGGER_KEYS.index("coverage")] = [0.5, 1.0]
+    meta = np.array([[0, 3, 7], [1, 4, 9]], dtype=np.int32)
+    res = result_from_episode_log(stats, meta, total=2, steps=40, dt=2.0)
+    assert res.n_collected_episodes == 2 and res.n_collected_steps == 40 and res.collect_speed == 20.0
+    assert res.returns.tolist() == [1.5, -0.5] and res.lens.tolist() == [7, 9]
+    assert res.returns_stat == SequenceSummaryStats(mean=0.5, std=1.0, max=1.5, min=-0.5) and res.lens_stat.mean == 8.0
+    assert res.info.stats["coverage"].mean == 0.75 and set(res.info.stats) == set(_lib.LOGGER_KEYS)
+    assert res["n/ep"] == 2 and res["n/st"] == 40 and res["coverage"] == 0.75 and res["len"] == 8.0 and "nope" not in res
+    empty = result_from_episode_log(stats[:0], meta[:0], total=0, steps=5, dt=1.0)
+    assert empty.returns_stat is None and empty.lens_stat is None and len(empty.returns) == 0 and empty.info.stats == {}
