@@ -406,7 +406,7 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
 
     # HBM-side rooflines of the non-contraction kernels: COMPULSORY bytes per launch - every row the launch
     # needs read once, every row it produces written once - over the launch's average duration, against the HBM peak.  They
-    # are latency / VALU bound; the fractions say how far from a streaming kernel they are.
+    # are latency / VALU bound (NOTES.md section 5); the fractions say how far from a streaming kernel they are.
     hbm_rooflines = None
     if args.mode == "round" and args.model == "l_dgn":
         esz = 2 if args.dtype == "bf16" else 4

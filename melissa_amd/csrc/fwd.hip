@@ -83,7 +83,7 @@ static void gemm_launch_ring_t(const GemmArgs* gs, int count, hipStream_t s) {
 static void gemm_launch_ragged(const GemmArgs* gs, int count, hipStream_t s, int tag) {
     // Long-K problems (the heads' first layer, K = 1152: 36 K steps per tile) go to the specialised-wavefront kernel:
     // measured 27.4 vs 30.7 us for the head launches; at K <= 512 the one-role kernel is as fast or faster
-    // (conv2 84 vs 85 us, conv1 46 vs 53 us), see DESIGN.md.
+    // (conv2 84 vs 85 us, conv1 46 vs 53 us), see NOTES.md.
     bool long_k = true;
     for (int i = 0; i < count; ++i) long_k = long_k && gs[i].K >= 1024 && gs[i].ldy % 4 == 0;
     if (long_k) {
@@ -405,8 +405,6 @@ struct Dims {
     int64_t u2_cap;    // most conv1 sources
 };
 
-// tuning switch (mel_debug_att_env): 0 = the row kernels for every attention launch
-static int g_att_env = 1;
 static Dims make_dims(int64_t bs, int n, int64_t rows_cap, bool single_agent) {
     Dims d;
     d.bs = bs, d.n = n, d.rows_cap = rows_cap;
@@ -868,10 +866,6 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const int T = n * FEATURE_TUPLES_PER_DEGREE;
     const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && hint1 + hint2 >= 2L * T;
     bool fused_enc = false;
-    // attention with the env's source rows staged in LDS (gat_attend_env_kernel): worth it when an env has several targets
-    // that share sources, i.e. for the agent-set entry points (one agent per row has ~7 targets per env and bs workgroups of
-    // eight waves each would mostly idle: the row kernel stays)
-    const bool att_env = !single && g_att_env != 0;
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -952,7 +946,6 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = ft.h0;
         a.out_scale = L.plan.dm1;       // the decision-maker mask (l_dgn.py:128) is applied as h1 is stored; x_2 is taken before it
         a.fid = table ? L.plan.fid : nullptr;
-        a.env_off = att_env ? L.plan.off1 : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
         if (mel_status st = launch_attend<ATT_ROWS>(a, hc, s, "conv1 attention")) return st;
     }
@@ -980,7 +973,6 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.bs = (int)bs, a.n = n, a.lanes_per_head = w->conv2.channels / (hc / 64);
         a.desc = L.plan.desc2, a.rows_dev = nL, a.rows_cap = R, a.rows_hint = hintL;
         a.xcat = L.xcat, a.ld_cat = latent, a.cat_off = hidden + hc;
-        a.env_off = att_env ? L.plan.offL : nullptr;
         StageScope t(MEL_STAGE_CONV2_ATT, s);
         if (mel_status st = launch_attend<ATT_SINGLE>(a, hc, s, "conv2 attention")) return st;
     }
@@ -994,8 +986,6 @@ using namespace mel;
 extern "C" {
 
 const char* mel_last_error(void) { return g_err; }
-// tuning only: 1 = L-DGN's round-batched attention launches stage an env's source rows in LDS (default), 0 = the row kernels
-void mel_debug_att_env(int on) { g_att_env = on; }
 // tuning builds only (-DMEL_FIN_PROF): read and reset the head finish kernel's cycle counters
 void mel_debug_fin_prof(unsigned long long* out5) {
 #ifdef MEL_FIN_PROF

@@ -8,7 +8,7 @@
 //                         epilogue (scale, bias, ReLU, 16-byte row stores) of the tile the consumers just finished
 //
 // Why: in the one-role kernels (gemm_f32.hpp) the workgroups that share a CU move through load -> LDS -> MFMA phases
-// in step, so the data-movement skeleton and the MFMA chain of a launch add up instead of overlapping (DESIGN.md,
+// in step, so the data-movement skeleton and the MFMA chain of a launch add up instead of overlapping (NOTES.md,
 // "GEMM status": conv2 38 us + 51.5 us ~ the measured 87).  Here the two never wait for each other inside a K step:
 // a consumer wave's step is 8 fragment reads + 16 MFMAs and nothing else, a loader wave's step is "issue the DMAs of
 // step g+4, make sure step g+2 has landed", and one s_barrier per step hands a stage over in each direction.

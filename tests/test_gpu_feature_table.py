@@ -127,40 +127,3 @@ def test_prepared_tables_equal_per_call_tables(model, dtype):
         changed = net.hip_forward(obs, integer_features=True).clone()
         net.prepared_tables = False
         assert not torch.equal(changed, per_call) and torch.equal(changed, net.hip_forward(obs, integer_features=True))
-
-
-@pytest.mark.parametrize("table", [False, True], ids=["row_lists", "feature_table"])
-@pytest.mark.parametrize("n,bs,density", [(20, 300, 0.2), (50, 260, 0.12), (50, 64, 0.9), (100, 96, 0.08), (100, 40, 0.5)])
-def test_env_staged_attention_is_bit_identical_to_the_row_kernels(n, bs, density, table):
-    """gat_attend_env_kernel (csrc/attention.hpp): a workgroup per env stages the env's source rows in LDS once and its targets
-    read them from there - the same arithmetic per row in the same order as the one-wave-per-target kernels, so logits, actions
-    and the head input must be BIT-IDENTICAL, with row lists and with the node-feature table, one- and two-word node sets, and for
-    envs whose source set exceeds the 32 rows an env can stage (dense agent sets: those take the row kernel's loads inside the
-    same launch)."""
-    from melissa_amd import _lib
-    lib = _lib.load()
-    rng = np.random.RandomState(n + bs)
-    obs = torch.from_numpy(env_like_obs(n, bs, 11 + n, index_col=False)).cuda()
-    member = rng.uniform(size=(bs, n)) < density
-    member[::11] = False                                                   # envs without a single agent
-    words = (n + 63) // 64
-    masks = np.zeros((bs, words), dtype=np.uint64)
-    for b, a in zip(*np.nonzero(member)):
-        masks[b, a // 64] |= np.uint64(1) << np.uint64(a % 64)
-    am = torch.from_numpy(masks.view(np.int64).reshape(bs, words) if words > 1 else masks.view(np.int64).reshape(bs)).cuda()
-    rows = int(member.sum())
-    net, _ = make("l_dgn", n)
-    outs = []
-    for env_kernel in (0, 1):
-        lib.mel_debug_att_env(env_kernel)
-        with torch.no_grad():
-            logits, offsets = net.hip_forward_agents(obs, am, bs * n, integer_features=table)
-            xcat = net.hip_tap(1, bs, bs * n)[:rows].clone()           # head input x_1 | x_2 | x_3 of every agent row
-        torch.cuda.synchronize()
-        assert int(offsets[-1]) == rows
-        outs.append((logits[:rows].clone(), xcat))
-        used = int(net.hip_tap(3, bs, bs * n)[0])
-        assert used in (0, n * 40) and (table or used == 0)
-    lib.mel_debug_att_env(1)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert torch.isfinite(outs[1][0]).all() and rows > 0

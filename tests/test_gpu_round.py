@@ -533,6 +533,7 @@ def test_collector_surface_counts_and_episode_stats(n, B):
 def test_multi_agent_collector_is_called_like_the_reference():
     """l_dgn.py:119-127 / 185-201: ``MultiAgentCollector(agents_num=..., policy=masp_policy, env=envs, buffer=...,
     exploration_noise=...)``, ``.reset()``, ``.collect(n_step=...)`` / ``.collect(n_episode=...)`` -> the reference's result fields."""
+    from melissa_amd import _lib as L
     from melissa_amd.collect import MultiAgentCollector
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
     from melissa_amd.policy import DQNPolicy, MultiAgentSharedPolicy

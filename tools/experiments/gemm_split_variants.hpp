@@ -47,7 +47,7 @@ constexpr int GEMW_BIAS_FLOATS = 2048;
 // DENSE (WN = 2 only): THREE workgroups per CU - LDS rows without the pad chunk (96 bytes; chunk c of row r sits in slot
 // c ^ ((r >> 3) & 1), which keeps the fragment reads conflict-free), 48 KB of stages and nothing else in LDS (the epilogue
 // stores straight from the accumulators), at most 168 VGPRs.  A wave's K step is ~3 000 cycles of latencies around 768 cycles of
-// matrix work: a third wave per SIMD is a third more of them in flight.
+// matrix work (NOTES.md): a third wave per SIMD is a third more of them in flight.
 template <int TAG = 0, int WN = 4, bool DENSE = false>
 __global__ __launch_bounds__(128 * WN, DENSE ? 3 : 2) void gemm_split_wide_kernel(GemmBatch batch) {
     static_assert(!DENSE || WN == 2, "DENSE is the 128 x 128 form");
