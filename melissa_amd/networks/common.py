@@ -558,6 +558,28 @@ class GraphQNetwork(HipForwardMixin, nn.Module):
         logits = self._dispatch(self._prepare_obs(obs))
         return logits, (state if self._RETURNS_STATE else None)
 
+    def torch_forward_all_agents(self, obs_matrix: torch.Tensor) -> torch.Tensor:
+        """Q values of EVERY node of every graph as controlling agent: ``obs_matrix`` [G, 8N] (a round's shared observation,
+        graph.py:186-188: the rows of a round's agents differ only in the index column) -> logits [G, N, A] with
+        ``[g, j] == torch_forward(cat(obs_matrix[g], j))`` - encoder and both convolutions run ONCE per graph (they do not
+        depend on the controlling agent, l_dgn.py:117-135 / dgn_r.py:95-125), only the head runs per (graph, agent).  The learn
+        path of DGN-R (policies/dgn.py:31-55 sums Q over all agents that acted in the sampled round) evaluates one graph per
+        sampled experience instead of one per sibling, with static shapes."""
+        if not hasattr(self, "conv2"):
+            raise RuntimeError("torch_forward_all_agents is for the two-convolution networks (L-DGN, DGN-R)")
+        obs_matrix = obs_matrix.to(self.device)
+        G, n = obs_matrix.shape[0], self.agents_num
+        node = obs_matrix.reshape(G, n, self.input_dim + 3).float()
+        pos, feats, dm = node[:, :, :2], node[:, :, 2:2 + self.input_dim], node[:, :, -1:]
+        hip = use_hip_autograd(self, obs_matrix)
+        # (the adjacency kernels take observation rows with an index column: any value, it is not read)
+        adj = learn_adjacency(torch.cat([obs_matrix.float(), obs_matrix.new_zeros(G, 1, dtype=torch.float32)], dim=1), pos, n,
+                              self.input_dim, hip)
+        x_1 = F.relu(mlp(self.encoder, feats.reshape(G * n, -1), hip))
+        x_2 = conv_relu(self.conv1, x_1, adj, n, hip)
+        x_3 = conv_relu(self.conv2, x_2 * dm.reshape(G * n, 1), adj, n, hip)
+        return self._head(torch.cat([x_1, x_2, x_3], dim=1), hip).view(G, n, -1)
+
     def _two_conv_torch_forward(self, obs: torch.Tensor) -> torch.Tensor:
         """encoder -> conv1 -> dm mask -> conv2 with the controlling agent's rows gathered after each stage
         (l_dgn.py:117-149, dgn_r.py:95-127) in differentiable ops; on ROCm devices the convolutions' attention runs in

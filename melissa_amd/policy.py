@@ -151,34 +151,51 @@ class DGNPolicy(DQNPolicy):
     (SURVEY.md 8(f) #3).  Same loss value and gradients (tests/test_host_logic.py compares with the loop)."""
 
     def learn(self, batch, grad_hook=None) -> dict:
-        """batch: ``returns`` [B]; ``active_obs`` [M, 8N+1] (all sibling observations, index column = the sibling),
-        ``active_act`` [M], ``segment`` [M] = experience each sibling row belongs to; optional ``weight``."""
+        """batch: ``returns`` [B] and EITHER the reference's row form - ``active_obs`` [M, 8N+1] (all sibling observations,
+        index column = the sibling), ``active_act`` [M], ``segment`` [M] = experience each sibling row belongs to - OR the
+        dense form ``obs_matrix`` [B, 8N], ``act_all`` [B, N], ``sibling`` [B, N] (who acted in the sampled round): the same
+        loss, one graph evaluation per experience instead of one per sibling.  Optional ``weight``."""
         if self._target and self._iter % self._freq == 0:
             self.sync_weight()
-        self.optim.zero_grad()
+        loss = self.loss_backward(batch)
+        if grad_hook is not None:
+            grad_hook(self.model)
+        self.optim.step()
+        self._iter += 1
+        return {"loss": float(loss)}
+
+    def loss_backward(self, batch) -> torch.Tensor:
+        """zero_grad + forward + DGN loss + backward; returns the detached loss (a device tensor, no host synchronisation:
+        the dense form has static shapes and can be captured by replay.CapturedUpdate)."""
+        self.optim.zero_grad(set_to_none=True)
         with torch.enable_grad():
-            logits, _ = self.model(batch["active_obs"])
-            dev = logits.device
-            act = torch.as_tensor(batch["active_act"], device=dev, dtype=torch.long)
-            seg = torch.as_tensor(batch["segment"], device=dev, dtype=torch.long)
-            returns = torch.as_tensor(batch["returns"], device=dev, dtype=logits.dtype).flatten()
-            q = logits[torch.arange(len(act), device=dev), act]
-            batch_q = torch.zeros_like(returns).index_add(0, seg, q)
+            if "obs_matrix" in batch:
+                q_all = self.model.torch_forward_all_agents(batch["obs_matrix"])               # [B, N, A]
+                dev = q_all.device
+                act = torch.as_tensor(batch["act_all"], device=dev, dtype=torch.long)
+                sib = torch.as_tensor(batch["sibling"], device=dev).to(q_all.dtype)
+                returns = torch.as_tensor(batch["returns"], device=dev, dtype=q_all.dtype).flatten()
+                q = q_all.gather(2, act[..., None]).squeeze(2)                                  # [B, N]
+                batch_q = (q * sib).sum(dim=1)                                                  # dgn.py:43-55
+            else:
+                logits, _ = self.model(batch["active_obs"])
+                dev = logits.device
+                act = torch.as_tensor(batch["active_act"], device=dev, dtype=torch.long)
+                seg = torch.as_tensor(batch["segment"], device=dev, dtype=torch.long)
+                returns = torch.as_tensor(batch["returns"], device=dev, dtype=logits.dtype).flatten()
+                q = logits[torch.arange(len(act), device=dev), act]
+                batch_q = torch.zeros_like(returns).index_add(0, seg, q)
             td = returns - batch_q
             if self._clip_loss_grad:
                 loss = torch.nn.functional.huber_loss(batch_q.reshape(-1, 1), returns.reshape(-1, 1), reduction="mean")
             else:
                 weight = batch.get("weight", 1.0) if isinstance(batch, dict) else 1.0
-                weight = torch.as_tensor(weight, device=dev, dtype=logits.dtype)
+                weight = torch.as_tensor(weight, device=dev, dtype=td.dtype)
                 loss = (td.pow(2) * weight).mean()
             loss.backward()
-        if grad_hook is not None:
-            grad_hook(self.model)
-        self.optim.step()
-        self._iter += 1
-        if isinstance(batch, dict):
+        if isinstance(batch, dict) and "obs_matrix" not in batch:
             batch["weight"] = td.detach()            # prio-buffer hook, dgn.py:66
-        return {"loss": float(loss.detach())}
+        return loss.detach()
 
     @staticmethod
     def segments_from_indices(indices: np.ndarray, active_index: np.ndarray):

@@ -281,10 +281,17 @@ class CapturedUpdate:
 
 class DGNLearner(DQNLearner):
     """DGN-R update (policies/dgn.py): the sampled experiences' n-step returns regress on the summed Q of their
-    siblings; one batched forward over all sibling observations (policy = :class:`melissa_amd.policy.DGNPolicy`)."""
+    siblings (policy = :class:`melissa_amd.policy.DGNPolicy`).  All siblings of an experience acted in the same env round and
+    so share its observation matrix: the network body runs once per sampled experience and its head once per (experience,
+    node) - ``GraphQNetwork.torch_forward_all_agents`` - instead of one whole forward per sibling row (the reference's loop,
+    dgn.py:31-55: ~21 siblings per experience at N = 50).  Every tensor of the update then has a static shape, so it replays
+    from HIP graphs like the DQN update (``capture()``)."""
 
-    def step(self) -> dict:
-        b = self.replay.sample_collective(self.batch_size, self.n_step, self.gamma, self.gen)
+    def sample_batch(self) -> dict:
+        """Sample + n-step targets in the DENSE form (static shapes, no host synchronisation): obs_matrix [B, 8N], act_all
+        [B, N], sibling [B, N] (the agents that acted in the sampled round), returns [B]."""
+        b = self.replay.sample(self.batch_size, self.n_step, self.gamma, self.gen)
+        e, k = b["env"], b["slot"]
         with torch.no_grad():
             target_net = self.policy.model_old if getattr(self.policy, "_target", False) else self.policy.model
             fwd = (lambda net, o: net.hip_forward(o)) if b["boot_obs"].is_cuda else (lambda net, o: net.torch_forward(o))
@@ -294,5 +301,21 @@ class DGNLearner(DQNLearner):
             else:
                 best = q_next.max(dim=1).values
             returns = b["ret"] + b["boot_w"] * best
-        self.last_batch = dict(active_obs=b["active_obs"], active_act=b["active_act"], segment=b["segment"], returns=returns)
-        return self.policy.learn(dict(self.last_batch), grad_hook=self.grad_hook)
+        return dict(obs_matrix=self.replay.obs[e, k], act_all=self.replay.act[e, k].long(),
+                    sibling=self.replay._members(self.replay.acted[e, k]), returns=returns, boot_obs=b["boot_obs"], ret=b["ret"],
+                    boot_w=b["boot_w"], env=e, slot=k)
+
+    def row_form(self, batch: dict) -> dict:
+        """The same batch in the reference's row form (what collective_experience_collector.py:70-80 records as ``info.indices``:
+        one row per sibling, ordered by experience then agent id): active_obs [M, 8N+1], active_act [M], segment [M].  M depends
+        on the data (host synchronisation): for tests and for callers that keep the reference's loss loop."""
+        seg, agent = torch.nonzero(batch["sibling"], as_tuple=True)
+        obs = torch.cat([batch["obs_matrix"][seg], agent.float()[:, None]], dim=1)
+        return dict(active_obs=obs, active_act=batch["act_all"][seg, agent], segment=seg, returns=batch["returns"])
+
+    def step(self) -> dict:
+        if self.captured is not None:
+            return self.captured.step()
+        batch = self.sample_batch()
+        self.last_batch = dict(batch, **self.row_form(batch))
+        return self.policy.learn(dict(batch), grad_hook=self.grad_hook)

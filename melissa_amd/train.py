@@ -39,8 +39,8 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     ``graphs``: size of the synthetic training-graph dataset (the reference trains on 50 000 graphs per size, README.md:92-93;
     pools >= 4096 go through the on-disk packed cache, ``melissa_amd.env.cached_graph_pool``).  Episodes come from the
     device episode stream: every reset draws a new (graph, source, interested set, movement seed) like World.reset.
-    ``capture_updates``: replay the DQN update from HIP graphs (``DQNLearner.capture``; L-DGN / HL-DGN - a DGN-R batch has a
-    data-dependent number of sibling rows).  None = on unless a probe is attached; with several ranks the collective stays
+    ``capture_updates``: replay the update from HIP graphs (``DQNLearner.capture``; DGN-R too: its dense sibling form has static
+    shapes, replay.DGNLearner).  None = on unless a probe is attached; with several ranks the collective stays
     eager between two graphs.  The capture takes two extra (real, untimed) updates first: ``warmup_updates`` in the result."""
     import torch
     from . import launch, parallel
@@ -74,7 +74,7 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
         # on by default, with any number of ranks: the collective stays EAGER between two graphs (pack | all-reduce | unpack +
         # step), so RCCL never enters a capture; rehearsed with two ranks on one GPU (tests/test_gpu_round.py)
         capture_updates = probe is None
-    captured = bool(capture_updates) and model != "dgn_r" and device.type == "cuda"
+    captured = bool(capture_updates) and device.type == "cuda"
     warmup_updates = 0
     if captured:
         learner.capture()                                      # (two warm-up updates, then the graphs)

@@ -475,6 +475,7 @@ def test_training_loop_n50_first_update_matches_oracle_autograd(model):
         else:
             cap["batch"] = {key: v.detach().cpu() for key, v in learner.last_batch.items()}
             cap["after"] = {key: v.detach().cpu().clone() for key, v in net.state_dict().items()}
+            cap["grad"] = {key: p.grad.detach().cpu().clone() for key, p in net.named_parameters() if p.grad is not None}
 
     out = train(model=model, n_nodes=n, envs=64, updates=2, rounds_per_update=3, batch_size=32, lr=lr,
                 log=lambda *_: None, probe=probe)
@@ -504,6 +505,20 @@ def test_training_loop_n50_first_update_matches_oracle_autograd(model):
         checked += int(big.sum())
         agree += int((torch.sign(delta[big]) == -torch.sign(g[big])).sum())
     assert checked > 10000 and agree >= 0.999 * checked, (checked, agree)
+    # ... and the gradient itself, number for number: what the HIP learn path (csrc/grad.hip backward kernels + the library's
+    # GEMMs) left in .grad against oracle autograd on the same batch and weights - every tensor within 2e-4 of its largest entry
+    # (the bar of tests/test_gpu_grad.py, here at the training loop's own size: N = 50, 32 sampled experiences, DGN-R: all their
+    # siblings)
+    compared = 0
+    for k, g in ((k, v.grad) for k, v in sd.items()):
+        if g is None:
+            continue
+        assert k in cap["grad"], k
+        got = cap["grad"][k]
+        scale = float(g.abs().max())
+        assert float((got - g).abs().max()) <= 2e-4 * max(scale, 1e-6), (k, float((got - g).abs().max()), scale)
+        compared += g.numel()
+    assert compared > 300000
 
 
 @pytest.mark.parametrize("n,B", [(20, 32), (100, 8)])
@@ -690,7 +705,7 @@ def test_captured_update_targets_follow_the_target_network_sync(dtype):
 
 
 @pytest.mark.parametrize("collective", [False, True], ids=["one_graph", "pack_reduce_unpack"])
-@pytest.mark.parametrize("model", ["hl_dgn", "l_dgn"])
+@pytest.mark.parametrize("model", ["hl_dgn", "l_dgn", "dgn_r"])
 def test_captured_update_equals_the_eager_update(model, collective):
     """DQNLearner.capture(): the update replayed from HIP graphs (sample -> n-step targets -> forward / backward ->
     [pack | eager reduce | unpack] -> Adam) must move the parameters exactly like an eager update on the same batch from the same
@@ -701,18 +716,22 @@ def test_captured_update_equals_the_eager_update(model, collective):
     from melissa_amd import parallel
     from melissa_amd.collect import RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
-    from melissa_amd.networks import HLDGNNetwork, LDGNNetwork
-    from melissa_amd.policy import DQNPolicy
-    from melissa_amd.replay import DQNLearner, RoundReplay
+    from melissa_amd.networks import DGNRNetwork, HLDGNNetwork, LDGNNetwork
+    from melissa_amd.policy import DGNPolicy, DQNPolicy
+    from melissa_amd.replay import DGNLearner, DQNLearner, RoundReplay
     n, envs = 20, 64
+    # dgn_r: DGNPolicy's summed-sibling loss in its dense form (static shapes: one graph per sampled experience)
+    policy_cls, learner_cls = (DGNPolicy, DGNLearner) if model == "dgn_r" else (DQNPolicy, DQNLearner)
 
     def make_policy():
         torch.manual_seed(3)
         if model == "hl_dgn":
             net = HLDGNNetwork(5, 128, 2, 4, n, aggregator="max", dueling_param=DUEL(), device="cuda")
+        elif model == "dgn_r":
+            net = DGNRNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda")
         else:
             net = LDGNNetwork(5, 128, 2, 4, n, dueling_param=DUEL(), device="cuda")
-        return net, DQNPolicy(net, torch.optim.Adam(net.parameters(), lr=1e-3), estimation_step=4, target_update_freq=3)
+        return net, policy_cls(net, torch.optim.Adam(net.parameters(), lr=1e-3), estimation_step=4, target_update_freq=3)
 
     net, policy = make_policy()
     venv = HipGraphVectorEnv(envs, n, graph_pool=synthetic_graph_pool(n, 8, 0), dynamic_graph=True, device="cuda", max_moves=48,
@@ -729,7 +748,7 @@ def test_captured_update_equals_the_eager_update(model, collective):
             self.flat.mul_(1.0)
 
     hook = LocalReducer(net) if collective else None
-    learner = DQNLearner(policy, replay, batch_size=32, n_step=4, gamma=0.99, grad_hook=hook, seed=2)
+    learner = learner_cls(policy, replay, batch_size=32, n_step=4, gamma=0.99, grad_hook=hook, seed=2)
     learner.capture()
     twin_net, twin = make_policy()
     for k in range(5):                                       # covers two target syncs (every 3 updates; 2 warm-up updates ran)

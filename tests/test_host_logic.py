@@ -255,6 +255,44 @@ def test_sample_collective_siblings_and_dgn_learner_step(n):
     assert any(not torch.equal(a, p.detach()) for a, p in zip(before, net.parameters()))
 
 
+@pytest.mark.parametrize("model,n", [("dgn_r", 6), ("l_dgn", 9), ("dgn_r", 70)])
+def test_dgn_dense_form_equals_the_row_form(model, n):
+    """The learn path's dense form - network body once per sampled experience, head once per (experience, node), siblings as a
+    [B, N] mask (GraphQNetwork.torch_forward_all_agents, DGNPolicy.loss_backward) - against the reference's row form (one
+    observation row per sibling, policies/dgn.py:31-55): same Q values, same loss, same gradients."""
+    from melissa_amd.networks import LDGNNetwork
+    from melissa_amd.policy import DGNPolicy
+    from melissa_amd.replay import DGNLearner
+    rp = _filled_round_replay(n=n)
+
+    def make():
+        torch.manual_seed(4)
+        cls = DGNRNetwork if model == "dgn_r" else LDGNNetwork
+        return cls(5, 32, 2, 2, n, dueling_param=({"hidden_sizes": [64]}, {"hidden_sizes": [64]}), device="cpu", backend="torch")
+
+    net_a, net_b = make(), make()
+    pol_a = DGNPolicy(net_a, torch.optim.SGD(net_a.parameters(), lr=0.0))
+    pol_b = DGNPolicy(net_b, torch.optim.SGD(net_b.parameters(), lr=0.0))
+    learner = DGNLearner(pol_a, rp, batch_size=8, n_step=2, gamma=0.9, seed=1)
+    dense = learner.sample_batch()
+    rows = learner.row_form(dense)
+    assert rows["segment"].numel() == int(dense["sibling"].sum()) and dense["obs_matrix"].shape == (8, 8 * n)
+    # Q of every (experience, node) equals the per-row forward on [obs_matrix | node]
+    with torch.no_grad():
+        q_all = net_a.torch_forward_all_agents(dense["obs_matrix"])
+        per_row = net_a.torch_forward(rows["active_obs"])
+    seg, agent = rows["segment"], rows["active_obs"][:, -1].long()
+    torch.testing.assert_close(q_all[seg, agent], per_row, atol=1e-6, rtol=1e-5)
+    la = pol_a.loss_backward({k: dense[k] for k in ("obs_matrix", "act_all", "sibling", "returns")})
+    lb = pol_b.loss_backward(dict(rows))
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    for (name, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        if pb.grad is None:
+            assert pa.grad is None or float(pa.grad.abs().max()) == 0.0, name
+            continue
+        torch.testing.assert_close(pa.grad, pb.grad, atol=2e-6, rtol=1e-4)
+
+
 def test_construct_time_samplings_line_up_with_the_wrapped_oracle():
     """PettingZooEnv(GraphEnv(...)) samples THREE episodes while being constructed (core.py:190, graph.py:118, [3P]
     tianshou PettingZooEnv.__init__ -> env.reset()); HipGraphVectorEnv(construct_like_reference=True) replays that

@@ -36,28 +36,33 @@ def timed(f, reps=30):
         f()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps * 1e3
-sample = (lambda: replay.sample_collective(32, 4, 0.99, L.gen)) if model == "dgn_r" else (lambda: replay.sample(32, 4, 0.99, L.gen))
+sample = lambda: replay.sample(32, 4, 0.99, L.gen)
 print(f"{model}: whole update {timed(L.step):.2f} ms")
 print(f"  replay sample      {timed(sample):.2f} ms")
 b = sample()
 with torch.no_grad():
     print(f"  target forward     {timed(lambda: policy.model_old.hip_forward(b['boot_obs'])):.2f} ms")
-obs = b["active_obs"] if model == "dgn_r" else b["obs"]
+if model == "dgn_r":            # the dense form: one graph per sampled experience, the head per (experience, node)
+    obs = L.sample_batch()["obs_matrix"]
+    body = net.torch_forward_all_agents
+    rows = L.row_form(L.sample_batch())["segment"].numel()
+    print(f"  (row form of this batch: {rows} sibling rows - what the per-sibling forward evaluated before round 3)")
+else:
+    obs, body = b["obs"], net.torch_forward
 def fwd():
     with torch.enable_grad():
-        return net.torch_forward(obs)
-print(f"  learn forward      {timed(fwd):.2f} ms  ({obs.shape[0]} rows)")
+        return body(obs)
+print(f"  learn forward      {timed(fwd):.2f} ms  ({obs.shape[0]} graphs)")
 def fb():
     policy.optim.zero_grad()
     with torch.enable_grad():
-        net.torch_forward(obs).pow(2).mean().backward()
+        body(obs).pow(2).mean().backward()
 print(f"  forward + backward {timed(fb):.2f} ms")
 print(f"  optimizer step     {timed(policy.optim.step):.2f} ms")
 with torch.no_grad():
     print(f"  4 collect rounds   {timed(lambda: loop.run(4)):.2f} ms")
-if model != "dgn_r":                            # the same update replayed from HIP graphs (DQNLearner.capture)
-    L.capture()
-    print(f"  whole update, replayed from HIP graphs {timed(L.step):.2f} ms")
+L.capture()                                     # the same update replayed from HIP graphs (DQNLearner / DGNLearner.capture)
+print(f"  whole update, replayed from HIP graphs {timed(L.step):.2f} ms")
 if "--kernels" in sys.argv:                     # per-kernel device time of 10 whole updates (torch profiler, kineto/roctracer)
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
