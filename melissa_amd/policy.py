@@ -189,9 +189,11 @@ class DGNPolicy(DQNPolicy):
             if self._clip_loss_grad:
                 loss = torch.nn.functional.huber_loss(batch_q.reshape(-1, 1), returns.reshape(-1, 1), reduction="mean")
             else:
-                weight = batch.get("weight", 1.0) if isinstance(batch, dict) else 1.0
-                weight = torch.as_tensor(weight, device=dev, dtype=td.dtype)
-                loss = (td.pow(2) * weight).mean()
+                weight = batch.get("weight") if isinstance(batch, dict) else None
+                if weight is None:                   # (no host -> device copy: this runs inside HIP-graph captures)
+                    loss = td.pow(2).mean()
+                else:
+                    loss = (td.pow(2) * torch.as_tensor(weight, device=dev, dtype=td.dtype)).mean()
             loss.backward()
         if isinstance(batch, dict) and "obs_matrix" not in batch:
             batch["weight"] = td.detach()            # prio-buffer hook, dgn.py:66

@@ -510,13 +510,16 @@ def test_training_loop_n50_first_update_matches_oracle_autograd(model):
     # (the bar of tests/test_gpu_grad.py, here at the training loop's own size: N = 50, 32 sampled experiences, DGN-R: all their
     # siblings)
     compared = 0
+    overall = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
     for k, g in ((k, v.grad) for k, v in sd.items()):
         if g is None:
             continue
         assert k in cap["grad"], k
         got = cap["grad"][k]
-        scale = float(g.abs().max())
-        assert float((got - g).abs().max()) <= 2e-4 * max(scale, 1e-6), (k, float((got - g).abs().max()), scale)
+        # (a tensor whose gradient is zero in exact arithmetic - TransformerConv's key bias: the softmax is invariant to it - holds
+        # rounding noise ~1e-10 on both sides: its bar is set by the gradient's overall scale, not by its own)
+        scale = max(float(g.abs().max()), 1e-3 * overall)
+        assert float((got - g).abs().max()) <= 2e-4 * scale, (k, float((got - g).abs().max()), scale)
         compared += g.numel()
     assert compared > 300000
 
