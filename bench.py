@@ -537,8 +537,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="round mode: sub-batches of the GPU's envs on separate HIP streams")
     ap.add_argument("--dtype", default="f32a", choices=["f32", "bf16", "f32s", "f32a"],
-                    help="f32 (default): the reference's arithmetic, logits within 1e-4.  bf16: BASELINE's 'bf16 feature "
-                         "path' (feature rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
+                    help="f32a (default): fp32 operands, accumulation and results, logits within 1e-4 of the oracle (measured 1e-7); "
+                         "each dense projection's arithmetic chosen per launch - the exact-fp32 matrix instruction, or for large "
+                         "launches exact bf16 x 3 operand splitting on the bf16 matrix pipe.  f32: every projection on the exact-fp32 "
+                         "instruction.  f32s: every projection by operand splitting.  bf16: BASELINE's 'bf16 feature path' (feature "
+                         "rows + projection weights bf16, fp32 accumulate / softmax / logits; ~5e-4 on logits)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the extra timed legs of the default run (bf16 feature path, BASELINE configs[1] and [3], "
@@ -671,7 +674,9 @@ def main():
                   else f"env-steps/s (agent-decisions/s) {args.model} {args.nodes}-node",
         "value": value, "unit": "agent-decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32a" else args.dtype, "data": "synthetic",
+        # f32a: fp32 operands / accumulation / results; the large launches multiply by exact bf16 x 3 operand splitting (see
+        # precision_mode) - named as such, not as plain "f32"
+        "dtype": "f32 (f32a)" if args.dtype == "f32a" else args.dtype, "data": "synthetic",
         "precision_mode": {"f32a": "MEL_PREC_F32_AUTO: fp32 operands, fp32 results, fp32 accumulation everywhere (logits within 1e-4 of the "
                                    "oracle, measured 1e-7); the arithmetic of each dense projection is chosen per launch by its size - the "
                                    "exact-fp32 matrix instruction, or for the large launches (here conv2 and the heads' first layer) exact "
