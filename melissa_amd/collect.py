@@ -355,6 +355,9 @@ class CollectStatsWithInfo:
     def __iter__(self):
         return iter(self.keys())
 
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
 
 def result_from_episode_log(stats: np.ndarray, meta: np.ndarray, total: int, steps: int, dt: float) -> CollectStatsWithInfo:
     """The collect result from the device's episode log (``HipGraphVectorEnv.read_episode_log``: one row per finished episode

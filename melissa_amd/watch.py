@@ -35,7 +35,10 @@ def watch(model="l_dgn", n_nodes=20, envs=1, episodes=10, load=None, graph_pool=
     per_env = -(-episodes // envs) + 2
     col = Collector(policy, venv, episodes_per_env=per_env, seed=seed, eps=0.0, chunk=4, use_graph=envs >= 64)
     out = col.collect(n_episode=episodes)
-    return {k: (v if isinstance(v, (int, float)) else None) for k, v in out.items() if not hasattr(v, "shape") and k != "episode_info"}
+    # the scalars of the collect result (counts, speed, mean return / length, mean of every logger_stats key) as a plain dict
+    keys = ["n/ep", "n/st", "collect_time", "collect_speed"] + (["rew", "len"] if out.returns_stat is not None else []) \
+        + list(out.info.stats)
+    return {k: out[k] for k in keys}
 
 
 def main():
