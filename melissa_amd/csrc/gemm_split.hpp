@@ -18,6 +18,8 @@
 // Same persistent tile loop, XCD-aware tile order and next-tile prefetch as gemm_f32_persistent_kernel.
 #pragma once
 #include "gemm_bf16.hpp"
+#include "gemm_ring.hpp"      // wait_lds_done
+#include <type_traits>
 
 namespace mel {
 
@@ -587,6 +589,354 @@ __global__ __launch_bounds__(256, 2) void gemm_split_big_kernel(GemmBatch batch)
 // 4-stage LDS rings), a 128 x 256 tile, three workgroups per CU - all bit-identical to it and none faster; they are parked with
 // their probes and the reason (the CU's vector-memory path delivers ~17 B / clk while its matrix pipe is saturated: this tile
 // needs 26) in tools/experiments/gemm_split_variants.hpp.
+
+// ---- 128 x 256 tiles fed from bf16 PLANES on both sides, specialised wavefronts (round 3) ---------------------------------------
+// What bounds the kernels above is the CU's vector-memory path while its matrix pipe is busy: ~17 B / clk (tools/overlap_probe.hip).
+// This kernel is built around that number:
+//   * 128 x 256 outputs per workgroup (eight MFMA waves of 64 x 64: two per SIMD, each other's cover for fragment-read latency):
+//     a 16-k step moves 12 KB of A planes + 24 KB of W planes for 2 x 768 cycles of matrix work per SIMD - 23 B / clk at the pipe's
+//     rate, against 26 for the 128 x 128 tile;
+//   * A arrives ALREADY SPLIT ([rows][K / 16][3][16] bf16 planes, the weights' format, written by the producer of the rows - the
+//     conv1 attention's store): no vector arithmetic is left in the GEMM, so nothing competes with the MFMA stream for issue slots;
+//   * four loader waves (one per SIMD) only move bytes: nine 16-byte loads per thread and step, three steps ahead of their LDS
+//     write (three register sets), one s_barrier per step; the MFMA waves read their fragments at the start of a step;
+//   * the MFMA waves write a finished tile out through a private 4 KB LDS transposition as 16-byte row stores, bias from LDS.
+// LDS: three 36 KB stages (96-byte rows, chunk c of row r in slot c ^ ((r >> 3) & 1): conflict-free fragment reads without a pad
+// chunk) + 8 x 4 KB + 6 KB of biases = 146 KB, one 768-thread workgroup per CU.  No row scale, no split-K (conv2's launches).
+constexpr int GEMP_BN = 256;
+constexpr int GEMP_STAGES = 3;
+constexpr int GEMP_RC = 6;                            // 16-byte chunks per LDS row
+constexpr int GEMP_BIAS_FLOATS = 1536;
+
+#ifdef MEL_PLANES_STAMPS
+__device__ long long planes_stamps[32];
+#define PST(i, expr) do { if (blockIdx.x == 0 && lane == 0) planes_stamps[i] += (expr); } while (0)
+#define PCLK() clock64()
+#else
+#define PST(i, expr) do { } while (0)
+#define PCLK() 0ll
+#endif
+template <int TAG = 0>
+__global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
+    constexpr int BM = 128, BN = GEMP_BN, RC = GEMP_RC;
+    constexpr int BUF = (BM + BN) * RC;               // 16-byte chunks per LDS stage
+    constexpr int XP = 8 * 256;                       // transposition buffers: 4 KB per MFMA wave
+    __shared__ u32x4 lds[GEMP_STAGES * BUF + XP + GEMP_BIAS_FLOATS / 4];
+    float* xpose = reinterpret_cast<float*>(lds + GEMP_STAGES * BUF);
+    float* bias_s = xpose + 4 * XP;
+
+    int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP], boff[GEMM_MAX_GROUP];
+    pre[0] = 0;
+    {
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
+            act[i] = 0, rows[i] = 0, boff[i] = o;
+            if (i < batch.count) {
+                const GemmArgs& q = batch.p[i];
+                rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
+                act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN);
+                for (int n = threadIdx.x; n < q.N; n += 768)
+                    bias_s[o + n] = (q.bias_hi && n >= q.split_n) ? q.bias_hi[n - q.split_n] : (q.bias ? q.bias[n] : 0.f);
+                o += q.N;
+            }
+            pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
+        }
+    }
+    const int total = pre[GEMM_MAX_GROUP];
+    const int stride = gridDim.x;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 0-7 MFMA waves, 8-11 loader waves
+
+    auto next_valid = [&](int t) {
+        for (; t < total; t += stride) {
+            int pi = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (t >= pre[k]) pi = k;
+            if (t - pre[pi] < act[pi]) return t;
+        }
+        return total;
+    };
+    struct Meta {
+        int m0, n0, M, pi, KT;
+    };
+    auto meta_of = [&](int t) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (t >= pre[k]) pi = k;
+        const GemmArgs& g = batch.p[pi];
+        const int nbn = g.N / BN;
+        int wg = t - pre[pi];
+        {
+            const int active = act[pi];
+            const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
+            wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+        }
+        Meta m;
+        m.pi = pi, m.M = rows[pi], m.KT = g.K / GEMS2_BK;
+        m.m0 = (wg / nbn) * BM, m.n0 = (wg % nbn) * BN;
+        return m;
+    };
+
+    const int t0 = next_valid(blockIdx.x);
+    __syncthreads();                          // the biases are staged
+    if (t0 >= total) return;
+    int nsteps = 0;
+    for (int tt = t0; tt < total; tt = next_valid(tt + stride)) nsteps += meta_of(tt).KT;
+    const int npad = ((nsteps + 2) / 3) * 3;  // the loaders run whole triples of steps: every wave executes npad + 1 barriers
+
+    if (wid < 8) {
+        // ---- MFMA waves ------------------------------------------------------------------------------------------------
+        const int wm = wid >> 2, wn = wid & 3;
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 3) & 1;                                           // (64 wm, 64 wn, 32 u are multiples of 16)
+        const int a_off = (wm * 64 + r) * RC + (h ^ sw);                       // + u * 32 rows, + plane * 2
+        const int w_off = (BM + wn * 64 + r) * RC + (h ^ sw);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        float* xp = xpose + wid * 1024;
+        auto write_out = [&](const Meta& m) {
+            const GemmArgs& g = batch.p[m.pi];
+            float* __restrict__ Y = g.Y;
+            const int relu = g.relu, ldy = g.ldy;
+            int bo = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (m.pi >= k) bo = boff[k];
+            const int rr = lane >> 3, c4 = (lane & 7) * 4;          // read side: row rr + 8 q, floats c4 .. c4 + 3
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = m.n0 + wn * 64 + j * 32 + c4;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + bo + n);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        xp[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][j][e];
+                        acc[i][j][e] = 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = rr + 8 * q, mrow = m.m0 + wm * 64 + i * 32 + row;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(xp + row * 32 + c4);
+                        f32x4 o = {a[0] + b4[0], a[1] + b4[1], a[2] + b4[2], a[3] + b4[3]};
+                        if (relu) o = f32x4{fmaxf(o[0], 0.f), fmaxf(o[1], 0.f), fmaxf(o[2], 0.f), fmaxf(o[3], 0.f)};
+                        if (mrow < m.M) *reinterpret_cast<f32x4*>(Y + (size_t)mrow * ldy + n) = o;
+                    }
+                }
+            }
+        };
+        int t = t0, kt = 0;
+        Meta cm = meta_of(t0);
+        bf16x8 a[2][3], b[2][3];
+        auto read_frags = [&](int g) {
+            const u32x4* cst = lds + (g % GEMP_STAGES) * BUF;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[u][p] = __builtin_bit_cast(bf16x8, cst[a_off + u * 32 * RC + 2 * p]);
+                    b[u][p] = __builtin_bit_cast(bf16x8, cst[w_off + u * 32 * RC + 2 * p]);
+                }
+        };
+        // per block smallest products first (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi), the four blocks interleaved
+        auto products = [&](auto K0, auto K1) {
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#ifdef MEL_PLANES_NOMFMA
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p2 = 0; p2 < 3; ++p2) asm volatile("" ::"v"(a[i][p2]), "v"(b[i][p2]));
+#else
+#pragma unroll
+            for (int k = decltype(K0)::value; k < decltype(K1)::value; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[k]], b[j][PB[k]], acc[i][j], 0, 0, 0);
+#endif
+        };
+        auto step_done = [&]() {
+            if (++kt == cm.KT) {              // the work item is complete
+                write_out(cm);
+                t = next_valid(t + stride), kt = 0;
+                if (t < total) cm = meta_of(t);
+                else cm.KT = 1 << 30;
+                wait_lds_done();
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I3 = std::integral_constant<int, 3>;
+        using I6 = std::integral_constant<int, 6>;
+        // The two MFMA waves of a SIMD run HALF A STEP APART: all eight reading their fragments right after the barrier would
+        // leave the matrix pipes idle for the ~800 cycles the LDS needs for 96 KB.  Waves 0-3 read stage g and run its 24
+        // MFMAs; waves 4-7 first run the second half of step g - 1 from their registers (covering the others' reads), then read
+        // stage g (covered by the others' MFMAs), then its first half.  Both have read stage g before B(g), as the loaders assume.
+#ifndef MEL_PLANES_INPHASE
+        const bool late = wid >= 4;
+#else
+        const bool late = false;
+#endif
+        __builtin_amdgcn_s_barrier();         // B(-1): stages 0 and 1 hold steps 0 and 1
+        if (!late) {
+            for (int g = 0; g < nsteps; ++g) {
+                const long long c0 = PCLK();
+                read_frags(g);
+#ifdef MEL_PLANES_STAMPS
+                wait_lds_done();
+#endif
+                const long long c1 = PCLK();
+                products(I0{}, I6{});
+                const long long c2 = PCLK();
+                step_done();
+                const long long c3 = PCLK();
+                __builtin_amdgcn_s_barrier(); // B(g): this wave has read stage g % 3 (the MFMAs consumed the fragments)
+                const long long c4 = PCLK();
+                if (wid == 0) { PST(0, c1 - c0); PST(1, c2 - c1); PST(2, c3 - c2); PST(3, c4 - c3); PST(4, 1); }
+            }
+        } else {
+            read_frags(0);
+            products(I0{}, I3{});
+            __builtin_amdgcn_s_barrier();     // B(0)
+            for (int g = 1; g < nsteps; ++g) {
+                const long long c0 = PCLK();
+                products(I3{}, I6{});
+                const long long c1 = PCLK();
+                step_done();
+                const long long c2 = PCLK();
+                read_frags(g);
+#ifdef MEL_PLANES_STAMPS
+                wait_lds_done();
+#endif
+                const long long c3 = PCLK();
+                products(I0{}, I3{});
+                const long long c4 = PCLK();
+                __builtin_amdgcn_s_barrier(); // B(g)
+                const long long c5 = PCLK();
+                if (wid == 4) { PST(8, c1 - c0); PST(9, c2 - c1); PST(10, c3 - c2); PST(11, c4 - c3); PST(12, c5 - c4); PST(13, 1); }
+            }
+            products(I3{}, I6{});
+            step_done();
+        }
+        for (int pad = npad - nsteps; pad > 0; --pad) __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ---- loader waves: nine 16-byte chunks per thread and step (A: 128 rows x 6, W: 256 rows x 6), nothing else ------------------
+    const int tid = threadIdx.x - 512;
+    // addresses as 32-bit byte offsets from two wave-uniform bases (the A planes and the W planes of the work item: scalar
+    // registers): nine 64-bit pointers per thread would cost the loaders their third register set
+    struct Ctx {
+        const char* a_base;
+        const char* w_base;
+        uint32_t off[9];                   // chunk i of this thread, K step 0 of the work item
+        int KT;
+    };
+    int dst[9];                            // LDS slot of chunk i (16-byte units inside a stage)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int ch = tid + i * 256, row = ch / 6, c = ch - row * 6;          // rows 0-127: A, 128-383: W
+        dst[i] = row * RC + (c ^ ((row >> 3) & 1));
+    }
+    auto setup = [&](Ctx& c, int t) {
+        const Meta m = meta_of(t);
+        const GemmArgs& g = batch.p[m.pi];
+        c.KT = m.KT;
+        c.a_base = reinterpret_cast<const char*>(g.A);
+        // a 256-column tile lies inside ONE weight matrix (split_n is a multiple of 256: the launcher checks)
+        c.w_base = (g.W_hi && m.n0 >= g.split_n)
+                       ? reinterpret_cast<const char*>(g.W_hi) + (size_t)(m.n0 - g.split_n) * 6 * g.K
+                       : reinterpret_cast<const char*>(g.W) + (size_t)m.n0 * 6 * g.K;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int ch = tid + i * 256, row = ch / 6, cc = ch - row * 6;
+            if (i < 3) {                       // A planes [rows][K / 16][3][16]; rows beyond M clamped, never predicated
+                const int gr = min(m.m0 + row, m.M - 1);
+                const int ar = g.arow ? g.arow[gr] : gr;
+                c.off[i] = (uint32_t)ar * (uint32_t)(g.lda * 2) + cc * 16;     // lda: bf16 elements per plane row (3 K)
+            } else {
+                c.off[i] = (uint32_t)(row - BM) * (uint32_t)(6 * g.K) + cc * 16;
+            }
+        }
+    };
+    struct Regs {
+        u32x4 v[9];
+    };
+    Ctx pf;
+    int pf_t = t0, pf_kt = 0;
+    bool pf_valid = true;
+    setup(pf, t0);
+    auto issue = [&](Regs& R) {               // loads of the next step of the stream, unconditional (see gemm_split_kernel)
+        const uint32_t ks = (uint32_t)pf_kt * 96u;
+#ifdef MEL_PLANES_NOLOAD
+        if (pf_t == t0 && pf_kt < 3)
+#endif
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            R.v[i] = *reinterpret_cast<const u32x4*>((i < 3 ? pf.a_base : pf.w_base) + (pf.off[i] + ks));
+        if (pf_valid && ++pf_kt == pf.KT) {
+            const int tn = next_valid(pf_t + stride);
+            if (tn < total) {
+                setup(pf, tn);
+                pf_t = tn, pf_kt = 0;
+            } else {
+                pf_valid = false, pf_kt = pf.KT - 1;
+            }
+        }
+    };
+    auto fill = [&](int s, const Regs& R) {
+        u32x4* stage = lds + (s % GEMP_STAGES) * BUF;
+#ifdef MEL_PLANES_NOFILL
+        if (s < 3)
+#endif
+#pragma unroll
+        for (int i = 0; i < 9; ++i) stage[dst[i]] = R.v[i];
+#ifdef MEL_PLANES_NOFILL
+        asm volatile("" ::"v"(R.v[0]), "v"(R.v[4]), "v"(R.v[8]));
+#endif
+    };
+    Regs R0, R1, R2;
+    issue(R0);                                 // step 0
+    issue(R1);                                 // step 1
+    issue(R2);                                 // step 2
+    fill(0, R0);
+    issue(R0);                                 // step 3
+    fill(1, R1);
+    issue(R1);                                 // step 4
+    wait_lds_done();
+    __builtin_amdgcn_s_barrier();              // B(-1)
+    int g = 0;
+    // during step g: Ra (step g + 2) -> stage (g + 2) % 3 (read at the start of step g - 1: free since B(g - 1)), Ra <- step g + 5
+    auto step = [&](Regs& Ra) {
+        const long long c0 = PCLK();
+#ifdef MEL_PLANES_STAMPS
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // the loads this fill consumes have landed
+#endif
+        const long long c1 = PCLK();
+        fill(g + 2, Ra);
+        issue(Ra);
+        const long long c2 = PCLK();
+        wait_lds_done();
+        const long long c3 = PCLK();
+        __builtin_amdgcn_s_barrier();          // B(g)
+        const long long c4 = PCLK();
+        if (wid == 8) { PST(16, c1 - c0); PST(17, c2 - c1); PST(18, c3 - c2); PST(19, c4 - c3); PST(20, 1); }
+        ++g;
+    };
+    for (int it = 0; it < npad / 3; ++it) {
+        step(R2);
+        step(R0);
+        step(R1);
+    }
+}
 
 // fp32 [rows, K] weight matrices -> [rows][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k), all matrices of the model in one launch
 struct SplitBatch {
