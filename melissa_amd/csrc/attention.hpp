@@ -30,6 +30,9 @@ struct AttArgs {
     int ldo;
     const float* out_scale; // optional [rows]: row r of `out` is stored times out_scale[r] (the decision-maker mask of
                             // l_dgn.py:128 - the x_2 snapshot in xcat is taken before it, l_dgn.py:127)
+    uint16_t* out_blocks;   // optional (fp32 path, 4+ features per lane): the rows go out ALREADY SPLIT into bf16 planes in the
+                            // layout gemm_planes_kernel reads its A operand in, [rows / 128][ldo / 16][128][3][16], instead of
+                            // fp32 rows to `out` - the same split4() the split GEMMs apply to fp32 rows on their way into LDS
     float* xcat;            // [R, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
     int ld_cat, hidden;
     const float* h0;        // encoder rows (packed by smask), [*, hidden]
@@ -251,6 +254,24 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
     return out;
 }
 
+// row r of a [rows, K] matrix as bf16 planes in 128-row blocks (gemm_planes_kernel's A operand): this lane's VPL consecutive
+// features k = lane * VPL ..; 16-k step k >> 4, the 96 bytes of (row, step) hold hi | mid | lo of its 16 values
+template <int VPL>
+__device__ __forceinline__ void store_row_blocks(uint16_t* base, int r, int K, int lane, const Vec<VPL>& o) {
+    static_assert(VPL % 4 == 0, "planes need whole groups of four features per lane");
+    uint16_t* row = base + (size_t)(r >> 7) * ((size_t)K * 384) + (size_t)(r & 127) * 48;
+#pragma unroll
+    for (int i = 0; i < VPL; i += 4) {
+        const int k = lane * VPL + i;
+        u32x2 hi, mid, lo;
+        split4(f32x4{o.v[i], o.v[i + 1], o.v[i + 2], o.v[i + 3]}, hi, mid, lo);
+        uint16_t* d = row + (size_t)(k >> 4) * (128 * 48) + (k & 15);
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + 16) = mid;
+        *reinterpret_cast<u32x2*>(d + 32) = lo;
+    }
+}
+
 template <int VPL>
 __device__ __forceinline__ Vec<VPL> load_vec_or_zero(const float* p, int lane) {
     Vec<VPL> r;
@@ -336,15 +357,17 @@ __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttA
         if constexpr (MODE == ATT_SINGLE) {
             store_row<VPL, BF>(a.xcat, (size_t)r * a.ld_cat + a.cat_off + lane * VPL, o);
         } else {
+            Vec<VPL> om = o;
             if (a.out_scale) {
                 const float dmv = a.out_scale[r];
-                Vec<VPL> om;
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) om.v[i] = o.v[i] * dmv;
-                store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, om);
-            } else {
-                store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, o);
             }
+            bool as_rows = true;
+            if constexpr (!BF && VPL % 4 == 0) {
+                if (a.out_blocks) store_row_blocks<VPL>(a.out_blocks, r, a.ldo, lane, om), as_rows = false;
+            }
+            if (as_rows) store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, om);
             if (d.cat_row >= 0) {
                 const size_t cat = (size_t)d.cat_row * a.ld_cat;
                 // x_2: the controlling agent's conv1 row BEFORE the decision-maker mask (l_dgn.py:127)

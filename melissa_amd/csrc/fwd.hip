@@ -2,6 +2,7 @@
 // field), fp32-MFMA row GEMMs (gemm_f32.hpp), GATv2 edge-softmax/aggregate, segmented pool, dueling
 // tail, DQN action selection.  Reference semantics: networks/common.py:6-64, l_dgn.py:92-151,
 // hl_dgn.py:82-119 and SURVEY.md Appendix A for the third-party operators.
+#include <cstdlib>
 #include "common.hpp"
 #include "gemm_f32.hpp"
 #include "gemm_bf16.hpp"
@@ -126,6 +127,9 @@ static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_
 
 // split path: a persistent 64 x 64 kernel for small launches, 128 x 128 tiles from MEL_SPLIT_BIG_FROM expected big tiles on
 // (both named per call site like the fp32 one)
+#ifndef MEL_PLANES_FROM
+#define MEL_PLANES_FROM 160          // expected 128 x 256 work items from which conv2 runs on gemm_planes_kernel (256 CUs, one each)
+#endif
 #ifndef MEL_SPLIT_BIG_FROM
 #define MEL_SPLIT_BIG_FROM 192
 #endif
@@ -182,6 +186,37 @@ static void gemm_launch_split(const GemmArgs* gs, int count, int mode, hipStream
         case 2: gemm_launch_split_t<2>(gs, count, mode, s); break;
         case 3: gemm_launch_split_t<3>(gs, count, mode, s); break;
         default: gemm_launch_split_t<0>(gs, count, mode, s); break;
+    }
+}
+
+// gemm_planes_kernel (gemm_split.hpp): A as [rows / 128][K / 16][128][3][16] bf16 planes, W / W_hi as [N / 256][K / 16][256][3][16]
+static bool planes_fit(const GemmArgs* gs, int count) {
+    long ncols = 0;
+    for (int i = 0; i < count; ++i) {
+        const GemmArgs& g = gs[i];
+        if (g.N % GEMP_BN || g.K % GEMS2_BK || g.K / GEMS2_BK < 4 || g.ldy % 4 || g.rscale || g.ksplit > 1) return false;
+        if (g.W_hi && g.split_n % GEMP_BN) return false;
+        if ((((size_t)g.M + 127) & ~(size_t)127) * (size_t)g.K * 6 >= ((size_t)1 << 32)) return false;      // 32-bit operand offsets
+        ncols += g.N;
+    }
+    return count >= 1 && count <= GEMM_MAX_GROUP && ncols <= GEMP_BIAS_FLOATS;
+}
+template <int TAG>
+static void gemm_launch_planes_t(const GemmArgs* gs, int count, hipStream_t s) {
+    GemmBatch batch{};
+    batch.count = count;
+    long items = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        items += ((long)((gs[i].M + 127) / 128) * (gs[i].N / GEMP_BN) + 7) & ~7L;
+    }
+    const long grid = items < 256 ? items : 256;          // one 768-thread workgroup (146 KB of LDS) per CU
+    MEL_LAUNCH((gemm_planes_kernel<TAG>), dim3((int)grid), dim3(768), 0, s, batch);
+}
+static void gemm_launch_planes(const GemmArgs* gs, int count, hipStream_t s, int tag) {
+    switch (tag) {
+        case 2: gemm_launch_planes_t<2>(gs, count, s); break;
+        default: gemm_launch_planes_t<0>(gs, count, s); break;
     }
 }
 
@@ -437,6 +472,8 @@ struct ProjWeights {
     const float* enc1;
     const float* c1l; const float* c1r; const float* c1v;
     const float* c2l; const float* c2r; const float* c2v;
+    // conv2's matrices once more in 256-row blocks (planes only): what gemm_planes_kernel reads; null when the shape does not fit
+    const float* c2l_blk; const float* c2r_blk; const float* c2v_blk;
     const float* q[MEL_MAX_HEAD_LAYERS];
     const float* v[MEL_MAX_HEAD_LAYERS];
     const ProjWeights* alt;        // MEL_PREC_F32_AUTO: the same matrices as bf16 planes (the slots above hold the fp32 ones)
@@ -464,6 +501,25 @@ static size_t projection_elems(const mel_weights* w) {
     ProjWeights pw{};
     size_t total = 0;
     for_each_projection(w, pw, [&](const mel_linear& l, const float**) { total += (lin_elems(l) + 7) & ~(size_t)7; });
+    return total;
+}
+
+// conv2's projection weights in gemm_planes_kernel's block layout, kept beside the row-major planes (small launches stay on
+// the kernels that read those): f(const mel_linear&, const float* ProjWeights::* slot)
+static bool conv2_blocks_fit(const mel_weights* w) {
+    return w->model != MEL_MODEL_HLDGN && w->conv2.lin_l.weight && w->conv2.lin_l.out_dim % GEMP_BN == 0 &&
+           w->conv2.lin_l.in_dim % GEMS2_BK == 0 && w->conv2.lin_l.in_dim / GEMS2_BK >= 4;
+}
+template <class F>
+static void for_each_conv2_block(const mel_weights* w, ProjWeights& pw, F f) {
+    if (!conv2_blocks_fit(w)) return;
+    f(w->conv2.lin_l, &pw.c2l_blk), f(w->conv2.lin_r, &pw.c2r_blk);
+    if (w->conv2.kind == MEL_CONV_TRANSFORMER) f(w->conv2.lin_v, &pw.c2v_blk);
+}
+static size_t plane_elems(const mel_weights* w) {       // bf16 elements of all planes of a model (row-major + conv2's blocks)
+    ProjWeights pw{};
+    size_t total = 3 * projection_elems(w);
+    for_each_conv2_block(w, pw, [&](const mel_linear& l, const float**) { total += 3 * ((lin_elems(l) + 7) & ~(size_t)7); });
     return total;
 }
 
@@ -510,7 +566,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         const int srcw = (w->conv1.kind == MEL_CONV_TRANSFORMER) ? 2 * hc : hc;     // key | value side by side
         L.xl1 = c.take<float>(rows2 * srcw);
         L.xr1 = c.take<float>(rows1 * hc);
-        L.h1 = c.take<float>((size_t)d.u1_cap * hc);
+        // (fp32 rows, or - conv2 on gemm_planes_kernel - three bf16 planes in 128-row blocks: 6 bytes per value)
+        L.h1 = c.take<float>(((((size_t)d.u1_cap + 127) & ~(size_t)127) * hc * 3 + 1) / 2);
         L.xl2 = c.take<float>((size_t)d.u1_cap * srcw);
         L.xr2 = c.take<float>(R * hc);
     } else {
@@ -526,8 +583,7 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
     L.hq[1] = c.take<float>(R * (hw > 0 ? hw : 1));
     L.hpart = c.take<float>(hw > 0 ? (size_t)HEAD_KSPLIT_MAX * R * hw : 8);
     L.minmax = c.take<float>(64);
-    L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w)
-                 : has_planes(w) ? 3 * projection_elems(w) : 0;
+    L.wb_elems = (w->precision == MEL_PREC_BF16) ? projection_elems(w) : has_planes(w) ? plane_elems(w) : 0;
     if (w->prepared) L.wb_elems = 0;             // the caller holds the converted weights (mel_prepare_weights)
     L.wb = c.take<uint16_t>(L.wb_elems ? L.wb_elems : 8);
     L.bytes = c.off;
@@ -619,11 +675,23 @@ static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjW
             const size_t cnt = lin_elems(l);
             if (b.n >= CVT_MAX_SEG || cnt % 8 != 0 || l.in_dim % 32 != 0 || !l.weight) { bad = true; return; }
             b.src[b.n] = l.weight, b.dst[b.n] = dst + off, b.count[b.n] = (int)cnt, b.K[b.n] = l.in_dim, b.start[b.n] = blocks;
+            b.rb[b.n] = 0;
             *slot = reinterpret_cast<const float*>(dst + off);
             blocks += (int)((cnt / 4 + 255) / 256);
             off += 3 * ((cnt + 7) & ~(size_t)7);
             ++b.n;
         });
+        if (!bad)
+            for_each_conv2_block(w, planes, [&](const mel_linear& l, const float** slot) {
+                const size_t cnt = lin_elems(l);
+                if (b.n >= CVT_MAX_SEG || !l.weight || l.out_dim % GEMP_BN) return;       // (the slot stays null: no planes kernel)
+                b.src[b.n] = l.weight, b.dst[b.n] = dst + off, b.count[b.n] = (int)cnt, b.K[b.n] = l.in_dim, b.start[b.n] = blocks;
+                b.rb[b.n] = GEMP_BN;
+                *slot = reinterpret_cast<const float*>(dst + off);
+                blocks += (int)((cnt / 4 + 255) / 256);
+                off += 3 * ((cnt + 7) & ~(size_t)7);
+                ++b.n;
+            });
         if (bad && both) {                       // AUTO: shapes the split kernels cannot take simply stay on the exact-fp32 path
             alt = ProjWeights{}, pw.alt = nullptr;
             return MEL_OK;
@@ -658,7 +726,7 @@ static mel_status resolve_projections(const mel_weights* w, uint16_t* dst, ProjW
     return check_launch("weights -> bf16");
 }
 static size_t prepared_elems(const mel_weights* w) {
-    return w->precision == MEL_PREC_BF16 ? projection_elems(w) : has_planes(w) ? 3 * projection_elems(w) : 0;
+    return w->precision == MEL_PREC_BF16 ? projection_elems(w) : has_planes(w) ? plane_elems(w) : 0;
 }
 static mel_status resolve_projections(const mel_weights* w, const FwdLayout& L, ProjWeights& pw, ProjWeights& alt, hipStream_t s) {
     if (w->prepared && w->precision != MEL_PREC_F32)
@@ -866,6 +934,26 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const int T = n * FEATURE_TUPLES_PER_DEGREE;
     const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && hint1 + hint2 >= 2L * T;
     bool fused_enc = false;
+    // conv2's projections on gemm_planes_kernel (both operands as bf16 planes in blocks, gemm_split.hpp): decided HERE, because
+    // the conv1 attention then stores h1 already split, in that kernel's A layout.  Large launches of the fp32-accurate
+    // paths only: a launch of fewer work items than CUs stays on the 128 x 128 / 64 x 64 kernels.
+    const ProjWeights* planes = sp ? &pw : pw.alt;
+    GemmArgs c2[2];
+    {
+        c2[0].A = L.h1, c2[0].lda = hc, c2[0].bias = w->conv2.lin_l.bias, c2[0].split = 1;
+        c2[0].Y = L.xl2, c2[0].ldy = srcw, c2[0].M = U1, c2[0].M_dev = n1, c2[0].N = srcw, c2[0].K = hc;
+        if (tconv) c2[0].bias_hi = w->conv2.lin_v.bias, c2[0].split_n = hc;
+        c2[1].A = L.h1, c2[1].lda = hc, c2[1].arow = L.plan.arow_g, c2[1].bias = w->conv2.lin_r.bias, c2[1].split = 1;
+        c2[1].Y = L.xr2, c2[1].ldy = hc, c2[1].M = R, c2[1].M_dev = nL, c2[1].N = hc, c2[1].K = hc;
+        if (planes) {
+            c2[0].W = planes->c2l_blk, c2[1].W = planes->c2r_blk;
+            if (tconv) c2[0].W_hi = planes->c2v_blk;
+        }
+    }
+    const long c2_items = ((hint1 + 127) / 128) * (srcw / GEMP_BN) + ((hintL + 127) / 128) * (hc / GEMP_BN);
+    static const bool planes_off = getenv("MEL_NO_PLANES_GEMM") != nullptr;         // A/B switch for bench and tests
+    const bool conv2_planes = !planes_off && !bf && planes && c2[0].W && c2[1].W && (!tconv || c2[0].W_hi) && hc % 4 == 0 &&
+                              hc / 64 >= 4 && c2_items >= MEL_PLANES_FROM && planes_fit(c2, 2);
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -944,6 +1032,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = ft.h0;
+        if (conv2_planes) a.out_blocks = reinterpret_cast<uint16_t*>(L.h1);
         a.out_scale = L.plan.dm1;       // the decision-maker mask (l_dgn.py:128) is applied as h1 is stored; x_2 is taken before it
         a.fid = table ? L.plan.fid : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
@@ -963,7 +1052,10 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         g[1].Y = L.xr2, g[1].ldy = hc, g[1].M = R, g[1].M_dev = nL, g[1].N = hc, g[1].K = hc;
         const long hints[2] = {hint1, hintL};
         StageScope t(MEL_STAGE_CONV2_LIN, s);
-        if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv2.lin_l + lin_r", 2)) return st;
+        if (conv2_planes) {
+            gemm_launch_planes(c2, 2, s, 2);
+            if (mel_status st = check_launch("conv2.lin_l + lin_r (planes)")) return st;
+        } else if (mel_status st = launch_gemm_group(g, hints, 2, s, "conv2.lin_l + lin_r", 2)) return st;
     }
     {   // conv2 attention, one target per agent row -> x_3
         AttArgs a{};
@@ -1272,11 +1364,32 @@ mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const
     if (!A || !W || !Y || !scratch || M <= 0 || M > (1ll << 30) || lda < K || ldy < N || N < 64 || K < 128)
         return fail(MEL_ERR_INVALID_ARG, "bad split-precision gemm arguments");
     const int64_t plane_bytes = ((int64_t)6 * N * K + 255) & ~255ll;
-    const int64_t need = plane_bytes + (ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0);
+    const bool blocks = tile % 100 == 3;                // gemm_planes_kernel: A goes through bf16 plane blocks in scratch as well
+    const int64_t a_bytes = blocks ? ((M + 127) & ~127ll) * K * 6 : 0;
+    const int64_t need = plane_bytes + a_bytes + (ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0);
     if (K % 32 || N % 64 || scratch_bytes < need)
         return fail(MEL_ERR_UNSUPPORTED, "split-precision gemm: K %% 32 == 0, N %% 64 == 0, scratch >= %lld bytes", (long long)need);
     clear_stale_error();
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (blocks) {
+        GemmArgs g;
+        g.A = reinterpret_cast<const float*>(static_cast<char*>(scratch) + plane_bytes), g.lda = K;
+        g.W = static_cast<const float*>(scratch), g.bias = bias, g.Y = Y, g.ldy = ldy, g.M = (int)M, g.N = N, g.K = K, g.relu = relu, g.split = 1;
+        if (ksplit > 1 || lda != K || M * K >= (1ll << 31) || !planes_fit(&g, 1))
+            return fail(MEL_ERR_UNSUPPORTED, "split-precision gemm, 128 x 256 planes kernel: N %% 256 == 0, N <= %d, K / 16 >= 4, lda == K, "
+                                             "ldy %% 4 == 0, no split-K", GEMP_BIAS_FLOATS);
+        SplitBatch b{};
+        b.n = 2, b.start[0] = 0;
+        b.src[0] = W, b.dst[0] = static_cast<uint16_t*>(scratch), b.count[0] = N * K, b.K[0] = K, b.rb[0] = GEMP_BN;
+        b.start[1] = (int)(((int64_t)N * K / 4 + 255) / 256);
+        b.src[1] = A, b.dst[1] = reinterpret_cast<uint16_t*>(static_cast<char*>(scratch) + plane_bytes), b.count[1] = (int)(M * K), b.K[1] = K;
+        b.rb[1] = 128;
+        b.start[2] = b.start[1] + (int)((M * K / 4 + 255) / 256);
+        MEL_LAUNCH(split_weights_kernel, dim3(b.start[2]), dim3(256), 0, s, b);
+        if (mel_status st = check_launch("operands -> bf16 plane blocks")) return st;
+        gemm_launch_planes(&g, 1, s, 0);
+        return check_launch("mel_gemm_f32_split (planes)");
+    }
     SplitBatch b{};
     b.n = 1, b.src[0] = W, b.dst[0] = static_cast<uint16_t*>(scratch), b.count[0] = N * K, b.K[0] = K, b.start[0] = 0;
     b.start[1] = (int)(((int64_t)N * K / 4 + 255) / 256);

@@ -24,6 +24,7 @@ namespace mel {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // round-to-nearest-even pair conversion (v_cvt_pk_bf16_f32); lo lands in bits [0,16)
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmBatch ba
 // fp32 -> bf16 copies of the weight matrices the bf16 GEMMs read, one launch for all of them (the library keeps
 // no state between calls: the copies live in the caller's workspace and are refreshed by every forward, ~1 M
 // elements, so optimizer steps and load_state_dict are seen immediately, as on the fp32 path)
-constexpr int CVT_MAX_SEG = 16;
+constexpr int CVT_MAX_SEG = 20;
 struct CvtBatch {
     const float* src[CVT_MAX_SEG];
     uint16_t* dst[CVT_MAX_SEG];

@@ -590,19 +590,24 @@ __global__ __launch_bounds__(256, 2) void gemm_split_big_kernel(GemmBatch batch)
 // their probes and the reason (the CU's vector-memory path delivers ~17 B / clk while its matrix pipe is saturated: this tile
 // needs 26) in tools/experiments/gemm_split_variants.hpp.
 
-// ---- 128 x 256 tiles fed from bf16 PLANES on both sides, specialised wavefronts (round 3) ---------------------------------------
-// What bounds the kernels above is the CU's vector-memory path while its matrix pipe is busy: ~17 B / clk (tools/overlap_probe.hip).
-// This kernel is built around that number:
-//   * 128 x 256 outputs per workgroup (eight MFMA waves of 64 x 64: two per SIMD, each other's cover for fragment-read latency):
-//     a 16-k step moves 12 KB of A planes + 24 KB of W planes for 2 x 768 cycles of matrix work per SIMD - 23 B / clk at the pipe's
-//     rate, against 26 for the 128 x 128 tile;
-//   * A arrives ALREADY SPLIT ([rows][K / 16][3][16] bf16 planes, the weights' format, written by the producer of the rows - the
-//     conv1 attention's store): no vector arithmetic is left in the GEMM, so nothing competes with the MFMA stream for issue slots;
-//   * four loader waves (one per SIMD) only move bytes: nine 16-byte loads per thread and step, three steps ahead of their LDS
-//     write (three register sets), one s_barrier per step; the MFMA waves read their fragments at the start of a step;
+// ---- 128 x 256 tiles fed from bf16 PLANES on both sides, specialised wavefronts (round 3) -------------------------------------
+// What bounded the kernels above, found one layer at a time (tools/planes_probe.hip, profiles/r03k_*):
+//   * a CU's vector-memory path delivers ~17 B / clk of 64- / 96-byte row pieces while its matrix pipe is busy
+//     (tools/overlap_probe.hip), and a 128 x 128 tile needs 26: so 128 x 256 outputs per workgroup (eight MFMA waves of 64 x 64,
+//     two per SIMD), and BOTH operands stored the way a K step reads them - A as [rows / 128][K / 16][128][3][16] bf16 planes
+//     (written by the producer of the rows, the conv1 attention's store), W as [N / 256][K / 16][256][3][16] (mel_prepare_weights):
+//     the 12 KB + 24 KB of a step are two contiguous runs, every load instruction of a wave one whole KB;
+//   * A arrives ALREADY SPLIT: no vector arithmetic is left in the GEMM, nothing competes with the MFMA stream for issue slots;
+//     four loader waves (one per SIMD) only move bytes - nine 16-byte loads per thread and step, three steps ahead of their LDS
+//     write (three register sets);
+//   * all eight MFMA waves reading their 96 KB of fragments right behind the step's barrier left the matrix pipes idle for a
+//     third of the step: they now refresh their fragments plane by plane WHILE the step's MFMAs run (below) - no second
+//     register set, nothing to wait for behind the barrier.  (Replacing the barrier by LDS counters between the two roles,
+//     with s_setprio keeping the two MFMA waves of a SIMD level, came out the same: with loads, LDS writes and fragment reads
+//     hidden, 48 MFMAs per SIMD and step take 1 800 cycles at the clock the chip holds under this load.)
 //   * the MFMA waves write a finished tile out through a private 4 KB LDS transposition as 16-byte row stores, bias from LDS.
-// LDS: three 36 KB stages (96-byte rows, chunk c of row r in slot c ^ ((r >> 3) & 1): conflict-free fragment reads without a pad
-// chunk) + 8 x 4 KB + 6 KB of biases = 146 KB, one 768-thread workgroup per CU.  No row scale, no split-K (conv2's launches).
+// LDS: 3 x 36 KB stages (96-byte rows, chunk c of row r in slot c ^ ((r >> 3) & 1): conflict-free fragment reads without a pad
+// chunk) + 8 x 4 KB + 6 KB of biases = 146 KB, one 768-thread workgroup per CU.  No row scale, no split-K.
 constexpr int GEMP_BN = 256;
 constexpr int GEMP_STAGES = 3;
 constexpr int GEMP_RC = 6;                            // 16-byte chunks per LDS row
@@ -610,12 +615,9 @@ constexpr int GEMP_BIAS_FLOATS = 1536;
 
 #ifdef MEL_PLANES_STAMPS
 __device__ long long planes_stamps[32];
-#define PST(i, expr) do { if (blockIdx.x == 0 && lane == 0) planes_stamps[i] += (expr); } while (0)
-#define PCLK() clock64()
-#else
-#define PST(i, expr) do { } while (0)
-#define PCLK() 0ll
+__device__ long long planes_block[512][2];
 #endif
+
 template <int TAG = 0>
 __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
     constexpr int BM = 128, BN = GEMP_BN, RC = GEMP_RC;
@@ -683,9 +685,11 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
     const int t0 = next_valid(blockIdx.x);
     __syncthreads();                          // the biases are staged
     if (t0 >= total) return;
-    int nsteps = 0;
+#ifdef MEL_PLANES_STAMPS
+    const long long k_c0 = clock64(), k_w0 = wall_clock64();
+#endif
+    int nsteps = 0;                           // K steps of this workgroup's whole stream of work items
     for (int tt = t0; tt < total; tt = next_valid(tt + stride)) nsteps += meta_of(tt).KT;
-    const int npad = ((nsteps + 2) / 3) * 3;  // the loaders run whole triples of steps: every wave executes npad + 1 barriers
 
     if (wid < 8) {
         // ---- MFMA waves ------------------------------------------------------------------------------------------------
@@ -736,103 +740,81 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
         int t = t0, kt = 0;
         Meta cm = meta_of(t0);
         bf16x8 a[2][3], b[2][3];
-        auto read_frags = [&](int g) {
-            const u32x4* cst = lds + (g % GEMP_STAGES) * BUF;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[u][p] = __builtin_bit_cast(bf16x8, cst[a_off + u * 32 * RC + 2 * p]);
-                    b[u][p] = __builtin_bit_cast(bf16x8, cst[w_off + u * 32 * RC + 2 * p]);
-                }
-        };
-        // per block smallest products first (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi), the four blocks interleaved
-        auto products = [&](auto K0, auto K1) {
-            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
-#ifdef MEL_PLANES_NOMFMA
+        // A step's 24 MFMAs, per block smallest products first (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi), the four blocks
+        // interleaved.  The fragments of step g + 1 are read WHILE step g's MFMAs run, each plane into the registers of the
+        // plane it replaces as soon as that one has had its last use (b.lo after group 1, a.lo after 2, b.mid after 3, a.mid
+        // after 4, the hi planes after 5).
+        auto mf = [&](auto PAc, auto PBc) {
+            constexpr int pa = decltype(PAc)::value, pb = decltype(PBc)::value;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int p2 = 0; p2 < 3; ++p2) asm volatile("" ::"v"(a[i][p2]), "v"(b[i][p2]));
-#else
-#pragma unroll
-            for (int k = decltype(K0)::value; k < decltype(K1)::value; ++k)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[k]], b[j][PB[k]], acc[i][j], 0, 0, 0);
-#endif
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][pa], b[j][pb], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         };
-        auto step_done = [&]() {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using P2 = std::integral_constant<int, 2>;
+        __builtin_amdgcn_s_barrier();         // B(-1): stages 0 and 1 hold steps 0 and 1
+#ifdef MEL_PLANES_STAMPS
+        if (wid == 0 && lane == 0) planes_stamps[26] = clock64() - k_c0;
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[u][pl] = __builtin_bit_cast(bf16x8, lds[a_off + u * 32 * RC + 2 * pl]);
+                b[u][pl] = __builtin_bit_cast(bf16x8, lds[w_off + u * 32 * RC + 2 * pl]);
+            }
+        // Interval g (between B(g - 1) and B(g)): the MFMAs of step g out of registers, the fragments of step g + 1 out of
+        // stage (g + 1) % 3 (filled in interval g - 1); the loaders fill stage (g + 2) % 3, last read in interval g - 2.
+        for (int g = 0; g < nsteps; ++g) {
+            const u32x4* nx = lds + ((g + 1) % GEMP_STAGES) * BUF;
+            auto ra = [&](auto Pc) {
+                constexpr int pl = decltype(Pc)::value;
+                a[0][pl] = __builtin_bit_cast(bf16x8, nx[a_off + 2 * pl]);
+                a[1][pl] = __builtin_bit_cast(bf16x8, nx[a_off + 32 * RC + 2 * pl]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto rb = [&](auto Pc) {
+                constexpr int pl = decltype(Pc)::value;
+                b[0][pl] = __builtin_bit_cast(bf16x8, nx[w_off + 2 * pl]);
+                b[1][pl] = __builtin_bit_cast(bf16x8, nx[w_off + 32 * RC + 2 * pl]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            mf(P1{}, P1{});
+            mf(P0{}, P2{});
+            rb(P2{});
+            mf(P2{}, P0{});
+            ra(P2{});
+            mf(P0{}, P1{});
+            rb(P1{});
+            mf(P1{}, P0{});
+            ra(P1{});
+            mf(P0{}, P0{});
+            ra(P0{});
+            rb(P0{});
             if (++kt == cm.KT) {              // the work item is complete
                 write_out(cm);
                 t = next_valid(t + stride), kt = 0;
                 if (t < total) cm = meta_of(t);
                 else cm.KT = 1 << 30;
-                wait_lds_done();
             }
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I3 = std::integral_constant<int, 3>;
-        using I6 = std::integral_constant<int, 6>;
-        // The two MFMA waves of a SIMD run HALF A STEP APART: all eight reading their fragments right after the barrier would
-        // leave the matrix pipes idle for the ~800 cycles the LDS needs for 96 KB.  Waves 0-3 read stage g and run its 24
-        // MFMAs; waves 4-7 first run the second half of step g - 1 from their registers (covering the others' reads), then read
-        // stage g (covered by the others' MFMAs), then its first half.  Both have read stage g before B(g), as the loaders assume.
-#ifndef MEL_PLANES_INPHASE
-        const bool late = wid >= 4;
-#else
-        const bool late = false;
-#endif
-        __builtin_amdgcn_s_barrier();         // B(-1): stages 0 and 1 hold steps 0 and 1
-        if (!late) {
-            for (int g = 0; g < nsteps; ++g) {
-                const long long c0 = PCLK();
-                read_frags(g);
-#ifdef MEL_PLANES_STAMPS
-                wait_lds_done();
-#endif
-                const long long c1 = PCLK();
-                products(I0{}, I6{});
-                const long long c2 = PCLK();
-                step_done();
-                const long long c3 = PCLK();
-                __builtin_amdgcn_s_barrier(); // B(g): this wave has read stage g % 3 (the MFMAs consumed the fragments)
-                const long long c4 = PCLK();
-                if (wid == 0) { PST(0, c1 - c0); PST(1, c2 - c1); PST(2, c3 - c2); PST(3, c4 - c3); PST(4, 1); }
-            }
-        } else {
-            read_frags(0);
-            products(I0{}, I3{});
-            __builtin_amdgcn_s_barrier();     // B(0)
-            for (int g = 1; g < nsteps; ++g) {
-                const long long c0 = PCLK();
-                products(I3{}, I6{});
-                const long long c1 = PCLK();
-                step_done();
-                const long long c2 = PCLK();
-                read_frags(g);
-#ifdef MEL_PLANES_STAMPS
-                wait_lds_done();
-#endif
-                const long long c3 = PCLK();
-                products(I0{}, I3{});
-                const long long c4 = PCLK();
-                __builtin_amdgcn_s_barrier(); // B(g)
-                const long long c5 = PCLK();
-                if (wid == 4) { PST(8, c1 - c0); PST(9, c2 - c1); PST(10, c3 - c2); PST(11, c4 - c3); PST(12, c5 - c4); PST(13, 1); }
-            }
-            products(I3{}, I6{});
-            step_done();
+            __builtin_amdgcn_s_barrier();     // B(g)
         }
-        for (int pad = npad - nsteps; pad > 0; --pad) __builtin_amdgcn_s_barrier();
+#ifdef MEL_PLANES_STAMPS
+        if (wid == 0 && lane == 0) {
+            planes_stamps[24] = clock64() - k_c0, planes_stamps[25] = wall_clock64() - k_w0;
+            planes_block[blockIdx.x][0] = k_w0, planes_block[blockIdx.x][1] = wall_clock64();
+        }
+#endif
         return;
     }
 
     // ---- loader waves: nine 16-byte chunks per thread and step (A: 128 rows x 6, W: 256 rows x 6), nothing else ------------------
     const int tid = threadIdx.x - 512;
-    // addresses as 32-bit byte offsets from two wave-uniform bases (the A planes and the W planes of the work item: scalar
+    // addresses as 32-bit byte offsets from two wave-uniform bases (the A blocks and the W blocks of the work item: scalar
     // registers): nine 64-bit pointers per thread would cost the loaders their third register set
     struct Ctx {
         const char* a_base;
@@ -858,12 +840,12 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int ch = tid + i * 256, row = ch / 6, cc = ch - row * 6;
-            if (i < 3) {                       // A planes [rows][K / 16][3][16]; rows beyond M clamped, never predicated
+            if (i < 3) {                       // A blocks [rows / 128][K / 16][128][3][16]; rows beyond M clamped, never predicated
                 const int gr = min(m.m0 + row, m.M - 1);
                 const int ar = g.arow ? g.arow[gr] : gr;
-                c.off[i] = (uint32_t)ar * (uint32_t)(g.lda * 2) + cc * 16;     // lda: bf16 elements per plane row (3 K)
-            } else {
-                c.off[i] = (uint32_t)(row - BM) * (uint32_t)(6 * g.K) + cc * 16;
+                c.off[i] = (uint32_t)(ar >> 7) * (uint32_t)(g.K * 768) + (uint32_t)(ar & 127) * 96u + cc * 16;
+            } else {                           // W blocks [N / 256][K / 16][256][3][16]: a step's 24 KB are contiguous
+                c.off[i] = (uint32_t)(row - BM) * 96u + cc * 16;
             }
         }
     };
@@ -875,13 +857,10 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
     bool pf_valid = true;
     setup(pf, t0);
     auto issue = [&](Regs& R) {               // loads of the next step of the stream, unconditional (see gemm_split_kernel)
-        const uint32_t ks = (uint32_t)pf_kt * 96u;
-#ifdef MEL_PLANES_NOLOAD
-        if (pf_t == t0 && pf_kt < 3)
-#endif
+        const uint32_t ks = (uint32_t)pf_kt * 12288u;          // a K step: 12 KB of an A block, 24 KB of a W block
 #pragma unroll
         for (int i = 0; i < 9; ++i)
-            R.v[i] = *reinterpret_cast<const u32x4*>((i < 3 ? pf.a_base : pf.w_base) + (pf.off[i] + ks));
+            R.v[i] = *reinterpret_cast<const u32x4*>((i < 3 ? pf.a_base : pf.w_base) + (pf.off[i] + (i < 3 ? ks : 2 * ks)));
         if (pf_valid && ++pf_kt == pf.KT) {
             const int tn = next_valid(pf_t + stride);
             if (tn < total) {
@@ -892,16 +871,10 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
             }
         }
     };
-    auto fill = [&](int s, const Regs& R) {
-        u32x4* stage = lds + (s % GEMP_STAGES) * BUF;
-#ifdef MEL_PLANES_NOFILL
-        if (s < 3)
-#endif
+    auto fill = [&](int st, const Regs& R) {
+        u32x4* stage = lds + (st % GEMP_STAGES) * BUF;
 #pragma unroll
         for (int i = 0; i < 9; ++i) stage[dst[i]] = R.v[i];
-#ifdef MEL_PLANES_NOFILL
-        asm volatile("" ::"v"(R.v[0]), "v"(R.v[4]), "v"(R.v[8]));
-#endif
     };
     Regs R0, R1, R2;
     issue(R0);                                 // step 0
@@ -913,38 +886,45 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
     issue(R1);                                 // step 4
     wait_lds_done();
     __builtin_amdgcn_s_barrier();              // B(-1)
-    int g = 0;
-    // during step g: Ra (step g + 2) -> stage (g + 2) % 3 (read at the start of step g - 1: free since B(g - 1)), Ra <- step g + 5
-    auto step = [&](Regs& Ra) {
-        const long long c0 = PCLK();
-#ifdef MEL_PLANES_STAMPS
-        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // the loads this fill consumes have landed
-#endif
-        const long long c1 = PCLK();
+    // interval g: Ra (step g + 2) -> stage (g + 2) % 3, Ra <- step g + 5; every wave of the workgroup runs nsteps + 1 barriers
+    auto step = [&](int g, Regs& Ra) {
         fill(g + 2, Ra);
         issue(Ra);
-        const long long c2 = PCLK();
         wait_lds_done();
-        const long long c3 = PCLK();
         __builtin_amdgcn_s_barrier();          // B(g)
-        const long long c4 = PCLK();
-        if (wid == 8) { PST(16, c1 - c0); PST(17, c2 - c1); PST(18, c3 - c2); PST(19, c4 - c3); PST(20, 1); }
-        ++g;
     };
-    for (int it = 0; it < npad / 3; ++it) {
-        step(R2);
-        step(R0);
-        step(R1);
+    for (int g = 0; g < nsteps; g += 3) {
+        step(g, R2);
+        if (g + 1 < nsteps) step(g + 1, R0);
+        if (g + 2 < nsteps) step(g + 2, R1);
     }
 }
 
-// fp32 [rows, K] weight matrices -> [rows][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k), all matrices of the model in one launch
+// [rows][K / 16][3][16] planes -> blocks of RB rows, [rows / RB][K / 16][RB][3][16]: what a 16-k step of gemm_planes_kernel reads
+// from one operand (12 KB of 128 A rows, 24 KB of 256 W rows) is one contiguous run.  Rows beyond `rows` are written as zeros.
+__global__ __launch_bounds__(256) void planes_to_blocks_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int rows, int K, int RB) {
+    const size_t ch = (size_t)blockIdx.x * 256 + threadIdx.x;              // 16-byte chunk of the destination
+    const int KT = K / 16;
+    const size_t per_block = (size_t)KT * RB * 6;
+    const size_t total = (size_t)((rows + RB - 1) / RB) * per_block;
+    if (ch >= total) return;
+    const int blk = (int)(ch / per_block);
+    const int rem = (int)(ch - (size_t)blk * per_block);
+    const int kt = rem / (RB * 6), r = (rem - kt * RB * 6) / 6, c = rem % 6;
+    const int row = blk * RB + r;
+    dst[ch] = row < rows ? src[((size_t)row * KT + kt) * 6 + c] : u32x4{0, 0, 0, 0};
+}
+
+// fp32 [rows, K] weight matrices -> [rows][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k), all matrices of the model in one launch.
+// rb[s] > 0: segment s is written in blocks of rb rows instead, [rows / rb][K / 16][rb][3][16] (gemm_planes_kernel's operands:
+// rb = 256 for W, 128 for A; rows a multiple of rb or the buffer rounded up to it - rows beyond the matrix are not written).
 struct SplitBatch {
     const float* src[CVT_MAX_SEG];
     uint16_t* dst[CVT_MAX_SEG];
     int start[CVT_MAX_SEG + 1];     // first workgroup of each segment
     int count[CVT_MAX_SEG];         // elements (multiple of 4)
     int K[CVT_MAX_SEG];
+    int rb[CVT_MAX_SEG];
     int n;
 };
 
@@ -959,7 +939,9 @@ __global__ __launch_bounds__(256) void split_weights_kernel(SplitBatch b) {
     const int row = i / K, k = i - row * K;
     u32x2 hi, mid, lo;
     split4(*reinterpret_cast<const f32x4*>(b.src[s] + i), hi, mid, lo);
-    uint16_t* d = b.dst[s] + (size_t)row * 3 * K + (k >> 4) * 48 + (k & 15);
+    const int rb = b.rb[s];
+    uint16_t* d = rb ? b.dst[s] + ((size_t)(row / rb) * (K >> 4) + (k >> 4)) * ((size_t)rb * 48) + (size_t)(row % rb) * 48 + (k & 15)
+                     : b.dst[s] + (size_t)row * 3 * K + (k >> 4) * 48 + (k & 15);
     *reinterpret_cast<u32x2*>(d) = hi;
     *reinterpret_cast<u32x2*>(d + 16) = mid;
     *reinterpret_cast<u32x2*>(d + 32) = lo;

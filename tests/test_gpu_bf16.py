@@ -196,11 +196,16 @@ def test_prepared_weights_follow_weight_versions(dtype):
     (129, 128, 128, 2, 0), (1, 128, 128, 2, 0),              # one row beyond a tile; a single row
     (333, 384, 256, 2, 2), (333, 384, 256, 2, 4), (2048, 640, 160, 1, 0),
     (40000, 512, 512, 2, 0), (70000, 128, 128, 2, 0),        # several work items per workgroup; eight-step work items
-    (4000, 1024, 160, 2, 0)])                                # a ten-step stream
+    (4000, 1024, 160, 2, 0),                                 # a ten-step stream
+    (1000, 512, 512, 3, 0), (129, 256, 128, 3, 0), (1, 256, 128, 3, 0),   # 128 x 256 planes kernel: ragged rows, one row beyond a
+    (40000, 512, 512, 3, 0), (70000, 256, 128, 3, 0),                    # tile, a single row; several work items per
+    (4000, 1536, 160, 3, 0), (15473, 1024, 512, 3, 0)])                  # workgroup; ten-step stream, widest N; DGN-R's conv2
 def test_split_gemm_matches_float64(m, n, k, tile, ksplit):
     """mel_gemm_f32_split (MEL_PREC_F32_SPLIT's projections on their own): fp32 operands split exactly into three bf16
     pieces, six partial products per term on the bf16 matrix cores, fp32 accumulation - as close to the float64 product as
-    an fp32 GEMM is.  Both tile shapes (64 x 64, 128 x 128) and the 128 x 128 kernel's split-K."""
+    an fp32 GEMM is.  The tile shapes (1: 64 x 64, 2: 128 x 128, 3: 128 x 256 fed from plane blocks on both sides -
+    gemm_planes_kernel, conv2's kernel in large forwards) and the 128 x 128 kernel's split-K.  Tile 3 adds the same six
+    products in the same order as tile 2: its result must be bit-identical."""
     from melissa_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(m + n + k)
@@ -208,7 +213,7 @@ def test_split_gemm_matches_float64(m, n, k, tile, ksplit):
     w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
     b = torch.randn(n, generator=g).cuda()
     y = torch.full((m, n), float("nan"), device="cuda")
-    scratch = torch.empty(6 * n * k + 256 + 4 * max(ksplit, 1) * m * n, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(6 * n * k + 256 + 4 * max(ksplit, 1) * m * n + 6 * ((m + 127) // 128 * 128) * k, dtype=torch.uint8, device="cuda")
     _lib.check(lib.mel_gemm_f32_split(a.data_ptr(), k, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, n, k, 1, tile, ksplit,
                                       scratch.data_ptr(), scratch.numel(), _lib.current_stream_ptr()))
     want = torch.relu(torch.addmm(b.double(), a.double(), w.double().t()))
@@ -216,6 +221,11 @@ def test_split_gemm_matches_float64(m, n, k, tile, ksplit):
     native = float((torch.relu(torch.addmm(b, a, w.t())).double() - want).abs().max())
     print(f"split gemm {m}x{n}x{k} tile {tile} ksplit {ksplit}: max error {err:.1e} (torch fp32 matmul: {native:.1e})")
     assert err <= 4e-6 * max(1.0, float(want.abs().max()))
+    if tile == 3:
+        y2 = torch.full((m, n), float("nan"), device="cuda")
+        _lib.check(lib.mel_gemm_f32_split(a.data_ptr(), k, w.data_ptr(), b.data_ptr(), y2.data_ptr(), n, m, n, k, 1, 2, 0,
+                                          scratch.data_ptr(), scratch.numel(), _lib.current_stream_ptr()))
+        assert torch.equal(y, y2)
 
 
 def test_split_gemm_rejects_shapes_the_big_tile_cannot_take():

@@ -32,7 +32,15 @@ static uint16_t* planes_of(const float* src, int rows, int K) {
     hipLaunchKernelGGL(split_weights_kernel, dim3(b.start[1]), dim3(256), 0, 0, b);
     return d;
 }
-struct Problem { int M, N, K, a_rows; float *A, *W, *bias, *Y[2]; uint16_t *Ap, *Wp; int32_t* arow; };
+static uint16_t* blocks_of(const uint16_t* planes, int rows, int K, int RB) {
+    uint16_t* d;
+    const size_t chunks = (size_t)((rows + RB - 1) / RB) * (K / 16) * RB * 6;
+    CK(hipMalloc(&d, chunks * 16));
+    hipLaunchKernelGGL(planes_to_blocks_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<const u32x4*>(planes),
+                       reinterpret_cast<u32x4*>(d), rows, K, RB);
+    return d;
+}
+struct Problem { int M, N, K, a_rows; float *A, *W, *bias, *Y[2]; uint16_t *Ap, *Wp, *Ab, *Wb; int32_t* arow; };
 static Problem make_problem(int M, int N, int K, int a_rows, bool gather, unsigned seed) {
     Problem p{};
     p.M = M, p.N = N, p.K = K, p.a_rows = a_rows;
@@ -41,6 +49,7 @@ static Problem make_problem(int M, int N, int K, int a_rows, bool gather, unsign
     p.bias = dev_random(N, 1.0f, seed + 2);
     for (int i = 0; i < 2; ++i) CK(hipMalloc(&p.Y[i], (size_t)M * N * 4));
     p.Ap = planes_of(p.A, a_rows, K), p.Wp = planes_of(p.W, N, K);
+    p.Ab = blocks_of(p.Ap, a_rows, K, 128), p.Wb = blocks_of(p.Wp, N, K, 256);
     if (gather) {
         std::vector<int32_t> idx(a_rows);
         for (int i = 0; i < a_rows; ++i) idx[i] = i;
@@ -63,7 +72,7 @@ static void run_case(const char* name, std::vector<Problem> ps, int rounds) {
         g.A = ps[i].A, g.lda = ps[i].K, g.arow = ps[i].arow, g.W = reinterpret_cast<const float*>(ps[i].Wp), g.bias = ps[i].bias;
         g.Y = ps[i].Y[0], g.ldy = ps[i].N, g.M = ps[i].M, g.N = ps[i].N, g.K = ps[i].K, g.split = 1, g.relu = 1;
         b0.p[i] = g;
-        g.A = reinterpret_cast<const float*>(ps[i].Ap), g.lda = 3 * ps[i].K, g.Y = ps[i].Y[1];
+        g.A = reinterpret_cast<const float*>(ps[i].Ab), g.W = reinterpret_cast<const float*>(ps[i].Wb), g.lda = 3 * ps[i].K, g.Y = ps[i].Y[1];
         b1.p[i] = g;
         items0 += ((long)((ps[i].M + 127) / 128) * (ps[i].N / 128) + 7) & ~7L;
         items1 += ((long)((ps[i].M + 127) / 128) * (ps[i].N / 256) + 7) & ~7L;
@@ -100,9 +109,23 @@ static void run_case(const char* name, std::vector<Problem> ps, int rounds) {
         CK(hipDeviceSynchronize());
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(planes_stamps), sizeof st));
         auto per = [&](int i, int n) { return st[n] ? (double)st[i] / st[n] : 0.0; };
-        printf("   stamps/step  wave0: read %.0f mfma %.0f done %.0f barrier %.0f (%lld steps) | wave4: mfmaB %.0f done %.0f read %.0f mfmaA %.0f barrier %.0f | loader: vmwait %.0f fill+issue %.0f ldswait %.0f barrier %.0f\n",
-               per(0, 4), per(1, 4), per(2, 4), per(3, 4), st[4], per(8, 13), per(9, 13), per(10, 13), per(11, 13), per(12, 13),
-               per(16, 20), per(17, 20), per(18, 20), per(19, 20));
+        printf("   block 0: %lld clock64 ticks in %lld wall ticks (100 MHz): clock64 runs at %.0f MHz; %.2f us inside the kernel\n", st[24], st[25],
+               st[25] ? 100.0 * st[24] / st[25] : 0.0, st[25] / 100.0);
+        {
+            static long long pb[512][2];
+            CK(hipMemcpyFromSymbol(pb, HIP_SYMBOL(planes_block), sizeof pb));
+            long long s0 = pb[0][0], s1 = pb[0][0], e0 = pb[0][1], e1 = pb[0][1];
+            double dur = 0;
+            for (int i = 0; i < grid1; ++i) {
+                s0 = std::min(s0, pb[i][0]), s1 = std::max(s1, pb[i][0]), e0 = std::min(e0, pb[i][1]), e1 = std::max(e1, pb[i][1]);
+                dur += (pb[i][1] - pb[i][0]) / 100.0;
+            }
+            int late = 0;
+            for (int i = 0; i < grid1; ++i) late += pb[i][0] - s0 > 300;
+            printf("   %d blocks: starts spread %.2f us (%d start > 3 us after the first), ends %.2f .. %.2f us after the first start, mean in-block %.2f us\n",
+                   grid1, (s1 - s0) / 100.0, late, (e0 - s0) / 100.0, (e1 - s0) / 100.0, dur / grid1);
+        }
+        printf("   block 0: first barrier passed at %lld ticks, step loop left at %lld, end %lld\n", st[26], st[27], st[24]);
     }
 #endif
     std::sort(t0s.begin(), t0s.end()), std::sort(t1s.begin(), t1s.end());
