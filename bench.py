@@ -371,7 +371,9 @@ def stage_profile(args, lib, net, loop, device, rank, decisions_per_step):
     if args.dtype == "f32a":        # per-launch arithmetic: the ceiling is the one of the pipe the dominant launch runs on
         peak = PEAK_BF16_MFMA_TFLOPS / 6 if split_launch else PEAK_F32_MFMA_TFLOPS
     if args.dtype == "f32a" and split_launch and args.mode == "round" and args.model == "l_dgn":
-        kname = f"mel::gemm_split_big_kernel<{tag}> ({dom})"                        # as rocprofv3 summaries name it
+        # as rocprofv3 summaries name it; conv2's large launches run on the kernel fed from bf16 plane blocks (fwd.hip, MEL_PLANES_FROM)
+        planes = dom == "conv2_lin" and "MEL_NO_PLANES_GEMM" not in os.environ
+        kname = f"mel::gemm_planes_kernel<{tag}> ({dom})" if planes else f"mel::gemm_split_big_kernel<{tag}> ({dom})"
     elif args.dtype in ("f32", "f32a") and args.mode == "round" and args.model == "l_dgn" and dom != "encoder":
         kname = f"mel::gemm_f32_persistent_kernel<2, 2, 1, 1, 0, {tag}> ({dom})"   # as rocprofv3 summaries name it
     else:

@@ -245,12 +245,12 @@ mel_status mel_gemm_f32_splitk(const float* A, int32_t lda, const float* W, cons
 
 /* The same product at MEL_PREC_F32_SPLIT (fp32 operands and results, six exact bf16 partial products per term on the bf16
  * matrix cores): W is split into bf16 planes in `scratch` first.  tile: 0 = the library's choice, 1 = 64 x 64, 2 = 128 x 128
- * (N % 128 == 0), 3 = 128 x 256 with BOTH operands converted to bf16 plane blocks in scratch first (the kernel conv2's projections
+ * (N % 128 == 0), 3 = 128 x 256 with BOTH operands converted to bf16 planes in scratch first (the kernel conv2's projections
  * run on in large forwards, where the conv1 attention stores its rows in that form; N % 256 == 0, N <= 1536, lda == K, ldy % 4 == 0,
  * no split-K; bit-identical to tile 2), + 100 = W's planes are already in scratch (an earlier call with the same W: benchmarks;
  * not with tile 3); ksplit > 1: the 128 x 128 kernel's split-K (K / 16 a multiple of ksplit, >= 4 steps per chunk, ldy % 4 == 0).
  * K % 32 == 0, K >= 128, N % 64 == 0; scratch: device, >= round_up(6 N K, 256) + (ksplit > 1 ? 4 ksplit M N : 0)
- * + (tile 3 ? 6 K round_up(M, 128) : 0) bytes. */
+ * + (tile 3 ? 6 K M : 0) bytes. */
 mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                               int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, int32_t ksplit, void* scratch,
                               int64_t scratch_bytes, void* stream);

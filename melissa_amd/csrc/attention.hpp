@@ -30,9 +30,9 @@ struct AttArgs {
     int ldo;
     const float* out_scale; // optional [rows]: row r of `out` is stored times out_scale[r] (the decision-maker mask of
                             // l_dgn.py:128 - the x_2 snapshot in xcat is taken before it, l_dgn.py:127)
-    uint16_t* out_blocks;   // optional (fp32 path, 4+ features per lane): the rows go out ALREADY SPLIT into bf16 planes in the
-                            // layout gemm_planes_kernel reads its A operand in, [rows / 128][ldo / 16][128][3][16], instead of
-                            // fp32 rows to `out` - the same split4() the split GEMMs apply to fp32 rows on their way into LDS
+    uint16_t* out_planes;   // optional (fp32 path, 4+ features per lane): the rows go out ALREADY SPLIT into bf16 planes,
+                            // [rows][ldo / 16][3][16] - gemm_planes_kernel's A operand - instead of fp32 rows to `out`: the same
+                            // split4() the split GEMMs apply to fp32 rows on their way into LDS
     float* xcat;            // [R, ld_cat] head input: x_1 | x_2 | x_3 (l_dgn.py:139)
     int ld_cat, hidden;
     const float* h0;        // encoder rows (packed by smask), [*, hidden]
@@ -254,21 +254,35 @@ __device__ __forceinline__ Vec<VPL> attend_target(const AttArgs& a, size_t xr_ro
     return out;
 }
 
-// row r of a [rows, K] matrix as bf16 planes in 128-row blocks (gemm_planes_kernel's A operand): this lane's VPL consecutive
-// features k = lane * VPL ..; 16-k step k >> 4, the 96 bytes of (row, step) hold hi | mid | lo of its 16 values
+// row r of a [rows, K] matrix as bf16 planes (gemm_planes_kernel's A operand): this lane's VPL consecutive features
+// k = lane * VPL ..; the 96 bytes of 16-k step k >> 4 hold hi | mid | lo of its 16 values
 template <int VPL>
-__device__ __forceinline__ void store_row_blocks(uint16_t* base, int r, int K, int lane, const Vec<VPL>& o) {
+__device__ __forceinline__ void store_row_planes(uint16_t* base, int r, int K, int lane, const Vec<VPL>& o) {
     static_assert(VPL % 4 == 0, "planes need whole groups of four features per lane");
-    uint16_t* row = base + (size_t)(r >> 7) * ((size_t)K * 384) + (size_t)(r & 127) * 48;
+    uint16_t* row = base + (size_t)r * 3 * K;
+    if constexpr (VPL % 8 == 0) {                 // eight features = half of a 16-k step: one 16-byte store per plane
 #pragma unroll
-    for (int i = 0; i < VPL; i += 4) {
-        const int k = lane * VPL + i;
-        u32x2 hi, mid, lo;
-        split4(f32x4{o.v[i], o.v[i + 1], o.v[i + 2], o.v[i + 3]}, hi, mid, lo);
-        uint16_t* d = row + (size_t)(k >> 4) * (128 * 48) + (k & 15);
-        *reinterpret_cast<u32x2*>(d) = hi;
-        *reinterpret_cast<u32x2*>(d + 16) = mid;
-        *reinterpret_cast<u32x2*>(d + 32) = lo;
+        for (int i = 0; i < VPL; i += 8) {
+            const int k = lane * VPL + i;
+            u32x2 h0, m0, l0, h1, m1, l1;
+            split4(f32x4{o.v[i], o.v[i + 1], o.v[i + 2], o.v[i + 3]}, h0, m0, l0);
+            split4(f32x4{o.v[i + 4], o.v[i + 5], o.v[i + 6], o.v[i + 7]}, h1, m1, l1);
+            uint16_t* d = row + (k >> 4) * 48 + (k & 15);
+            *reinterpret_cast<u32x4*>(d) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+            *reinterpret_cast<u32x4*>(d + 16) = u32x4{m0[0], m0[1], m1[0], m1[1]};
+            *reinterpret_cast<u32x4*>(d + 32) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VPL; i += 4) {
+            const int k = lane * VPL + i;
+            u32x2 hi, mid, lo;
+            split4(f32x4{o.v[i], o.v[i + 1], o.v[i + 2], o.v[i + 3]}, hi, mid, lo);
+            uint16_t* d = row + (k >> 4) * 48 + (k & 15);
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + 16) = mid;
+            *reinterpret_cast<u32x2*>(d + 32) = lo;
+        }
     }
 }
 
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256, MEL_ATT_MINB) void gat_attend_rows_kernel(AttA
             }
             bool as_rows = true;
             if constexpr (!BF && VPL % 4 == 0) {
-                if (a.out_blocks) store_row_blocks<VPL>(a.out_blocks, r, a.ldo, lane, om), as_rows = false;
+                if (a.out_planes) store_row_planes<VPL>(a.out_planes, r, a.ldo, lane, om), as_rows = false;
             }
             if (as_rows) store_row<VPL, BF>(a.out, (size_t)r * a.ldo + lane * VPL, om);
             if (d.cat_row >= 0) {

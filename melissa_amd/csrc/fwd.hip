@@ -128,7 +128,9 @@ static void gemm_launch_bf16(const GemmArgs* gs, int count, int mode, hipStream_
 // split path: a persistent 64 x 64 kernel for small launches, 128 x 128 tiles from MEL_SPLIT_BIG_FROM expected big tiles on
 // (both named per call site like the fp32 one)
 #ifndef MEL_PLANES_FROM
-#define MEL_PLANES_FROM 160          // expected 128 x 256 work items from which conv2 runs on gemm_planes_kernel (256 CUs, one each)
+#define MEL_PLANES_FROM 129          // expected 128 x 256 work items from which conv2 runs on gemm_planes_kernel: up to 256 tiles of
+                                     // 128 x 128 the older kernel has a CU per tile (32 us), beyond it doubles up (42 us at 288); this one
+                                     // takes 33 us for anything up to 256 items
 #endif
 #ifndef MEL_SPLIT_BIG_FROM
 #define MEL_SPLIT_BIG_FROM 192
@@ -189,14 +191,14 @@ static void gemm_launch_split(const GemmArgs* gs, int count, int mode, hipStream
     }
 }
 
-// gemm_planes_kernel (gemm_split.hpp): A as [rows / 128][K / 16][128][3][16] bf16 planes, W / W_hi as [N / 256][K / 16][256][3][16]
+// gemm_planes_kernel (gemm_split.hpp): A as [rows][K / 16][3][16] bf16 planes, W / W_hi as [N / 256][K / 16][256][3][16]
 static bool planes_fit(const GemmArgs* gs, int count) {
     long ncols = 0;
     for (int i = 0; i < count; ++i) {
         const GemmArgs& g = gs[i];
         if (g.N % GEMP_BN || g.K % GEMS2_BK || g.K / GEMS2_BK < 4 || g.ldy % 4 || g.rscale || g.ksplit > 1) return false;
         if (g.W_hi && g.split_n % GEMP_BN) return false;
-        if ((((size_t)g.M + 127) & ~(size_t)127) * (size_t)g.K * 6 >= ((size_t)1 << 32)) return false;      // 32-bit operand offsets
+        if ((size_t)g.M * (size_t)g.K * 6 >= ((size_t)1 << 32)) return false;      // 32-bit operand offsets
         ncols += g.N;
     }
     return count >= 1 && count <= GEMM_MAX_GROUP && ncols <= GEMP_BIAS_FLOATS;
@@ -566,8 +568,8 @@ static FwdLayout carve(const mel_weights* w, const Dims& d, void* ws) {
         const int srcw = (w->conv1.kind == MEL_CONV_TRANSFORMER) ? 2 * hc : hc;     // key | value side by side
         L.xl1 = c.take<float>(rows2 * srcw);
         L.xr1 = c.take<float>(rows1 * hc);
-        // (fp32 rows, or - conv2 on gemm_planes_kernel - three bf16 planes in 128-row blocks: 6 bytes per value)
-        L.h1 = c.take<float>(((((size_t)d.u1_cap + 127) & ~(size_t)127) * hc * 3 + 1) / 2);
+        // (fp32 rows, or - conv2 on gemm_planes_kernel - three bf16 planes: 6 bytes per value)
+        L.h1 = c.take<float>(((size_t)d.u1_cap * hc * 3 + 1) / 2);
         L.xl2 = c.take<float>((size_t)d.u1_cap * srcw);
         L.xr2 = c.take<float>(R * hc);
     } else {
@@ -935,7 +937,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && hint1 + hint2 >= 2L * T;
     bool fused_enc = false;
     // conv2's projections on gemm_planes_kernel (both operands as bf16 planes in blocks, gemm_split.hpp): decided HERE, because
-    // the conv1 attention then stores h1 already split, in that kernel's A layout.  Large launches of the fp32-accurate
+    // the conv1 attention then stores h1 already split, as that kernel's A operand.  Large launches of the fp32-accurate
     // paths only: a launch of fewer work items than CUs stays on the 128 x 128 / 64 x 64 kernels.
     const ProjWeights* planes = sp ? &pw : pw.alt;
     GemmArgs c2[2];
@@ -952,8 +954,9 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
     }
     const long c2_items = ((hint1 + 127) / 128) * (srcw / GEMP_BN) + ((hintL + 127) / 128) * (hc / GEMP_BN);
     static const bool planes_off = getenv("MEL_NO_PLANES_GEMM") != nullptr;         // A/B switch for bench and tests
+    static const long planes_from = getenv("MEL_PLANES_FROM") ? atol(getenv("MEL_PLANES_FROM")) : MEL_PLANES_FROM;      // (tuning)
     const bool conv2_planes = !planes_off && !bf && planes && c2[0].W && c2[1].W && (!tconv || c2[0].W_hi) && hc % 4 == 0 &&
-                              hc / 64 >= 4 && c2_items >= MEL_PLANES_FROM && planes_fit(c2, 2);
+                              hc / 64 >= 4 && c2_items >= planes_from && planes_fit(c2, 2);
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -1032,7 +1035,7 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         a.desc = L.plan.desc1, a.rows_dev = n1, a.rows_cap = U1, a.rows_hint = hint1;
         a.lanes_per_head = w->conv1.channels / (hc / 64);
         a.out = L.h1, a.ldo = hc, a.xcat = L.xcat, a.ld_cat = latent, a.hidden = hidden, a.h0 = ft.h0;
-        if (conv2_planes) a.out_blocks = reinterpret_cast<uint16_t*>(L.h1);
+        if (conv2_planes) a.out_planes = reinterpret_cast<uint16_t*>(L.h1);
         a.out_scale = L.plan.dm1;       // the decision-maker mask (l_dgn.py:128) is applied as h1 is stored; x_2 is taken before it
         a.fid = table ? L.plan.fid : nullptr;
         StageScope t(MEL_STAGE_CONV1_ATT, s);
@@ -1364,8 +1367,8 @@ mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const
     if (!A || !W || !Y || !scratch || M <= 0 || M > (1ll << 30) || lda < K || ldy < N || N < 64 || K < 128)
         return fail(MEL_ERR_INVALID_ARG, "bad split-precision gemm arguments");
     const int64_t plane_bytes = ((int64_t)6 * N * K + 255) & ~255ll;
-    const bool blocks = tile % 100 == 3;                // gemm_planes_kernel: A goes through bf16 plane blocks in scratch as well
-    const int64_t a_bytes = blocks ? ((M + 127) & ~127ll) * K * 6 : 0;
+    const bool blocks = tile % 100 == 3;                // gemm_planes_kernel: A goes through bf16 planes in scratch as well
+    const int64_t a_bytes = blocks ? M * K * 6 : 0;
     const int64_t need = plane_bytes + a_bytes + (ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0);
     if (K % 32 || N % 64 || scratch_bytes < need)
         return fail(MEL_ERR_UNSUPPORTED, "split-precision gemm: K %% 32 == 0, N %% 64 == 0, scratch >= %lld bytes", (long long)need);
@@ -1383,10 +1386,10 @@ mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const
         b.src[0] = W, b.dst[0] = static_cast<uint16_t*>(scratch), b.count[0] = N * K, b.K[0] = K, b.rb[0] = GEMP_BN;
         b.start[1] = (int)(((int64_t)N * K / 4 + 255) / 256);
         b.src[1] = A, b.dst[1] = reinterpret_cast<uint16_t*>(static_cast<char*>(scratch) + plane_bytes), b.count[1] = (int)(M * K), b.K[1] = K;
-        b.rb[1] = 128;
+        b.rb[1] = 0;
         b.start[2] = b.start[1] + (int)((M * K / 4 + 255) / 256);
         MEL_LAUNCH(split_weights_kernel, dim3(b.start[2]), dim3(256), 0, s, b);
-        if (mel_status st = check_launch("operands -> bf16 plane blocks")) return st;
+        if (mel_status st = check_launch("operands -> bf16 planes")) return st;
         gemm_launch_planes(&g, 1, s, 0);
         return check_launch("mel_gemm_f32_split (planes)");
     }

@@ -594,9 +594,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_big_kernel(GemmBatch batch)
 // What bounded the kernels above, found one layer at a time (tools/planes_probe.hip, profiles/r03k_*):
 //   * a CU's vector-memory path delivers ~17 B / clk of 64- / 96-byte row pieces while its matrix pipe is busy
 //     (tools/overlap_probe.hip), and a 128 x 128 tile needs 26: so 128 x 256 outputs per workgroup (eight MFMA waves of 64 x 64,
-//     two per SIMD), and BOTH operands stored the way a K step reads them - A as [rows / 128][K / 16][128][3][16] bf16 planes
-//     (written by the producer of the rows, the conv1 attention's store), W as [N / 256][K / 16][256][3][16] (mel_prepare_weights):
-//     the 12 KB + 24 KB of a step are two contiguous runs, every load instruction of a wave one whole KB;
+//     two per SIMD), and W stored the way a K step reads it - [N / 256][K / 16][256][3][16] (mel_prepare_weights), the 24 KB of
+//     a step one contiguous run, every load instruction of a wave one whole KB; A as [rows][K / 16][3][16] planes, written by
+//     the producer of the rows (the conv1 attention's store; 128-row blocks for A as well measured the same here and cost
+//     that kernel 13 us at N = 100 in scattered stores);
 //   * A arrives ALREADY SPLIT: no vector arithmetic is left in the GEMM, nothing competes with the MFMA stream for issue slots;
 //     four loader waves (one per SIMD) only move bytes - nine 16-byte loads per thread and step, three steps ahead of their LDS
 //     write (three register sets);
@@ -840,10 +841,10 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int ch = tid + i * 256, row = ch / 6, cc = ch - row * 6;
-            if (i < 3) {                       // A blocks [rows / 128][K / 16][128][3][16]; rows beyond M clamped, never predicated
+            if (i < 3) {                       // A planes [rows][K / 16][3][16]; rows beyond M clamped, never predicated
                 const int gr = min(m.m0 + row, m.M - 1);
                 const int ar = g.arow ? g.arow[gr] : gr;
-                c.off[i] = (uint32_t)(ar >> 7) * (uint32_t)(g.K * 768) + (uint32_t)(ar & 127) * 96u + cc * 16;
+                c.off[i] = (uint32_t)ar * (uint32_t)(g.K * 6) + cc * 16;
             } else {                           // W blocks [N / 256][K / 16][256][3][16]: a step's 24 KB are contiguous
                 c.off[i] = (uint32_t)(row - BM) * 96u + cc * 16;
             }
@@ -857,10 +858,11 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
     bool pf_valid = true;
     setup(pf, t0);
     auto issue = [&](Regs& R) {               // loads of the next step of the stream, unconditional (see gemm_split_kernel)
-        const uint32_t ks = (uint32_t)pf_kt * 12288u;          // a K step: 12 KB of an A block, 24 KB of a W block
+        const uint32_t ka = (uint32_t)pf_kt * 96u;             // a K step: 96 bytes further in every A row,
+        const uint32_t kw = (uint32_t)pf_kt * 24576u;          // the next 24 KB of the W block
 #pragma unroll
         for (int i = 0; i < 9; ++i)
-            R.v[i] = *reinterpret_cast<const u32x4*>((i < 3 ? pf.a_base : pf.w_base) + (pf.off[i] + (i < 3 ? ks : 2 * ks)));
+            R.v[i] = *reinterpret_cast<const u32x4*>((i < 3 ? pf.a_base : pf.w_base) + (pf.off[i] + (i < 3 ? ka : kw)));
         if (pf_valid && ++pf_kt == pf.KT) {
             const int tn = next_valid(pf_t + stride);
             if (tn < total) {

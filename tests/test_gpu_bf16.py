@@ -213,7 +213,7 @@ def test_split_gemm_matches_float64(m, n, k, tile, ksplit):
     w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda()
     b = torch.randn(n, generator=g).cuda()
     y = torch.full((m, n), float("nan"), device="cuda")
-    scratch = torch.empty(6 * n * k + 256 + 4 * max(ksplit, 1) * m * n + 6 * ((m + 127) // 128 * 128) * k, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(6 * n * k + 256 + 4 * max(ksplit, 1) * m * n + 6 * m * k, dtype=torch.uint8, device="cuda")
     _lib.check(lib.mel_gemm_f32_split(a.data_ptr(), k, w.data_ptr(), b.data_ptr(), y.data_ptr(), n, m, n, k, 1, tile, ksplit,
                                       scratch.data_ptr(), scratch.numel(), _lib.current_stream_ptr()))
     want = torch.relu(torch.addmm(b.double(), a.double(), w.double().t()))

@@ -72,7 +72,8 @@ static void run_case(const char* name, std::vector<Problem> ps, int rounds) {
         g.A = ps[i].A, g.lda = ps[i].K, g.arow = ps[i].arow, g.W = reinterpret_cast<const float*>(ps[i].Wp), g.bias = ps[i].bias;
         g.Y = ps[i].Y[0], g.ldy = ps[i].N, g.M = ps[i].M, g.N = ps[i].N, g.K = ps[i].K, g.split = 1, g.relu = 1;
         b0.p[i] = g;
-        g.A = reinterpret_cast<const float*>(ps[i].Ab), g.W = reinterpret_cast<const float*>(ps[i].Wb), g.lda = 3 * ps[i].K, g.Y = ps[i].Y[1];
+        g.A = reinterpret_cast<const float*>(ps[i].Ap);
+        g.W = reinterpret_cast<const float*>(ps[i].Wb), g.lda = 3 * ps[i].K, g.Y = ps[i].Y[1];
         b1.p[i] = g;
         items0 += ((long)((ps[i].M + 127) / 128) * (ps[i].N / 128) + 7) & ~7L;
         items1 += ((long)((ps[i].M + 127) / 128) * (ps[i].N / 256) + 7) & ~7L;

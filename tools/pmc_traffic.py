@@ -18,7 +18,7 @@ from melissa_amd import build  # noqa: E402  (source hash of the library the pas
 # launches of the round step by kernel name (the call site is part of it: TAG 1 = conv1, 2 = conv2, 3 = heads)
 # (default precision MEL_PREC_F32_AUTO: conv2 and the heads' first layer run the 128 x 128 split-bf16 kernel at this size;
 #  the exact-fp32 names stay in the list for builds / workloads that launch those)
-LAUNCHES = {"conv1 (lin_l+lin_r, feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 0>", "conv2 (lin_l+lin_r)": "gemm_split_big_kernel<2>",
+LAUNCHES = {"conv1 (lin_l+lin_r, feature tuples)": "gemm_f32_kernel<2, 2, 1, 1, 0>", "conv2 (lin_l+lin_r)": "gemm_planes_kernel<2>",
          "conv2 (lin_l+lin_r), exact fp32": "gemm_f32_persistent_kernel<2, 2, 1, 1, 0, 2>",
          "head0 (Q|V, split-K)": "gemm_split_big_kernel<3>", "head0 (Q|V, split-K), exact fp32": "gemm_f32_ring_kernel<3,",
          "head finish": "head_finish_kernel",
