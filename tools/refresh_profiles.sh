@@ -22,6 +22,7 @@ python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traff
   cat $(find $OUT/stats -name '*kernel_stats.csv' | head -1); } > $OUT/${TAG}_round_kernel_stats.csv
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json       # bench.py reads roofline.traffic from profiles/ (hash-checked)
+cp $OUT/${TAG}_round_kernel_stats.csv profiles/${TAG}_round_kernel_stats.csv   # ... and profiler_avg_launch_us from the summary beside it
 python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.log
 echo "bench line done"
 if [ -z "$NO_SOAK" ]; then       # NO_SOAK=1: the soak (15-20 min with the 100-node cases) runs in its own gpurun call
