@@ -38,12 +38,15 @@ PEAK_HBM_GBS = 8000.0            # same guide, HBM3E ~8 TB/s
 N_NODES, ENVS_PER_GPU, HIDDEN, HEADS = 50, 1024, 128, 4
 N_GRAPHS, RING = 1024, int(os.environ.get("MEL_BENCH_RING", "16"))
 MAX_MOVES = int(os.environ.get("MEL_BENCH_MAX_MOVES", "48"))      # movement draws kept per episode (tuning knob)
-SETTLE_ROUNDS = 64                                                 # untimed rounds after the first reset (build_workload)
+SETTLE_ROUNDS = int(os.environ.get("MEL_BENCH_SETTLE", "512"))    # untimed rounds after the first reset (build_workload)
 HC = HIDDEN * HEADS
 
 
 def dueling():
     return ({"hidden_sizes": [128, 128]}, {"hidden_sizes": [128, 128]})     # common.py:41-42
+
+
+GRAPH_ROUNDS = [4]          # rounds per replayed HIP graph (--graph-rounds)
 
 
 def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, streams, seed=9, dtype="f32", supply="stream",
@@ -80,14 +83,16 @@ def build_workload(device, rank, envs, n_nodes, model_name, mode, use_graph, str
         # episodes: the device episode stream (every reset draws a new episode, core.py:372-394; ring of 16 slots per env
         # refilled every 7 rounds on a side stream INSIDE the timed region, resets included)
         loop = RoundLoop(venv, policy, seed=base, eps=0.001, use_graph=use_graph, ring=RING,
-                         episode_stream=None if supply == "stream" else False, episodes_per_env=12)
+                         episode_stream=None if supply == "stream" else False, episodes_per_env=12, graph_rounds=GRAPH_ROUNDS[0])
     else:
         venv = make_venv(envs, base)
         loop = DecisionLoop(venv, policy, seed=base, eps=0.001)
     # Untimed settling rounds (set-up, before the W warm-up steps the caller asks for): every env has just been reset, so all
     # of them start in round 0 of an episode and the first rounds of a run evaluate fewer agents per env than the steady
     # state does; after SETTLE_ROUNDS the envs' episode phases are decorrelated and a short timed region (the driver's
-    # --steps 20) measures the same loop state as a long one.
+    # --steps 20) measures the same loop state as a long one.  The chip too needs a run-up: the same 20 timed steps take
+    # 0.185 / 0.183 / 0.179 / 0.171 ms each after 5 / 30 / 100 / 300 warm-up steps on one box (profiles/r03n_warmup_ramp.log;
+    # the 2.4 s sustained leg: 0.172) - 512 rounds are ~90 ms of the loop's own work, the state a collector runs in.
     if mode == "round":
         with torch.no_grad():
             loop.run(SETTLE_ROUNDS)
@@ -260,9 +265,10 @@ def timed_run(loop, steps, warmup, device, parallel):
     the max over ranks, the counters are summed over ranks (whole-job throughput)."""
     import torch
     loop.run(warmup)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    c0 = loop.counters()
+    # the counters before the timed region are COPIED ON THE DEVICE behind the warm-up (one more launch in the queue) and read
+    # after it: a host read here leaves the GPU idle for a few hundred microseconds right before t0, and a short timed region
+    # (the driver's --steps 20) then starts on a chip that has dropped its clocks
+    snap0 = loop.snapshot_counters()
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
@@ -270,6 +276,7 @@ def timed_run(loop, steps, warmup, device, parallel):
     torch.cuda.synchronize()
     parallel.barrier()
     dt_local = time.perf_counter() - t0
+    c0 = loop.counters(snap0)
     c1 = loop.counters()
     local_dec = float(c1["decisions"] - c0["decisions"])
     dt = parallel.all_reduce_max(dt_local, device)
@@ -536,6 +543,8 @@ def main():
     ap.add_argument("--model", default="l_dgn", choices=["l_dgn", "hl_dgn", "dgn_r"])
     ap.add_argument("--mode", default="round", choices=["round", "aec"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph-rounds", type=int, default=4,
+                    help="rounds (= steps) per replayed HIP graph: a graph launch leaves the device idle ~8 us between replays")
     ap.add_argument("--streams", type=int, default=1,
                     help="round mode: sub-batches of the GPU's envs on separate HIP streams")
     ap.add_argument("--dtype", default="f32a", choices=["f32", "bf16", "f32s", "f32a"],
@@ -556,6 +565,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the gloo backend")
     args = ap.parse_args()
+    GRAPH_ROUNDS[0] = max(1, args.graph_rounds)
 
     # --gpus N without an external launcher: this process is still GPU-free (no torch.cuda call, no library load), so it
     # may start the N ranks as fresh children, relay rank 0's JSON line and leave with their exit code.  Under
@@ -698,6 +708,7 @@ def main():
                                   f"before the warm-up" if supply["mode"] == "device stream"
                                   else f"static table of {supply.get('episodes_per_env')} pre-drawn episodes per env"),
                    "loop": args.mode, "hip_graph": bool(args.mode == "round" and not args.no_graph),
+                   "rounds_per_graph_replay": (GRAPH_ROUNDS[0] if args.mode == "round" and not args.no_graph and args.streams == 1 else 1),
                    "streams": args.streams if args.mode == "round" else 1,
                    "envs_per_gpu": args.envs, "n_nodes": args.nodes, "global_envs": args.envs * world,
                    "parallelism": f"env-shard x{world} (no data-path collective)", "episode_supply": supply,

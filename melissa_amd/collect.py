@@ -38,6 +38,12 @@ def sample_episode_table(venv: HipGraphVectorEnv, episodes_per_env: int, seed: i
     return packed, table
 
 
+def _counters_of(scalars: torch.Tensor, iterations: int) -> dict:
+    sc = scalars.cpu().numpy()
+    return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
+                errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=iterations)
+
+
 class DecisionLoop:
     """AEC-order loop: one agent decision per env per iteration (the reference collector's granularity)."""
 
@@ -79,11 +85,16 @@ class DecisionLoop:
         for _ in range(iterations):
             self.step()
 
-    def counters(self) -> dict:
+    def snapshot_counters(self):
+        """Device-side copy of the per-env counters as they stand when the launches enqueued so far have run (no host
+        synchronisation: the copy is one more launch in the queue); ``counters(snapshot)`` reads it later."""
+        return (self.venv.scalars().clone(), self.iterations)
+
+    def counters(self, snapshot=None) -> dict:
         """Host read of the per-env counters (synchronises)."""
-        sc = self.venv.scalars().cpu().numpy()
-        return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
-                    errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)
+        if snapshot is not None:
+            return _counters_of(*snapshot)
+        return _counters_of(self.venv.scalars(), self.iterations)
 
 
 class RoundLoop:
@@ -101,12 +112,16 @@ class RoundLoop:
     def __init__(self, venv: HipGraphVectorEnv, policy, episodes_per_env: int = 8, seed: int = 0,
                  eps: float = 0.0, episodes=None, rows_cap: int | None = None, use_graph: bool = False,
                  stream: "torch.cuda.Stream | None" = None, replay=None, episode_stream: bool | None = None,
-                 ring: int = 16, discard: int = 0):
+                 ring: int = 16, discard: int = 0, graph_rounds: int = 4):
         """Episodes: by default a device STREAM (``melissa_amd.env.stream.EpisodeStream``: every reset draws a new episode
         like World.reset does, core.py:372-394; ``ring`` slots per env, ``discard`` construction-time samplings dropped);
         ``episodes`` = (packed, table) or ``episode_stream=False`` give a fixed table of ``episodes_per_env`` episodes."""
         self.venv, self.policy, self.eps, self.seed = venv, policy, eps, seed
         self.use_graph, self.graph = use_graph, None
+        # run(): whole groups of `graph_rounds` rounds are replayed from ONE HIP graph - a graph launch costs the device ~8 us
+        # of idle time between the last kernel of one replay and the first of the next (rocprofv3 kernel trace of the
+        # one-round graph: tools/gap_trace.py), a quarter of that per round with four rounds per graph
+        self.graph_rounds, self.group_graph = max(1, int(graph_rounds)), None
         # the observations are the env kernels' own, so their node features are integers in known ranges and the forward may
         # evaluate encoder / conv1 projections once per feature TUPLE (MEL_FWD_INTEGER_FEATURES); False forces row lists
         # (scripted agents relay without a step budget, so their message counts leave the table's range: row lists then)
@@ -212,14 +227,55 @@ class RoundLoop:
         self.iterations += 1
         self.supply.after_step(it, self.rounds)
 
+    def _run_groups(self, groups: int):
+        """``groups`` replays of the graph that holds ``graph_rounds`` rounds back to back (same launches, same buffers, same
+        device-side round counter as the one-round graph: bit-identical trajectories)."""
+        G, dev = self.graph_rounds, self.venv.device
+        if self.group_graph is None:
+            torch.cuda.synchronize(dev)
+            self.group_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.group_graph):
+                for _ in range(G):
+                    self._launch()
+        for _ in range(groups):
+            it = self.iterations - self._rounds_base
+            for k in range(G):
+                self.supply.before_step(it + k, self.rounds)
+            self.policy.model.ensure_prepared(dev)
+            self.group_graph.replay()
+            self.iterations += G
+            for k in range(G):                    # the refill gates go into the side stream's queue behind the rounds they wait for
+                self.supply.after_step(it + k, self.rounds)
+
     def run(self, iterations: int):
+        paced = getattr(self.supply, "_paced", None)            # (event-ordered refills touch the main stream between rounds)
+        while self.use_graph and self.graph is None and iterations > 0:      # eager warm-up round, then the capture
+            self.step()
+            iterations -= 1
+        if (self.use_graph and self.graph is not None and self.graph_rounds > 1 and iterations >= self.graph_rounds
+                and (paced is None or paced(self.rounds))):
+            groups = iterations // self.graph_rounds
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    self._run_groups(groups)
+            else:
+                self._run_groups(groups)
+            iterations -= groups * self.graph_rounds
         for _ in range(iterations):
             self.step()
 
-    def counters(self) -> dict:
-        sc = self.venv.scalars().cpu().numpy()
-        return dict(decisions=int(sc[:, _lib.S_DECISIONS].sum()), episodes=int(sc[:, _lib.S_EPISODES_DONE].sum()),
-                    errors=int(np.bitwise_or.reduce(sc[:, _lib.S_ERROR])), iterations=self.iterations)
+    def snapshot_counters(self):
+        """Device-side copy of the per-env counters as they stand when the launches enqueued so far have run (no host
+        synchronisation: the copy is one more launch on the loop's stream); ``counters(snapshot)`` reads it later."""
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                return (self.venv.scalars().clone(), self.iterations)
+        return (self.venv.scalars().clone(), self.iterations)
+
+    def counters(self, snapshot=None) -> dict:
+        if snapshot is not None:
+            return _counters_of(*snapshot)
+        return _counters_of(self.venv.scalars(), self.iterations)
 
     def feature_table(self) -> dict:
         """What the last forward did with the node-feature table: rows used (0 = row-list path) and how many envs had a
@@ -266,10 +322,13 @@ class MultiStreamRoundLoop:
         for _ in range(iterations):
             self.step()
 
-    def counters(self) -> dict:
+    def snapshot_counters(self):
+        return [l.snapshot_counters() for l in self.loops]
+
+    def counters(self, snapshot=None) -> dict:
         out = dict(decisions=0, episodes=0, errors=0, iterations=self.iterations)
-        for l in self.loops:
-            c = l.counters()
+        for k, l in enumerate(self.loops):
+            c = l.counters(snapshot[k] if snapshot is not None else None)
             out["decisions"] += c["decisions"]
             out["episodes"] += c["episodes"]
             out["errors"] |= c["errors"]

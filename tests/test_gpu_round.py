@@ -271,7 +271,9 @@ def round_loop_vs_oracle(n, dynamic, supply, B=6, K=40):
 
 def test_graph_replay_matches_eager_launches():
     """The round step captured once into a HIP graph and replayed must walk exactly the same trajectory as
-    the eager launch sequence (incl. the eps-greedy stream, which is keyed on a device-side round counter)."""
+    the eager launch sequence (incl. the eps-greedy stream, which is keyed on a device-side round counter) - replayed round by
+    round, and in groups of four rounds per graph (RoundLoop.run: 14 group replays + 2 single rounds here), with the episode
+    stream's refills paced on their side stream in all three."""
     from melissa_amd.collect import RoundLoop
     from melissa_amd.env import HipGraphVectorEnv, synthetic_graph_pool
     from melissa_amd.policy import DQNPolicy
@@ -279,18 +281,23 @@ def test_graph_replay_matches_eager_launches():
     graphs = synthetic_graph_pool(n, 4, first_seed=5)
     net, _ = make_ldgn(n)
     finals = []
-    for use_graph in (False, True):
+    for use_graph, rounds_per_graph in ((False, 1), (True, 1), (True, 4)):
         venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
                                  construct_like_reference=False)
-        loop = RoundLoop(venv, DQNPolicy(net), episodes_per_env=10, seed=3, eps=0.05, use_graph=use_graph)
-        loop.run(60)
+        loop = RoundLoop(venv, DQNPolicy(net), episodes_per_env=10, seed=3, eps=0.05, use_graph=use_graph,
+                         graph_rounds=rounds_per_graph)
+        loop.run(2)                      # warm-up + capture of the one-round graph
+        loop.run(58)
         torch.cuda.synchronize()
+        assert (loop.group_graph is not None) == (rounds_per_graph == 4)
         finals.append((venv.scalars().cpu().numpy().copy(), venv.node_sets().cpu().numpy().copy(),
                        venv.positions().cpu().numpy().copy(), loop.counters()))
-    np.testing.assert_array_equal(finals[0][0], finals[1][0])
-    np.testing.assert_array_equal(finals[0][1], finals[1][1])
-    np.testing.assert_array_equal(finals[0][2], finals[1][2])
-    assert finals[0][3] == finals[1][3] and finals[0][3]["errors"] == 0 and finals[0][3]["episodes"] > 20
+    for other in finals[1:]:
+        np.testing.assert_array_equal(finals[0][0], other[0])
+        np.testing.assert_array_equal(finals[0][1], other[1])
+        np.testing.assert_array_equal(finals[0][2], other[2])
+        assert finals[0][3] == other[3]
+    assert finals[0][3]["errors"] == 0 and finals[0][3]["episodes"] > 20 and finals[0][3]["iterations"] == 60
 
 
 def test_replay_sampling_and_dqn_learner():
