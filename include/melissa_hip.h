@@ -583,6 +583,29 @@ typedef struct mel_round_replay {
     int32_t*  cursor;          /* [B]    rounds recorded so far (slot = cursor % K)               */
 } mel_round_replay;
 
+/* Replay sampling in one launch (the learn half's first step, l_dgn.py:246-261 -> [3P] tianshou ReplayBuffer.sample +
+ * compute_nstep_return with estimation_step = n_step): `batch` (record, acting agent) pairs drawn uniformly with replacement
+ * from the records the ring holds, each followed through consecutive slots while the env's episode is the same and the agent
+ * keeps acting.  Outputs (device): obs / boot_obs float [batch, 8N+1] (the record's obs_matrix | agent id; the observation to
+ * bootstrap from), act int64, ret float (sum_j discount[j] * rew_j), boot_w float (discount[steps], 0 when the agent
+ * terminated inside the window), env / slot / agent int64.  discount: HOST float [n_step + 1] = gamma^j (copied into the launch).
+ * Draws are a counter-based function of (seed, *draw_counter, sample index); the launch increments *draw_counter (device
+ * uint64), so replaying it from a HIP graph keeps drawing new batches.  scratch: device int32 [n_envs * capacity + 1]. */
+#define MEL_REPLAY_MAX_NSTEP 16
+typedef struct mel_replay_batch {
+    float*   obs;
+    float*   boot_obs;
+    int64_t* act;
+    float*   ret;
+    float*   boot_w;
+    int64_t* env;
+    int64_t* slot;
+    int64_t* agent;
+} mel_replay_batch;
+mel_status mel_replay_sample(const mel_round_replay* replay, int64_t n_envs, int32_t n_nodes, int32_t batch, int32_t n_step,
+                             const float* discount, uint64_t seed, uint64_t* draw_counter, int32_t* scratch,
+                             const mel_replay_batch* out, void* stream);
+
 /* One whole env ROUND per launch for every env of the batch (round-batched loop): replays, in the
  * reference's AEC order, the dead-agent steps and one GraphEnv.step per active agent with that agent's
  * action until the world step fires or the episode ends (then the env is reset to
@@ -636,7 +659,8 @@ int32_t    mel_prof_read(void* prof, double* ms_sum, int64_t* count);
 const char* mel_last_error(void);
 /* sizeof() of the structs of this header as the library was compiled, for binding authors to check their mirrors
  * against: which = 0 mel_linear, 1 mel_gatv2, 2 mel_mlp, 3 mel_weights, 4 mel_select, 5 mel_env_batch,
- * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay, 9 mel_graph_pool, 10 mel_episode_stream; 0 for anything else. */
+ * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay, 9 mel_graph_pool, 10 mel_episode_stream, 11 mel_replay_batch;
+ * 0 for anything else. */
 size_t mel_abi_sizeof(int32_t which);
 const char* mel_version(void);
 

@@ -980,6 +980,141 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
     return check_launch("env_round");
 }
 
+// ---- replay sampling: one launch instead of ~150 small index launches (replay.RoundReplay.sample) ---------------------------------
+// Uniform over (record, acting agent) pairs with replacement, then the n-step walk of [3P] tianshou's compute_nstep_return as the
+// reference configures it (l_dgn.py:246-261, estimation_step): follow the agent through consecutive ring slots while the
+// episode is the same and it keeps acting.  One 1 024-thread workgroup: (1) per-record pair counts and their exclusive prefix
+// sums, (2) one thread per sample: a counter-based draw (splitmix64 of seed, the device-side draw counter, the sample index),
+// binary search in the prefix sums, the rank-th member of the record's acted set, the walk, (3) all threads copy the sampled
+// observation rows.  No host value enters but the seed: replayable from a HIP graph, the draw counter advances on the device.
+struct ReplaySampleArgs {
+    mel_round_replay rp;
+    mel_replay_batch out;
+    int B, n, W, batch, n_step;
+    float disc[MEL_REPLAY_MAX_NSTEP + 1];
+    unsigned long long seed;
+    unsigned long long* counter;
+    int* prefix;            // [B * K + 1]
+};
+
+__device__ __forceinline__ int replay_pairs(const ReplaySampleArgs& a, int rec) {
+    const int K = a.rp.capacity, e = rec / K, k = rec - e * K;
+    const int filled = min(a.rp.cursor[e], K);
+    if (k >= filled) return 0;
+    int c = 0;
+    for (int w = 0; w < a.W; ++w) c += __popcll(a.rp.acted[(size_t)rec * a.W + w]);
+    return c;
+}
+
+__global__ __launch_bounds__(1024) void replay_sample_kernel(ReplaySampleArgs a) {
+    __shared__ int part[1024];
+    __shared__ int s_env[1024], s_slot[1024], s_agent[1024], s_boot[1024];
+    const int tid = threadIdx.x, K = a.rp.capacity, BK = a.B * K;
+    const int per = (BK + 1023) / 1024, lo = min(tid * per, BK), hi = min(lo + per, BK);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += replay_pairs(a, i);
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the 1 024 partial sums
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        a.prefix[i] = run;
+        run += replay_pairs(a, i);
+    }
+    const int total = part[1023];
+    if (tid == 0) a.prefix[BK] = total;
+    __threadfence_block();
+    __syncthreads();
+    const unsigned long long draw = *a.counter;
+    if (tid < a.batch) {
+        int e = 0, k = 0, agent = 0, boot = 0;
+        float ret = 0.f, bw = 1.f;
+        if (total > 0) {
+            unsigned long long z = a.seed + draw * 0x9E3779B97F4A7C15ull + (unsigned long long)(tid + 1) * 0xD1B54A32D192ED03ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            const int pick = (int)(((z >> 32) * (unsigned long long)total) >> 32);       // uniform in [0, total)
+            int l = 0, h = BK;                             // last record whose prefix is <= pick (records without pairs share
+            while (h - l > 1) {                            // their successor's prefix and are skipped)
+                const int m = (l + h) >> 1;
+                if (a.prefix[m] <= pick) l = m;
+                else h = m;
+            }
+            int rank = pick - a.prefix[l];
+            e = l / K, k = l - e * K;
+            for (int w = 0; w < a.W; ++w) {                // the rank-th acting agent in id order
+                unsigned long long m = a.rp.acted[(size_t)l * a.W + w];
+                const int c = __popcll(m);
+                if (rank >= c) { rank -= c; continue; }
+                for (int r = 0; r < rank; ++r) m &= m - 1;
+                agent = 64 * w + __ffsll((long long)m) - 1;
+                break;
+            }
+            // the n-step walk (replay.RoundReplay.sample's loop, same operation order in fp32)
+            const int filled = min(a.rp.cursor[e], K), newest = (int)(((long long)a.rp.cursor[e] - 1) % K);
+            const int ep0 = a.rp.episode[(size_t)e * K + k];
+            const int aw = agent >> 6;
+            const unsigned long long abit = 1ull << (agent & 63);
+            bool alive = true;
+            int kk = k;
+            boot = k;
+            for (int j = 0; j < a.n_step; ++j) {
+                const size_t rec = (size_t)e * K + kk;
+                const bool ok = alive && a.rp.episode[rec] == ep0 && (a.rp.acted[rec * a.W + aw] & abit) && kk < filled;
+                if (ok) {
+                    ret = ret + a.disc[j] * a.rp.rew[rec * a.n + agent];
+                    boot = kk;
+                    bw = a.disc[j + 1];
+                }
+                const bool finished = ok && (a.rp.done[rec * a.W + aw] & abit);
+                if (finished) bw = 0.f;
+                alive = ok && !finished && kk != newest;
+                kk = kk + 1 == K ? 0 : kk + 1;
+            }
+        }
+        s_env[tid] = e, s_slot[tid] = k, s_agent[tid] = agent, s_boot[tid] = boot;
+        a.out.env[tid] = e, a.out.slot[tid] = k, a.out.agent[tid] = agent;
+        a.out.act[tid] = (long long)a.rp.act[((size_t)e * K + k) * a.n + agent];
+        a.out.ret[tid] = ret, a.out.boot_w[tid] = bw;
+    }
+    __syncthreads();
+    const int width = 8 * a.n, row = width + 1;
+    for (int i = tid; i < a.batch * row; i += 1024) {
+        const int sidx = i / row, c = i - sidx * row;
+        const size_t base = (size_t)s_env[sidx] * K;
+        a.out.obs[i] = c < width ? a.rp.obs[(base + s_slot[sidx]) * width + c] : (float)s_agent[sidx];
+        a.out.boot_obs[i] = c < width ? a.rp.obs_next[(base + s_boot[sidx]) * width + c] : (float)s_agent[sidx];
+    }
+    if (tid == 0) *a.counter = draw + 1;
+}
+
+mel_status mel_replay_sample(const mel_round_replay* replay, int64_t n_envs, int32_t n_nodes, int32_t batch, int32_t n_step,
+                             const float* discount, uint64_t seed, uint64_t* draw_counter, int32_t* scratch,
+                             const mel_replay_batch* out, void* stream) {
+    if (!replay || !discount || !draw_counter || !scratch || !out) return fail(MEL_ERR_INVALID_ARG, "mel_replay_sample: null argument");
+    if (replay->capacity < 1 || !replay->obs || !replay->obs_next || !replay->acted || !replay->done || !replay->act || !replay->rew ||
+        !replay->episode || !replay->cursor)
+        return fail(MEL_ERR_INVALID_ARG, "incomplete replay block");
+    if (!out->obs || !out->boot_obs || !out->act || !out->ret || !out->boot_w || !out->env || !out->slot || !out->agent)
+        return fail(MEL_ERR_INVALID_ARG, "incomplete replay batch");
+    if (n_envs < 1 || n_nodes < 1 || n_nodes > MEL_MAX_NODES || batch < 1 || batch > 1024 || n_step < 1 || n_step > MEL_REPLAY_MAX_NSTEP ||
+        n_envs * (int64_t)replay->capacity > (1ll << 24))
+        return fail(MEL_ERR_INVALID_ARG, "mel_replay_sample: batch in [1, 1024], n_step in [1, %d], n_envs * capacity <= 2^24", MEL_REPLAY_MAX_NSTEP);
+    clear_stale_error();
+    ReplaySampleArgs a{};
+    a.rp = *replay, a.out = *out, a.B = (int)n_envs, a.n = n_nodes, a.W = MEL_SET_WORDS(n_nodes), a.batch = batch, a.n_step = n_step;
+    for (int j = 0; j <= n_step; ++j) a.disc[j] = discount[j];
+    a.seed = seed, a.counter = reinterpret_cast<unsigned long long*>(draw_counter), a.prefix = scratch;
+    MEL_LAUNCH(replay_sample_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("replay_sample");
+}
+
 mel_status mel_episode_refill(const mel_episode_stream* st, const mel_graph_pool* graphs, const mel_episode_pool* pool,
                               const mel_env_batch* env, int32_t max_new, int32_t discard, void* stream) {
     return launch_episode_refill(st, graphs, pool, env, max_new, discard, static_cast<hipStream_t>(stream));

@@ -1140,6 +1140,7 @@ size_t mel_abi_sizeof(int32_t which) {
         case 8: return sizeof(mel_round_replay);
         case 9: return sizeof(mel_graph_pool);
         case 10: return sizeof(mel_episode_stream);
+        case 11: return sizeof(mel_replay_batch);
         default: return 0;
     }
 }

@@ -340,6 +340,20 @@ def test_replay_sampling_and_dqn_learner():
                 break
             kk = (kk + 1) % K
         assert abs(ret - want) < 1e-5 and abs(bw - w) < 1e-6
+    # obs / boot_obs rows: the record's obs_matrix (the bootstrap row: obs_next of the LAST slot the walk accepted) | agent id
+    np.testing.assert_array_equal(s["obs"][:, :-1].cpu().numpy(), replay.obs[s["env"], s["slot"]].cpu().numpy())
+    assert torch.equal(s["boot_obs"][:, -1], s["agent"].float()) and s["boot_obs"].shape == s["obs"].shape
+    # the one-launch sampler (mel_replay_sample) is uniform over (record, acting agent) pairs: 64 batches of 1024 draws against the
+    # pair counts per env (the ring is full: every slot valid), and every call advances the device-side draw counter
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    draws = torch.cat([replay.sample(1024, n_step, gamma, gen)["env"] for _ in range(64)])
+    pairs = np.array([[bin(int(m)).count("1") for m in row] for row in acted]).sum(axis=1).astype(np.float64)
+    freq = np.bincount(draws.cpu().numpy(), minlength=B).astype(np.float64)
+    expect = pairs / pairs.sum() * freq.sum()
+    chi2 = float(((freq - expect) ** 2 / expect).sum())
+    assert chi2 < 2.0 * B, (chi2, B)                      # B - 1 degrees of freedom: mean B - 1, sd ~ sqrt(2 B)
+    a, b = replay.sample(256, n_step, gamma, gen), replay.sample(256, n_step, gamma, gen)
+    assert not torch.equal(a["env"] * K + a["slot"], b["env"] * K + b["slot"])
     learner = DQNLearner(policy, replay, batch_size=64, n_step=n_step, gamma=gamma, seed=2)
     before = torch.cat([p.detach().flatten().clone() for p in net.parameters()])
     losses = [learner.step()["loss"] for _ in range(5)]
