@@ -278,11 +278,12 @@ mel_status mel_transpose_f32(const float* src, int32_t ld_src, int64_t rows, int
  * mel_gat_forward: out = relu(conv(x) + bias) given the projections (kind MEL_CONV_GATV2: xl = lin_l(x) sources,
  *   xr = lin_r(x) targets, att [HC], self-loops added, l_dgn.py:125-126; MEL_CONV_TRANSFORMER: xl = keys,
  *   xv = values, xr = queries, no self-loops, bias null, dgn_r.py:103-104).
- * mel_gat_backward: grad_out -> dxl (dxv) dxr datt dbias.  dxl / dxv / dxr are WRITTEN (deterministic sums: the source rows'
- *   gradients are gathered target by target, no atomics); datt / dbias must be ZERO on entry (a few thousand fp32 atomics,
- *   so their last bits depend on the order of arrival).  stats: device scratch, bs * n_nodes * heads * 4 floats.
+ * mel_gat_backward: grad_out -> dxl (dxv) dxr datt dbias, all WRITTEN, all deterministic sums (the source rows' gradients are
+ *   gathered target by target; d att / d bias are summed per workgroup and then over the workgroups in a fixed order: no
+ *   atomics).  stats: device scratch, bs * n_nodes * heads * 4 + MEL_GAT_PARTIAL_GROUPS * 2 * HC floats.
  * mel_pool_forward / backward: hl_dgn.py:105-108, pooled[b] = max / mean / add over nodes of x * dm;
  *   arg [bs, HC] int32 = node of the first maximum (max only). */
+#define MEL_GAT_PARTIAL_GROUPS 256
 mel_status mel_radius_graph(const float* obs, int64_t bs, int32_t n_nodes, int32_t obs_stride, int32_t in_dim,
                             uint64_t* adj, void* stream);
 mel_status mel_gat_forward(const float* xl, const float* xv, const float* xr, const float* att, const float* bias,
@@ -606,6 +607,25 @@ mel_status mel_replay_sample(const mel_round_replay* replay, int64_t n_envs, int
                              const float* discount, uint64_t seed, uint64_t* draw_counter, int32_t* scratch,
                              const mel_replay_batch* out, void* stream);
 
+/* One Adam update of up to MEL_ADAM_MAX_TENSORS parameter tensors in one launch ([3P] torch.optim.Adam as the reference
+ * configures it, l_dgn.py:207: no amsgrad, L2 weight decay): exp_avg <- lerp(exp_avg, g, 1 - beta1); exp_avg_sq <- beta2 exp_avg_sq
+ * + (1 - beta2) g^2; param <- param - lr / (1 - beta1^t) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps).  All pointers
+ * device fp32.  step[i]: the tensor's step counter as torch keeps it in capturable mode (device fp32 scalar, the number of updates
+ * DONE: the launch uses t = *step + 1 and a second small launch stores it back) - or NULL for all tensors, then t = host_step. */
+#define MEL_ADAM_MAX_TENSORS 64
+typedef struct mel_adam_tensors {
+    int32_t      count;
+    int32_t      reserved;
+    float*       param[MEL_ADAM_MAX_TENSORS];
+    const float* grad[MEL_ADAM_MAX_TENSORS];
+    float*       exp_avg[MEL_ADAM_MAX_TENSORS];
+    float*       exp_avg_sq[MEL_ADAM_MAX_TENSORS];
+    float*       step[MEL_ADAM_MAX_TENSORS];
+    int64_t      numel[MEL_ADAM_MAX_TENSORS];
+} mel_adam_tensors;
+mel_status mel_adam_step(const mel_adam_tensors* t, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         double host_step, void* stream);
+
 /* One whole env ROUND per launch for every env of the batch (round-batched loop): replays, in the
  * reference's AEC order, the dead-agent steps and one GraphEnv.step per active agent with that agent's
  * action until the world step fires or the episode ends (then the env is reset to
@@ -659,7 +679,7 @@ int32_t    mel_prof_read(void* prof, double* ms_sum, int64_t* count);
 const char* mel_last_error(void);
 /* sizeof() of the structs of this header as the library was compiled, for binding authors to check their mirrors
  * against: which = 0 mel_linear, 1 mel_gatv2, 2 mel_mlp, 3 mel_weights, 4 mel_select, 5 mel_env_batch,
- * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay, 9 mel_graph_pool, 10 mel_episode_stream, 11 mel_replay_batch;
+ * 6 mel_episode_pool, 7 mel_env_obs, 8 mel_round_replay, 9 mel_graph_pool, 10 mel_episode_stream, 11 mel_replay_batch, 12 mel_adam_tensors;
  * 0 for anything else. */
 size_t mel_abi_sizeof(int32_t which);
 const char* mel_version(void);

@@ -36,7 +36,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
 
 # every symbol include/melissa_hip.h declares
 EXPORTS = ("mel_wait_counter", "mel_feature_tables_bytes", "mel_prepare_feature_tables", "mel_prepared_weights_bytes", "mel_prepare_weights", "mel_transpose_f32", "mel_episode_refill", "mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
-           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_gemm_f32_splitk", "mel_gemm_f32_split", "mel_replay_sample", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_gemm_f32_splitk", "mel_gemm_f32_split", "mel_replay_sample", "mel_adam_step", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
@@ -88,6 +88,16 @@ class MelRoundReplay(C.Structure):
 class MelReplayBatch(C.Structure):
     _fields_ = [("obs", C.c_void_p), ("boot_obs", C.c_void_p), ("act", C.c_void_p), ("ret", C.c_void_p), ("boot_w", C.c_void_p),
                 ("env", C.c_void_p), ("slot", C.c_void_p), ("agent", C.c_void_p)]
+
+
+ADAM_MAX_TENSORS = 64
+
+
+class MelAdamTensors(C.Structure):
+    _fields_ = [("count", C.c_int32), ("reserved", C.c_int32), ("param", C.c_void_p * ADAM_MAX_TENSORS),
+                ("grad", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS), ("step", C.c_void_p * ADAM_MAX_TENSORS),
+                ("numel", C.c_int64 * ADAM_MAX_TENSORS)]
 
 
 class MelEnvBatch(C.Structure):
@@ -226,6 +236,8 @@ def load(build_if_missing: bool = True):
     lib.mel_env_step.argtypes = [E, P, vp, vp, i64, O, vp, i32, vp]
     lib.mel_env_round.restype = i32
     lib.mel_env_round.argtypes = [E, P, vp, vp, vp, vp, i32, i32, vp, C.POINTER(MelRoundReplay), vp]
+    lib.mel_adam_step.restype = i32
+    lib.mel_adam_step.argtypes = [C.POINTER(MelAdamTensors), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_double, vp]
     lib.mel_replay_sample.restype = i32
     lib.mel_replay_sample.argtypes = [C.POINTER(MelRoundReplay), i64, i32, i32, i32, C.POINTER(C.c_float), C.c_uint64, vp, vp,
                                       C.POINTER(MelReplayBatch), vp]

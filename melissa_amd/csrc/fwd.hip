@@ -1141,6 +1141,7 @@ size_t mel_abi_sizeof(int32_t which) {
         case 9: return sizeof(mel_graph_pool);
         case 10: return sizeof(mel_episode_stream);
         case 11: return sizeof(mel_replay_batch);
+        case 12: return sizeof(mel_adam_tensors);
         default: return 0;
     }
 }

@@ -82,8 +82,9 @@ struct GradArgs {
     float* dxr;             // written by the targets kernel
     float* stats;           // [rows, heads, 4] scratch: m_i, 1 / (l_i + eps), S_i per head (targets kernel -> sources kernel)
     int heads;
-    float* datt;            // [HC] zero-initialised
-    float* dbias;           // [HC] zero-initialised, or null
+    float* datt;            // [HC] written by gat_reduce_partials_kernel
+    float* dbias;           // [HC] likewise, or null
+    float* partials;        // [workgroups of the targets kernel][2][HC]: their sums of d att | d bias
 };
 
 template <int VPL, int KIND>
@@ -227,11 +228,31 @@ __global__ __launch_bounds__(256) void gat_backward_targets_kernel(GradArgs a) {
             st[0] = m, st[1] = inv, st[2] = S;
         }
     }
+    // d att / d bias: the workgroup's four waves are summed in LDS (in wave order) and the sum goes to THIS workgroup's row of
+    // the partials; gat_reduce_partials_kernel adds the rows in workgroup order.  (One atomicAdd per lane and wave onto the same
+    // 2 HC addresses was 1.6 M contended atomics for a batch of 32 graphs: 317 us of a 1.1 ms update - and their order of
+    // arrival made the last bits of these two gradients differ from run to run.)
+    __shared__ float red[4][2][HC];
+    const int w = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        if (KIND == MEL_CONV_GATV2) atomicAdd(a.datt + lane * VPL + i, datt.v[i]);
-        if (a.dbias) atomicAdd(a.dbias + lane * VPL + i, dbias.v[i]);
+    for (int i = 0; i < VPL; ++i) red[w][0][lane * VPL + i] = datt.v[i], red[w][1][lane * VPL + i] = dbias.v[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * HC; c += 256) {
+        const int which = c / HC, k = c - which * HC;
+        a.partials[((size_t)blockIdx.x * 2 + which) * HC + k] = ((red[0][which][k] + red[1][which][k]) + red[2][which][k]) + red[3][which][k];
     }
+}
+
+// rows of [workgroups][2][HC] partial sums -> datt, dbias (fixed order: deterministic)
+__global__ __launch_bounds__(256) void gat_reduce_partials_kernel(const float* __restrict__ partials, int groups, int hc, float* datt, float* dbias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * hc) return;
+    const int which = c / hc, k = c - which * hc;
+    float* dst = which ? dbias : datt;
+    if (!dst) return;
+    float sum = 0.f;
+    for (int g = 0; g < groups; ++g) sum += partials[((size_t)g * 2 + which) * hc + k];
+    dst[k] = sum;
 }
 
 // gradient of the SOURCE rows: d x_l[j] (GATv2) / d k[j], d v[j] (TransformerConv), one wave per source row j
@@ -384,9 +405,81 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
         if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][ty + 8 * k];
     }
 }
+// ---- Adam, every parameter tensor of a group in ONE launch ([3P] torch.optim.Adam's update, l_dgn.py:207: the optimizer the
+// reference trains with).  torch's capturable form - the one a HIP-graph capture needs - evaluates the bias corrections with a
+// dozen one-element launches PER PARAMETER TENSOR (~200 launches of a 300-launch update); here the step counters stay torch's
+// own state tensors, read by this kernel and advanced by a second one-workgroup launch.
+struct AdamArgs {
+    mel_adam_tensors t;
+    float lr, beta1, beta2, eps, weight_decay;
+    float bc1, bc2_sqrt;          // host-evaluated (eager form: the step counter is a host value), unused with device counters
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    const int ti = blockIdx.y;
+    float* __restrict__ p = a.t.param[ti];
+    const float* __restrict__ g = a.t.grad[ti];
+    float* __restrict__ m = a.t.exp_avg[ti];
+    float* __restrict__ v = a.t.exp_avg_sq[ti];
+    float bc1 = a.bc1, bc2s = a.bc2_sqrt;
+    if (a.t.step[ti]) {
+        const float step = *a.t.step[ti] + 1.0f;
+        bc1 = 1.0f - powf(a.beta1, step);
+        bc2s = sqrtf(1.0f - powf(a.beta2, step));
+    }
+    const float step_size = a.lr / bc1;
+    const long n = a.t.numel[ti];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (a.weight_decay != 0.f) gi = gi + a.weight_decay * pi;
+        const float mi = m[i] + (gi - m[i]) * (1.0f - a.beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * a.beta2 + ((1.0f - a.beta2) * gi) * gi;         // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vi) / bc2s + a.eps;
+        m[i] = mi, v[i] = vi;
+        p[i] = pi + (-step_size) * (mi / denom);                                // addcdiv_(exp_avg, denom, value=-step_size)
+    }
+}
+
+__global__ void adam_bump_kernel(mel_adam_tensors t) {
+    const int i = threadIdx.x;
+    if (i < t.count && t.step[i]) {
+        bool first = true;                                   // (tensors may share one counter: bump it once)
+        for (int k = 0; k < i; ++k) first = first && t.step[k] != t.step[i];
+        if (first) *t.step[i] += 1.0f;
+    }
+}
+
 }  // namespace mel
 
 extern "C" {
+
+mel_status mel_adam_step(const mel_adam_tensors* t, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         double host_step, void* stream) {
+    if (!t || t->count < 1 || t->count > MEL_ADAM_MAX_TENSORS) return fail(MEL_ERR_INVALID_ARG, "mel_adam_step: 1 .. %d tensors per call", MEL_ADAM_MAX_TENSORS);
+    bool dev_steps = t->step[0] != nullptr;
+    for (int i = 0; i < t->count; ++i) {
+        if (!t->param[i] || !t->grad[i] || !t->exp_avg[i] || !t->exp_avg_sq[i] || t->numel[i] < 1)
+            return fail(MEL_ERR_INVALID_ARG, "mel_adam_step: tensor %d incomplete", i);
+        if ((t->step[i] != nullptr) != dev_steps) return fail(MEL_ERR_INVALID_ARG, "mel_adam_step: step counters on the device for all tensors or for none");
+    }
+    if (!dev_steps && host_step < 1.0) return fail(MEL_ERR_INVALID_ARG, "mel_adam_step: host_step is the number of THIS update (>= 1)");
+    clear_stale_error();
+    AdamArgs a{};
+    a.t = *t, a.lr = lr, a.beta1 = beta1, a.beta2 = beta2, a.eps = eps, a.weight_decay = weight_decay;
+    if (!dev_steps) {                                        // as torch's eager form: Python doubles, then fp32 tensors ops
+        a.bc1 = (float)(1.0 - pow((double)beta1, host_step));
+        a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, host_step));
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MEL_LAUNCH(adam_kernel, dim3(64, t->count), dim3(256), 0, s, a);
+    if (mel_status st = check_launch("mel_adam_step")) return st;
+    if (dev_steps) {
+        MEL_LAUNCH(adam_bump_kernel, dim3(1), dim3(MEL_ADAM_MAX_TENSORS), 0, s, a.t);
+        return check_launch("mel_adam_step (counters)");
+    }
+    return MEL_OK;
+}
 
 mel_status mel_transpose_f32(const float* src, int32_t ld_src, int64_t rows, int32_t cols, float* dst, int32_t ld_dst,
                              void* stream) {
@@ -431,11 +524,14 @@ mel_status mel_gat_backward(const float* xl, const float* xv, const float* xr, c
     a.scale = 1.0f / sqrtf((float)channels);
     a.out = const_cast<float*>(out), a.gout = grad_out, a.dxl = dxl, a.dxv = dxv, a.dxr = dxr, a.datt = datt, a.dbias = dbias;
     a.stats = stats, a.heads = heads;
+    a.partials = stats + (size_t)a.rows * heads * 4;           // [MEL_GAT_PARTIAL_GROUPS][2][HC] behind the per-target statistics
     hipStream_t s = static_cast<hipStream_t>(stream);
     int grid = (a.rows + 3) / 4;
-    if (grid > 2048) grid = 2048;                 // grid-stride: bounds the number of datt / dbias atomics
+    if (grid > MEL_GAT_PARTIAL_GROUPS) grid = MEL_GAT_PARTIAL_GROUPS;      // grid-stride over the target rows
     MEL_GRAD_DISPATCH(gat_backward_targets_kernel, grid)
     if (mel_status st = check_launch("mel_gat_backward (targets)")) return st;
+    MEL_LAUNCH(gat_reduce_partials_kernel, dim3((2 * hc + 255) / 256), dim3(256), 0, s, a.partials, grid, hc, datt, dbias);
+    if (mel_status st = check_launch("mel_gat_backward (d att, d bias)")) return st;
     const int grid_s = (a.rows + 3) / 4;
     MEL_GRAD_DISPATCH(gat_backward_sources_kernel, grid_s)
     return check_launch("mel_gat_backward (sources)");

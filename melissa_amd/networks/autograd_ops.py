@@ -61,9 +61,10 @@ class _GatAttention(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dxl, dxr = torch.empty_like(xl), torch.empty_like(xr)            # written, not accumulated (no atomics on rows)
         dxv = torch.empty_like(xv) if xv is not None else None
-        stats = torch.empty(xl.shape[0] * heads * 4, dtype=torch.float32, device=xl.device)      # per (target, head): m, 1/l, S
-        datt = torch.zeros(heads * channels, dtype=torch.float32, device=xl.device) if att is not None else None
-        dbias = torch.zeros(heads * channels, dtype=torch.float32, device=xl.device) if has_bias else None
+        # scratch: per (target, head) m, 1/l, S + the workgroups' partial sums of d att | d bias (MEL_GAT_PARTIAL_GROUPS rows)
+        stats = torch.empty(xl.shape[0] * heads * 4 + 256 * 2 * heads * channels, dtype=torch.float32, device=xl.device)
+        datt = torch.empty(heads * channels, dtype=torch.float32, device=xl.device) if att is not None else None
+        dbias = torch.empty(heads * channels, dtype=torch.float32, device=xl.device) if has_bias else None
         p = lambda t: t.data_ptr() if t is not None else None
         _lib.check(lib.mel_gat_backward(xl.data_ptr(), p(xv), xr.data_ptr(), p(att), adj.data_ptr(), out.data_ptr(),
                                         grad_out.data_ptr(), xl.shape[0] // n_nodes, n_nodes, heads, channels, kind,

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .optim import adam_step
 
 
 class Batch(dict):
@@ -119,7 +120,7 @@ class DQNPolicy(nn.Module):
         loss = self.loss_backward(batch)
         if grad_hook is not None:
             grad_hook(self.model)
-        self.optim.step()
+        adam_step(self.optim)      # torch.optim.Adam's update on its own state, one launch (melissa_amd.optim)
         self._iter += 1
         return {"loss": float(loss)}
 
@@ -160,7 +161,7 @@ class DGNPolicy(DQNPolicy):
         loss = self.loss_backward(batch)
         if grad_hook is not None:
             grad_hook(self.model)
-        self.optim.step()
+        adam_step(self.optim)      # torch.optim.Adam's update on its own state, one launch (melissa_amd.optim)
         self._iter += 1
         return {"loss": float(loss)}
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .optim import adam_step
 
 
 class RoundReplay:
@@ -262,7 +263,7 @@ class CapturedUpdate:
                 policy.loss_backward(batch)
                 if self.collective:
                     hook.pack(), hook.reduce(), hook.unpack()
-                opt.step()
+                adam_step(opt)
                 policy._iter += 1
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -274,13 +275,13 @@ class CapturedUpdate:
             if self.collective:
                 hook.pack()
             else:
-                opt.step()
+                adam_step(opt)
         self.graph_b = None
         if self.collective:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
                 hook.unpack()
-                opt.step()
+                adam_step(opt)
         L.last_batch = self.batch
 
     def _sync_target(self):

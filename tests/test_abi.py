@@ -31,7 +31,7 @@ def test_struct_sizes_match_header(lib):
     # every mirror against sizeof() as the library was compiled
     mirrors = [_lib.MelLinear, _lib.MelGatv2, _lib.MelMlp, _lib.MelWeights, _lib.MelSelect, _lib.MelEnvBatch,
                _lib.MelEpisodePool, _lib.MelEnvObs, _lib.MelRoundReplay, _lib.MelGraphPool, _lib.MelEpisodeStream,
-               _lib.MelReplayBatch]
+               _lib.MelReplayBatch, _lib.MelAdamTensors]
     for which, cls in enumerate(mirrors):
         assert C.sizeof(cls) == lib.mel_abi_sizeof(which), cls.__name__
     assert lib.mel_abi_sizeof(99) == 0

@@ -3,7 +3,7 @@ the GATv2 / TransformerConv edge softmax + aggregation and of the graph pool, th
 against torch autograd THROUGH THE ORACLE (oracle/net_oracle.py is plain differentiable torch: the weights of the
 restatement are made leaves and the same loss is back-propagated on the CPU).
 Tolerance: forward 1e-4 absolute (the inference bar); gradients 2e-4 relative to the largest gradient entry of the
-tensor (fp32 atomics reorder sums; the CPU oracle itself rounds differently)."""
+tensor (the sums run in another order than the CPU oracle's, which itself rounds differently)."""
 import numpy as np
 import pytest
 import torch
@@ -177,3 +177,43 @@ def test_learn_path_dense_layers_run_on_the_library_gemm(monkeypatch):
         net.torch_forward(obs).sum().backward()
         assert seen and all(s[1] == 5 or s[0] <= 2 for s in seen), (model, seen)
         assert all(p.grad is not None for n_, p in net.named_parameters() if "lin_skip" not in n_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weight_decay", [0.0, 1e-2])
+def test_fused_adam_step_is_torch_adam(weight_decay):
+    """melissa_amd.optim.adam_step: torch.optim.Adam's update on torch's own optimizer state in one launch - against
+    torch.optim.Adam itself over eight updates on the same gradients, in the eager form (host step counters) and in the
+    capturable form (device step counters, the one a HIP-graph capture uses), and the state a twin optimizer loads from it."""
+    import copy
+    from melissa_amd.optim import adam_step
+    torch.manual_seed(4)
+    shapes = [(128, 5), (128,), (512, 128), (4, 128), (128, 1152), (1,), (3, 128)]
+    base = [torch.randn(*s, device="cuda") for s in shapes]
+
+    def make(capturable):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        return ps, torch.optim.Adam(ps, lr=1e-3, weight_decay=weight_decay, capturable=capturable)
+
+    ref_p, ref = make(False)
+    ref._mel_disable_fused = True
+    runs = [make(False), make(True)]
+    for step in range(8):
+        grads = [torch.randn(*s, device="cuda") * (0.1 if step % 2 else 10.0) for s in shapes]
+        for ps, opt in [(ref_p, ref)] + runs:
+            for p, g in zip(ps, grads):
+                p.grad = g.clone()
+        ref.step()
+        for ps, opt in runs:
+            adam_step(opt)                       # (the first call is torch's own step: it creates the state)
+        for ps, opt in runs:
+            for p, q in zip(ps, ref_p):
+                assert float((p - q).detach().abs().max()) <= 2e-7 * max(1.0, float(q.detach().abs().max())), step
+    for ps, opt in runs:
+        for p, q in zip(ps, ref_p):
+            np.testing.assert_allclose(opt.state[p]["exp_avg"].cpu().numpy(), ref.state[q]["exp_avg"].cpu().numpy(), rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(opt.state[p]["exp_avg_sq"].cpu().numpy(), ref.state[q]["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-5)
+            assert float(opt.state[p]["step"]) == 8.0
+    twin_p, twin = make(False)
+    twin.load_state_dict(copy.deepcopy(runs[0][1].state_dict()))
+    assert all(float(twin.state[p]["step"]) == 8.0 for p in twin_p)
