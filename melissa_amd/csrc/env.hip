@@ -984,7 +984,7 @@ mel_status mel_env_round(mel_env_batch* env, const mel_episode_pool* pool, const
 // Uniform over (record, acting agent) pairs with replacement, then the n-step walk of [3P] tianshou's compute_nstep_return as the
 // reference configures it (l_dgn.py:246-261, estimation_step): follow the agent through consecutive ring slots while the
 // episode is the same and it keeps acting.  One 1 024-thread workgroup: (1) per-record pair counts and their exclusive prefix
-// sums, (2) one thread per sample: a counter-based draw (splitmix64 of seed, the device-side draw counter, the sample index),
+// sums (chunks of 1 024 consecutive records: coalesced loads, shuffle scans), (2) one thread per sample: a counter-based draw (splitmix64 of seed, the device-side draw counter, the sample index),
 // binary search in the prefix sums, the rank-th member of the record's acted set, the walk, (3) all threads copy the sampled
 // observation rows.  No host value enters but the seed: replayable from a HIP graph, the draw counter advances on the device.
 struct ReplaySampleArgs {
@@ -1007,26 +1007,45 @@ __device__ __forceinline__ int replay_pairs(const ReplaySampleArgs& a, int rec) 
 }
 
 __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplaySampleArgs a) {
-    __shared__ int part[1024];
+    __shared__ int wave_tot[16];
     __shared__ int s_env[1024], s_slot[1024], s_agent[1024], s_boot[1024];
     const int tid = threadIdx.x, K = a.rp.capacity, BK = a.B * K;
-    const int per = (BK + 1023) / 1024, lo = min(tid * per, BK), hi = min(lo + per, BK);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += replay_pairs(a, i);
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the 1 024 partial sums
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    // (1) pair counts of consecutive records by consecutive threads (coalesced, sixteen chunks of 1 024 records in flight per
+    // thread), then per chunk an exclusive scan: inside the wave by shuffles, across the 16 waves through LDS
+    int run = 0;
+    for (int c0 = 0; c0 < BK; c0 += 16 * 1024) {
+        int cnt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = c0 + j * 1024 + tid;
+            cnt[j] = i < BK ? replay_pairs(a, i) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (c0 + j * 1024 >= BK) break;                 // (uniform)
+            int incl = cnt[j];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (lane == 63) wave_tot[wv] = incl;
+            __syncthreads();
+            int before = 0, total_c = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int t = wave_tot[k];
+                before += k < wv ? t : 0;
+                total_c += t;
+            }
+            const int i = c0 + j * 1024 + tid;
+            if (i < BK) a.prefix[i] = run + before + incl - cnt[j];
+            run += total_c;
+            __syncthreads();
+        }
     }
-    int run = part[tid] - sum;
-    for (int i = lo; i < hi; ++i) {
-        a.prefix[i] = run;
-        run += replay_pairs(a, i);
-    }
-    const int total = part[1023];
+    const int total = run;
     if (tid == 0) a.prefix[BK] = total;
     __threadfence_block();
     __syncthreads();

@@ -167,33 +167,37 @@ def hip_linear_supported(in_features: int, out_features: int) -> bool:
 
 class _HipLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu):
         x = x.contiguous()
         w = weight.contiguous()
         y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
         if x.shape[0]:
-            _gemm(x, w, bias, y)
-        ctx.save_for_backward(x, w)
+            _gemm(x, w, bias, y, relu=relu)                 # relu(x W^T + b) in the GEMM's epilogue: no separate launch
+        ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
+        if y is not None:                                   # relu': the gradient of the rows' positive outputs
+            dy = torch.ops.aten.threshold_backward(dy.contiguous(), y, 0.0)
         dy = dy.contiguous()
         m = x.shape[0]
         dx = dw = db = None
         if m == 0:
-            return (torch.zeros_like(x), torch.zeros_like(w), torch.zeros(w.shape[0], device=w.device) if ctx.has_bias else None)
+            return (torch.zeros_like(x), torch.zeros_like(w), torch.zeros(w.shape[0], device=w.device) if ctx.has_bias else None,
+                    None)
         if ctx.needs_input_grad[0]:                       # dX [M, K] = dY [M, N] . W [N, K]: contraction over N
             dx = _gemm(dy, _transpose(w), None, torch.empty_like(x))
         if ctx.needs_input_grad[1]:                       # dW [N, K] = dY^T [N, M] . X [M, K]: contraction over M (padded to 32)
             dw = _weight_grad(dy, x, w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=0)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def hip_linear(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
-    """``F.linear(x, weight, bias)`` on the library's fp32-MFMA GEMM with its own backward (x: CUDA fp32 [M, K])."""
-    return _HipLinear.apply(x, weight, bias)
+def hip_linear(x: torch.Tensor, weight: torch.Tensor, bias, relu: bool = False) -> torch.Tensor:
+    """``F.linear(x, weight, bias)`` - ``relu=True``: ``F.relu`` of it, in the same launch - on the library's fp32-MFMA GEMM with
+    its own backward (x: CUDA fp32 [M, K])."""
+    return _HipLinear.apply(x, weight, bias, relu)

@@ -480,22 +480,36 @@ def learn_adjacency(obs: torch.Tensor, pos: torch.Tensor, n: int, input_dim: int
     return radius_adjacency(pos)
 
 
-def linear(lin: nn.Linear, x: torch.Tensor, hip: bool) -> torch.Tensor:
-    """``lin(x)`` - on the learn path of a ROCm device through the library's own fp32-MFMA GEMM, forward and backward
-    (autograd_ops.hip_linear), for every layer its tiling takes; ``F.linear`` otherwise (CPU tensors, ``learn_kernels =
-    "dense"``, the 5-wide encoder input and the 2- / 1-wide last head layers)."""
+def linear(lin: nn.Linear, x: torch.Tensor, hip: bool, relu: bool = False) -> torch.Tensor:
+    """``lin(x)`` (``relu``: ``F.relu(lin(x))``) - on the learn path of a ROCm device through the library's own fp32-MFMA GEMM,
+    forward and backward (autograd_ops.hip_linear; the ReLU in the GEMM's epilogue), for every layer its tiling takes;
+    ``F.linear`` otherwise (CPU tensors, ``learn_kernels = "dense"``, the 5-wide encoder input and the 2- / 1-wide last head
+    layers)."""
     if hip and x.dim() == 2 and x.dtype == torch.float32:
         from .autograd_ops import hip_linear, hip_linear_supported
         if hip_linear_supported(lin.in_features, lin.out_features):
-            return hip_linear(x, lin.weight, lin.bias)
-    return lin(x)
+            return hip_linear(x, lin.weight, lin.bias, relu)
+    return F.relu(lin(x)) if relu else lin(x)
 
 
-def mlp(module: "MLP", x: torch.Tensor, hip: bool) -> torch.Tensor:
-    """``module.model(x)`` with its Linear layers routed through :func:`linear`."""
-    for layer in module.model:
-        x = linear(layer, x, hip) if isinstance(layer, nn.Linear) else layer(x)
-    return x
+def mlp(module: "MLP", x: torch.Tensor, hip: bool, final_relu: bool = False) -> torch.Tensor:
+    """``module.model(x)`` with its Linear layers routed through :func:`linear`; a Linear followed by ``nn.ReLU`` is one fused
+    call.  ``final_relu``: ``F.relu`` of the result (the callers' ``F.relu(mlp(...))``), fused into the last Linear."""
+    layers = list(module.model)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        if isinstance(layer, nn.Linear):
+            nxt_relu = i + 1 < len(layers) and type(layers[i + 1]) is nn.ReLU
+            last = i == len(layers) - 1
+            x = linear(layer, x, hip, relu=nxt_relu or (last and final_relu))
+            if last and final_relu:
+                final_relu = False
+            i += 2 if nxt_relu else 1
+        else:
+            x = layer(x)
+            i += 1
+    return F.relu(x) if final_relu else x
 
 
 def conv_relu(conv, x: torch.Tensor, adj, n: int, hip: bool) -> torch.Tensor:
@@ -575,7 +589,7 @@ class GraphQNetwork(HipForwardMixin, nn.Module):
         # (the adjacency kernels take observation rows with an index column: any value, it is not read)
         adj = learn_adjacency(torch.cat([obs_matrix.float(), obs_matrix.new_zeros(G, 1, dtype=torch.float32)], dim=1), pos, n,
                               self.input_dim, hip)
-        x_1 = F.relu(mlp(self.encoder, feats.reshape(G * n, -1), hip))
+        x_1 = mlp(self.encoder, feats.reshape(G * n, -1), hip, final_relu=True)
         x_2 = conv_relu(self.conv1, x_1, adj, n, hip)
         x_3 = conv_relu(self.conv2, x_2 * dm.reshape(G * n, 1), adj, n, hip)
         return self._head(torch.cat([x_1, x_2, x_3], dim=1), hip).view(G, n, -1)
@@ -589,7 +603,7 @@ class GraphQNetwork(HipForwardMixin, nn.Module):
         bs, n = pos.shape[:2]
         hip = use_hip_autograd(self, obs)
         adj = learn_adjacency(obs, pos, n, self.input_dim, hip)
-        x = F.relu(mlp(self.encoder, feats.reshape(bs * n, -1), hip))
+        x = mlp(self.encoder, feats.reshape(bs * n, -1), hip, final_relu=True)
         gi = torch.arange(bs, device=x.device) * n + g
         x_1 = x[gi]
         x = conv_relu(self.conv1, x, adj, n, hip)

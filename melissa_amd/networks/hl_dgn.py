@@ -30,7 +30,7 @@ class HLDGNNetwork(GraphQNetwork):
         pos, feats, dm, _g = unpack(obs, self.input_dim, self.agents_num)
         bs, n = pos.shape[:2]
         hip = use_hip_autograd(self, obs)
-        x = F.relu(mlp(self.encoder, feats.reshape(bs * n, -1), hip))
+        x = mlp(self.encoder, feats.reshape(bs * n, -1), hip, final_relu=True)
         x = conv_relu(self.conv1, x, learn_adjacency(obs, pos, n, self.input_dim, hip), n, hip)
         if hip:
             from .autograd_ops import graph_pool
