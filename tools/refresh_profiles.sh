@@ -18,7 +18,7 @@ echo "pmc write done"
 cd $ROOT
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-extra-legs   (MI355X, round 3, round-batched loop, fp32 results with the precision chosen per launch - MEL_PREC_F32_AUTO -, HIP-graph replay, device episode stream)";
-  echo "# 430 launches per forward kernel = 30 warm-up + 200 timed + 200 stage-timer steps (the stage timer's eager pass launches the same kernels); episode_* = the episode stream's refill on its side stream";
+  echo "# 942 launches per forward kernel = 512 untimed settling rounds + 30 warm-up + 200 timed (four rounds per graph replay) + 200 stage-timer steps (the stage timer's eager pass launches the same kernels); episode_* = the episode stream's refill on its side stream";
   cat $(find $OUT/stats -name '*kernel_stats.csv' | head -1); } > $OUT/${TAG}_round_kernel_stats.csv
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json       # bench.py reads roofline.traffic from profiles/ (hash-checked)
