@@ -65,7 +65,9 @@ def train(model="hl_dgn", n_nodes=20, envs=256, updates=20, rounds_per_update=4,
     venv = HipGraphVectorEnv(envs, n_nodes, graph_pool=graph_list, dynamic_graph=True, device=device, max_moves=48,
                              seed=1000 + rank * envs, construct_like_reference=False)
     replay = RoundReplay(envs, n_nodes, replay_rounds, device)
-    loop = RoundLoop(venv, policy, seed=1000 + rank * envs, eps=eps, replay=replay, ring=ring)
+    # the rounds between two updates replay from one HIP graph (bit-identical to the eager launches: tests/test_gpu_round.py)
+    loop = RoundLoop(venv, policy, seed=1000 + rank * envs, eps=eps, replay=replay, ring=ring,
+                     use_graph=device.type == "cuda" and probe is None, graph_rounds=max(1, rounds_per_update))
     learner = learner_cls(policy, replay, batch_size=batch_size, n_step=n_step, gamma=gamma,
                          grad_hook=parallel.FlatGradAllReducer(net), seed=seed + rank)
     with torch.no_grad():

@@ -284,19 +284,25 @@ def test_graph_replay_matches_eager_launches():
     for use_graph, rounds_per_graph in ((False, 1), (True, 1), (True, 4)):
         venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
                                  construct_like_reference=False)
+        from melissa_amd.replay import RoundReplay
+        replay = RoundReplay(B, n, 8, "cuda")                # (the learner's loops record while they replay graphs)
         loop = RoundLoop(venv, DQNPolicy(net), episodes_per_env=10, seed=3, eps=0.05, use_graph=use_graph,
-                         graph_rounds=rounds_per_graph)
+                         graph_rounds=rounds_per_graph, replay=replay)
         loop.run(2)                      # warm-up + capture of the one-round graph
         loop.run(58)
         torch.cuda.synchronize()
         assert (loop.group_graph is not None) == (rounds_per_graph == 4)
         finals.append((venv.scalars().cpu().numpy().copy(), venv.node_sets().cpu().numpy().copy(),
-                       venv.positions().cpu().numpy().copy(), loop.counters()))
+                       venv.positions().cpu().numpy().copy(), loop.counters(),
+                       [t.cpu().numpy().copy() for t in (replay.obs, replay.obs_next, replay.acted, replay.done, replay.act,
+                                                        replay.rew, replay.episode, replay.cursor)]))
     for other in finals[1:]:
         np.testing.assert_array_equal(finals[0][0], other[0])
         np.testing.assert_array_equal(finals[0][1], other[1])
         np.testing.assert_array_equal(finals[0][2], other[2])
         assert finals[0][3] == other[3]
+        for mine, theirs in zip(finals[0][4], other[4]):
+            np.testing.assert_array_equal(mine, theirs)
     assert finals[0][3]["errors"] == 0 and finals[0][3]["episodes"] > 20 and finals[0][3]["iterations"] == 60
 
 
