@@ -235,6 +235,15 @@ mel_status mel_hldgn_forward(const mel_weights* w, int32_t aggregator, const flo
 mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                         int64_t M, int32_t N, int32_t K, int32_t relu, int32_t tile, void* stream);
 
+/* The learn path's backward products without transposed copies of their operands: Y[m, n] = sum_k A'[m, k] W'[n, k] with
+ * W' = W^T read in place (W'[n, k] = W[k * ldw + n]) and, a_t != 0, A' = A^T likewise (A'[m, k] = A[k * lda + m]).
+ * dX [rows, in] = dY [rows, out] . W [out, in]:  mel_gemm_f32_t(dY, out, 0, W, in, 1, dX, in, rows, in, out);
+ * dW [out, in]  = dY^T . X [rows, in]:           mel_gemm_f32_t(dY, out, 1, X, in, 1, dW, in, out, in, rows).
+ * N % 64 == 0, K % 32 == 0, lda % 4 == ldw % 4 == 0, M % 4 == 0 with a_t; w_t must be 1 (the plain form is mel_gemm_f32).  Same
+ * tile, K order and MFMA sequence as mel_gemm_f32's 64 x 64 kernel on transposed copies: bit-identical sums. */
+mel_status mel_gemm_f32_t(const float* A, int32_t lda, int32_t a_t, const float* W, int32_t ldw, int32_t w_t, float* Y, int32_t ldy,
+                          int64_t M, int32_t N, int32_t K, void* stream);
+
 /* The same product with the contraction cut into `ksplit` equal chunks that run as independent work items and are summed in
  * chunk order afterwards: for the learn path's weight gradients dW = dY^T X, a few dozen output tiles over a contraction as
  * long as the batch has rows (one tile per workgroup would leave most of the chip idle).  K / 32 must be a multiple of

@@ -36,7 +36,7 @@ SET_HAS_MESSAGE, SET_ORIGIN, SET_INTERESTED, SET_SCRIPTED, SET_TRUNCATED, SET_AL
 
 # every symbol include/melissa_hip.h declares
 EXPORTS = ("mel_wait_counter", "mel_feature_tables_bytes", "mel_prepare_feature_tables", "mel_prepared_weights_bytes", "mel_prepare_weights", "mel_transpose_f32", "mel_episode_refill", "mel_abi_sizeof", "mel_radius_graph", "mel_gat_forward", "mel_gat_backward", "mel_pool_forward", "mel_pool_backward",
-           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_gemm_f32_splitk", "mel_gemm_f32_split", "mel_replay_sample", "mel_adam_step", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
+           "mel_gemm_bf16", "mel_convert_bf16", "mel_hldgn_forward_envs", "mel_hldgn_forward_envs_select", "mel_plan_pointers", "mel_select_action_envs", "mel_dgnr_forward", "mel_dgnr_forward_agents", "mel_gemm_f32", "mel_gemm_f32_t", "mel_gemm_f32_splitk", "mel_gemm_f32_split", "mel_replay_sample", "mel_adam_step", "mel_workspace_bytes", "mel_workspace_bytes_agents", "mel_ldgn_forward_agents",
            "mel_select_action_rows", "mel_ldgn_forward", "mel_hldgn_forward", "mel_forward_tap",
            "mel_select_action", "mel_env_state_bytes", "mel_env_bind", "mel_env_reset", "mel_env_step",
            "mel_env_observe", "mel_env_round", "mel_prof_create", "mel_prof_destroy", "mel_prof_attach", "mel_prof_reset",
@@ -186,6 +186,8 @@ def load(build_if_missing: bool = True):
     lib.mel_dgnr_forward_agents.argtypes = [W, vp, i64, i32, i32, vp, i64, vp, vp, C.POINTER(MelSelect), vp, sz, vp]
     lib.mel_hldgn_forward.restype = i32
     lib.mel_hldgn_forward.argtypes = [W, i32, vp, i64, i32, i32, vp, vp, sz, vp]
+    lib.mel_gemm_f32_t.restype = i32
+    lib.mel_gemm_f32_t.argtypes = [vp, i32, i32, vp, i32, i32, vp, i32, i64, i32, i32, vp]
     lib.mel_gemm_f32.restype = i32
     lib.mel_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]
     lib.mel_gemm_f32_split.restype = i32

@@ -1348,6 +1348,23 @@ mel_status mel_gemm_f32(const float* A, int32_t lda, const float* W, const float
     return launch_gemm(g, GEMM_MODE_PLAIN, static_cast<hipStream_t>(stream), "mel_gemm_f32", -1, tile);
 }
 
+mel_status mel_gemm_f32_t(const float* A, int32_t lda, int32_t a_t, const float* W, int32_t ldw, int32_t w_t, float* Y, int32_t ldy,
+                          int64_t M, int32_t N, int32_t K, void* stream) {
+    if (!A || !W || !Y || M < 1 || M > (1ll << 30) || N < 64 || K < 32 || ldy < N)
+        return fail(MEL_ERR_INVALID_ARG, "bad transposed-operand gemm arguments");
+    if (N % 64 || K % GEMM_BK || lda % 4 || ldw % 4 || (a_t ? (M % 4 || lda < M) : lda < K) || (w_t ? ldw < N : ldw < K) || !w_t)
+        return fail(MEL_ERR_UNSUPPORTED, "transposed-operand gemm: N %% 64 == 0, K %% 32 == 0, lda / ldw %% 4 == 0, M %% 4 == 0 with a "
+                                         "transposed A, W transposed (the plain form is mel_gemm_f32)");
+    clear_stale_error();
+    GemmTArgs g{A, W, Y, lda, ldw, ldy, (int)M, N, K};
+    const long grid = ((M + 63) / 64) * (N / 64);
+    if (grid > (1l << 30)) return fail(MEL_ERR_INVALID_ARG, "transposed-operand gemm: too many tiles");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a_t) MEL_LAUNCH((gemm_f32_t_kernel<true, true>), dim3((int)grid), dim3(256), 0, s, g);
+    else MEL_LAUNCH((gemm_f32_t_kernel<false, true>), dim3((int)grid), dim3(256), 0, s, g);
+    return check_launch("mel_gemm_f32_t");
+}
+
 mel_status mel_gemm_f32_splitk(const float* A, int32_t lda, const float* W, const float* bias, float* Y, int32_t ldy,
                                int64_t M, int32_t N, int32_t K, int32_t relu, int32_t ksplit, float* parts, int64_t parts_floats,
                                void* stream) {

@@ -332,6 +332,97 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_f32
     gemm_f32_tile<WM, WN, TM, TN, MODE>(batch, (int)blockIdx.x);
 }
 
+// ---- the learn path's backward products WITHOUT transposed copies of their operands -------------------------------------------
+// Y[m, n] = sum_k A'[m, k] W'[n, k] as above, with either operand read TRANSPOSED from memory: A_T: A'[m, k] = A[k * lda + m],
+// W_T: W'[n, k] = W[k * ldw + n].  dX = dY W is <false, true> (W' = W^T), dW = dY^T X is <true, true> (A' = dY^T, W' = X^T):
+// autograd_ops.py used to launch mel_transpose_f32 for each of them (21 launches of a ~150-launch update).  Same 64 x 64 tile,
+// LDS image, K order and MFMA sequence as gemm_f32_tile: the sums are bit-identical to the transposed-copy form.  A transposed
+// tile is staged by 4-row chunks along the operand's contiguous dimension (coalesced 16-byte loads) and scattered into LDS.
+struct GemmTArgs {
+    const float* A;
+    const float* W;
+    float* Y;
+    int lda, ldw, ldy, M, N, K;
+};
+
+template <bool A_T, bool W_T>
+__global__ __launch_bounds__(256, 2) void gemm_f32_t_kernel(GemmTArgs g) {
+    constexpr int BM = 64, BN = 64, T = 256;
+    constexpr int BUF = (BM + BN) * GEMM_LDS_STRIDE;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+    const int nbn = g.N / BN;
+    const int m0 = ((int)blockIdx.x / nbn) * BM, n0 = ((int)blockIdx.x % nbn) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // row-major staging (as gemm_f32_tile): 8 threads per 128-byte row slice, two rows per thread
+    const int crow = tid >> 3, kc = (tid & 7) * 4;
+    // transposed staging: chunk c of 512 = (k = c >> 4, rows 4 (c & 15) .. + 3), two chunks per thread
+    const int tk0 = tid >> 4, tr0 = (tid & 15) * 4;
+    f32x4 a_reg[2], w_reg[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (A_T) {
+                const int row = min(m0 + tr0, g.M - 4);                  // (M % 4 == 0: whole chunks)
+                a_reg[i] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(k0 + tk0 + 16 * i) * g.lda + row);
+            } else {
+                const int row = min(m0 + crow + 32 * i, g.M - 1);
+                a_reg[i] = *reinterpret_cast<const f32x4*>(g.A + (size_t)row * g.lda + k0 + kc);
+            }
+            if constexpr (W_T) w_reg[i] = *reinterpret_cast<const f32x4*>(g.W + (size_t)(k0 + tk0 + 16 * i) * g.ldw + n0 + tr0);
+            else w_reg[i] = *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + crow + 32 * i) * g.ldw + k0 + kc);
+        }
+    };
+    auto stage = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (A_T) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) buf[(tr0 + e) * GEMM_LDS_STRIDE + tk0 + 16 * i] = a_reg[i][e];
+            } else {
+                *reinterpret_cast<f32x4*>(buf + (crow + 32 * i) * GEMM_LDS_STRIDE + kc) = a_reg[i];
+            }
+            float* wb = buf + BM * GEMM_LDS_STRIDE;
+            if constexpr (W_T) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wb[(tr0 + e) * GEMM_LDS_STRIDE + tk0 + 16 * i] = w_reg[i][e];
+            } else {
+                *reinterpret_cast<f32x4*>(wb + (crow + 32 * i) * GEMM_LDS_STRIDE + kc) = w_reg[i];
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int a_off = (wm * 32 + r) * GEMM_LDS_STRIDE + 4 * h;
+    const int w_off = BM * GEMM_LDS_STRIDE + (wn * 32 + r) * GEMM_LDS_STRIDE + 4 * h;
+    fetch(0);
+    stage(lds);
+    __syncthreads();
+    const int KT = g.K / GEMM_BK;
+    for (int kt = 0; kt < KT; ++kt) {
+        const float* cur = lds + (kt & 1) * BUF;
+        const bool more = kt + 1 < KT;
+        if (more) fetch((kt + 1) * GEMM_BK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(cur + a_off + q * 8);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cur + w_off + q * 8);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+        }
+        if (more) stage(lds + ((kt + 1) & 1) * BUF);
+        __syncthreads();
+    }
+    float* col = g.Y + n0 + wn * 32 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 32 + 4 * h + (e & 3) + 8 * (e >> 2);
+        if (m < g.M) col[(size_t)m * g.ldy] = acc[e];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent variant: a fixed grid of workgroups walks the tile list of all problems of the launch.
 // What it buys at the sizes of this path (a few hundred to a few thousand tiles, K as short as 128):

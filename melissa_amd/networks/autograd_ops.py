@@ -17,6 +17,8 @@ These ops need a ROCm device and fail loudly without the library: no CPU fallbac
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib
@@ -126,6 +128,17 @@ def _gemm(a: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, relu: bool 
     return out
 
 
+_COPIES = bool(os.environ.get("MEL_BACKWARD_TRANSPOSED_COPIES"))      # A/B switch: round 2's transposed-copy form
+
+
+def _gemm_t(a: torch.Tensor, a_t: bool, w: torch.Tensor, out: torch.Tensor, m: int, n: int, k: int):
+    """out[m, n] = sum_k A'[m, k] W'[n, k] with W' = w^T read in place and, ``a_t``, A' = a^T likewise (mel_gemm_f32_t): the backward
+    products of a linear layer without transposed copies."""
+    _lib.check(_lib.load().mel_gemm_f32_t(a.data_ptr(), a.stride(0), int(a_t), w.data_ptr(), w.stride(0), 1, out.data_ptr(),
+                                          out.stride(0), m, n, k, _stream(a)), "mel_gemm_f32_t")
+    return out
+
+
 def _gemm_splitk(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, ksplit: int):
     """``_gemm`` with the contraction cut into ``ksplit`` chunks (mel_gemm_f32_splitk): few output tiles, long K."""
     m, k, n = a.shape[0], w.shape[1], w.shape[0]
@@ -188,10 +201,15 @@ class _HipLinear(torch.autograd.Function):
         if m == 0:
             return (torch.zeros_like(x), torch.zeros_like(w), torch.zeros(w.shape[0], device=w.device) if ctx.has_bias else None,
                     None)
-        if ctx.needs_input_grad[0]:                       # dX [M, K] = dY [M, N] . W [N, K]: contraction over N
-            dx = _gemm(dy, _transpose(w), None, torch.empty_like(x))
-        if ctx.needs_input_grad[1]:                       # dW [N, K] = dY^T [N, M] . X [M, K]: contraction over M (padded to 32)
-            dw = _weight_grad(dy, x, w)
+        in_place = not _COPIES
+        if ctx.needs_input_grad[0]:                       # dX [M, K] = dY [M, N] . W [N, K]: contraction over N, W read in place
+            dx = (_gemm_t(dy, False, w, torch.empty_like(x), m, w.shape[1], w.shape[0]) if in_place
+                  else _gemm(dy, _transpose(w), None, torch.empty_like(x)))
+        if ctx.needs_input_grad[1]:                       # dW [N, K] = dY^T [N, M] . X [M, K]: contraction over M
+            if in_place and m % 32 == 0 and m < 2048:     # both operands read transposed in place (mel_gemm_f32_t)
+                dw = _gemm_t(dy, True, x, torch.empty_like(w), w.shape[0], w.shape[1], m)
+            else:                                         # long batches: split-K over the rows (padded transposed copies)
+                dw = _weight_grad(dy, x, w)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(dim=0)
         return dx, dw, db, None

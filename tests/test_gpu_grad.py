@@ -217,3 +217,33 @@ def test_fused_adam_step_is_torch_adam(weight_decay):
     twin_p, twin = make(False)
     twin.load_state_dict(copy.deepcopy(runs[0][1].state_dict()))
     assert all(float(twin.state[p]["step"]) == 8.0 for p in twin_p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,out_f,in_f", [(1600, 128, 128), (32, 128, 1152), (1600, 512, 128), (96, 64, 64), (33, 128, 64)])
+def test_linear_backward_products_without_transposed_copies(rows, out_f, in_f):
+    """mel_gemm_f32_t: dX = dY W and dW = dY^T X with the operands read in place.  Bit-identical to the library's own GEMM on
+    transposed copies (same tile, K order and MFMA sequence) and equal to torch's products within fp32 rounding; hip_linear's
+    backward uses it (rows % 32 != 0 keeps the padded-copy form for dW)."""
+    from melissa_amd.networks import autograd_ops as ops
+    torch.manual_seed(rows + out_f)
+    x = torch.randn(rows, in_f, device="cuda")
+    w = torch.randn(out_f, in_f, device="cuda") / in_f ** 0.5
+    dy = torch.randn(rows, out_f, device="cuda")
+    dx = ops._gemm_t(dy, False, w, torch.empty_like(x), rows, in_f, out_f)
+    want_dx = ops._gemm(dy, ops._transpose(w), None, torch.empty_like(x))
+    assert torch.equal(dx, want_dx)
+    np.testing.assert_allclose(dx.cpu().numpy(), (dy.double() @ w.double()).float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    if rows % 32 == 0:
+        dw = ops._gemm_t(dy, True, x, torch.empty_like(w), out_f, in_f, rows)
+        want_dw = ops._gemm(ops._transpose(dy, 32), ops._transpose(x, 32), None, torch.empty_like(w))
+        assert torch.equal(dw, want_dw)
+        np.testing.assert_allclose(dw.cpu().numpy(), (dy.double().t() @ x.double()).float().cpu().numpy(), rtol=1e-4, atol=2e-4)
+    xg = x.clone().requires_grad_(True)
+    wg = w.clone().requires_grad_(True)
+    ops.hip_linear(xg, wg, None, True).backward(dy)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    torch.relu(torch.nn.functional.linear(xr, wr)).backward(dy)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=1e-4, atol=2e-4)
