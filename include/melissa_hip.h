@@ -265,7 +265,8 @@ mel_status mel_gemm_f32_split(const float* A, int32_t lda, const float* W, const
                               int64_t scratch_bytes, void* stream);
 
 /* The same projection on the bf16 feature path: A [M, lda] and W [N, K] device bf16, bias fp32, fp32
- * accumulation, Y [M, ldy] bf16 (y_f32 = 0) or fp32 (y_f32 = 1); K % 64 == 0, N % 64 == 0, lda % 8 == 0.
+ * accumulation, Y [M, ldy] bf16 (y_f32 = 0) or fp32 (y_f32 = 1); K % 64 == 0, N % 64 == 0, lda % 8 == 0.  tile: 0 = automatic,
+ * 2 = 128 x 128, 3 = the 128 x 256 kernel of the large launches (specialised loader / MFMA wavefronts; N % 256 == 0, N <= 1536).
  * mel_convert_bf16: count (multiple of 8) fp32 values -> bf16, round to nearest even. */
 mel_status mel_gemm_bf16(const void* A, int32_t lda, const void* W, const float* bias, void* Y, int32_t ldy,
                          int64_t M, int32_t N, int32_t K, int32_t relu, int32_t y_f32, int32_t tile, void* stream);

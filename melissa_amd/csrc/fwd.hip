@@ -222,6 +222,37 @@ static void gemm_launch_planes(const GemmArgs* gs, int count, hipStream_t s, int
     }
 }
 
+// gemm_bf16_wide_kernel (gemm_split.hpp): bf16 rows on both sides, 128 x 256 tiles, 64-k stages
+static bool bf16_wide_fit(const GemmArgs* gs, int count) {
+    long ncols = 0;
+    for (int i = 0; i < count; ++i) {
+        const GemmArgs& g = gs[i];
+        if (!g.bf16 || !g.A || g.N % GEMP_BN || g.K % GEMW_BK || g.K / GEMW_BK < 2 || g.lda % 8 || g.rscale || g.ksplit > 1) return false;
+        if (g.W_hi && g.split_n % GEMP_BN) return false;
+        if ((size_t)g.M * (size_t)g.lda * 2 >= ((size_t)1 << 32) || (size_t)GEMP_BN * g.K * 2 >= ((size_t)1 << 32)) return false;
+        ncols += g.N;
+    }
+    return count >= 1 && count <= GEMM_MAX_GROUP && ncols <= GEMP_BIAS_FLOATS;
+}
+template <int TAG>
+static void gemm_launch_bf16_wide_t(const GemmArgs* gs, int count, hipStream_t s) {
+    GemmBatch batch{};
+    batch.count = count;
+    long items = 0;
+    for (int i = 0; i < count; ++i) {
+        batch.p[i] = gs[i];
+        items += ((long)((gs[i].M + 127) / 128) * (gs[i].N / GEMP_BN) + 7) & ~7L;
+    }
+    const long grid = items < 256 ? items : 256;
+    MEL_LAUNCH((gemm_bf16_wide_kernel<TAG>), dim3((int)grid), dim3(768), 0, s, batch);
+}
+static void gemm_launch_bf16_wide(const GemmArgs* gs, int count, hipStream_t s, int tag) {
+    switch (tag) {
+        case 2: gemm_launch_bf16_wide_t<2>(gs, count, s); break;
+        default: gemm_launch_bf16_wide_t<0>(gs, count, s); break;
+    }
+}
+
 static mel_status check_gemm_shape(const GemmArgs& g, const char* what) {
     if (g.split && g.K < 128) return fail(MEL_ERR_UNSUPPORTED, "%s: the split path needs K >= 128 (K=%d)", what, g.K);
     const int bk = g.bf16 ? GEMB_BK : GEMM_BK;
@@ -249,6 +280,11 @@ mel_status launch_gemm(const GemmArgs& g, int mode, hipStream_t stream, const ch
     // 16 000: 17 -> 19 us)
     const bool enc_wide = mode == GEMM_MODE_ENC && force_tile == 0 && g.N % 128 == 0 && (g.bf16 || m_hint >= 20000);
     if (g.bf16) {
+        if (force_tile == 3) {
+            if (mode != GEMM_MODE_PLAIN || !bf16_wide_fit(&g, 1))
+                return fail(MEL_ERR_UNSUPPORTED, "%s: shape does not fit the 128 x 256 bf16 kernel (N %% 256, K %% 64, lda %% 8)", what);
+            gemm_launch_bf16_wide(&g, 1, stream, tag);
+        } else
         if (force_tile == 2 && g.N % 128 == 0) gemm_launch_bf16<2, 2, 2, 2>(&g, 1, mode, stream);
         else if (enc_wide) gemm_launch_bf16<2, 2, 1, 2>(&g, 1, mode, stream);
         else gemm_launch_bf16<2, 2, 1, 1>(&g, 1, mode, stream);
@@ -400,7 +436,15 @@ mel_status launch_gemm_group(const GemmArgs* gs, const long* hints, int count, h
     if (gs[0].bf16) {
         for (int i = 1; i < count; ++i)
             if (!gs[i].bf16) return fail(MEL_ERR_INVALID_ARG, "%s: mixed precisions in one group", what);
-        gemm_launch_bf16<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
+        // large launches: 128 x 256 tiles (conv2 of the bf16 feature path: 97 MB of operands through the L2 instead of 0.5 GB)
+        static const bool wide_off = getenv("MEL_NO_BF16_WIDE") != nullptr;
+        long items = 0;
+        for (int i = 0; i < count; ++i) {
+            const long h = (hints && hints[i] >= 0 && hints[i] <= gs[i].M) ? hints[i] : gs[i].M;
+            items += ((h + 127) / 128) * (gs[i].N / GEMP_BN);
+        }
+        if (!wide_off && items >= MEL_PLANES_FROM && bf16_wide_fit(gs, count)) gemm_launch_bf16_wide(gs, count, stream, tag);
+        else gemm_launch_bf16<2, 2, 1, 1>(gs, count, GEMM_MODE_PLAIN, stream);
         return check_launch(what);
     }
     bool ragged = false;

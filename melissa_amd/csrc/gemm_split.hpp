@@ -902,6 +902,254 @@ __global__ __launch_bounds__(768, 3) void gemm_planes_kernel(GemmBatch batch) {
     }
 }
 
+// ---- the bf16 feature path's large projections: the same workgroup (128 x 256 tile, 8 MFMA + 4 loader waves) on bf16 rows ---------
+// BASELINE's "bf16 feature path" (MEL_PREC_BF16): A [rows, lda] and W [N, K] are bf16 rows as the producers store them (a 64-k
+// stage takes one whole 128-byte line of every row), ONE product per term.  The 64 x 64 one-role kernel streams 0.5 GB of
+// operands through the L2 for conv2 (16 TB/s: its ceiling); this tile needs 97 MB.  Per 64-k stage: 48 KB of operands for 16
+// MFMAs per wave (1 024 matrix cycles per SIMD) - the load path (~20 B / clk), not the pipe, sets the pace.  Three 48 KB LDS
+// stages (128-byte rows, chunk c of row r in slot c ^ ((r >> 1) & 7): conflict-free fragment reads), the loaders two stages
+// ahead (two register sets of twelve 16-byte chunks per thread), fragments of the next stage refreshed sub-step by sub-step while
+// this one's MFMAs run, one barrier per stage; the epilogue stores straight from the accumulators (bf16, or fp32 with y_f32).
+constexpr int GEMW_BK = 64;
+constexpr int GEMW_RC = 8;                            // 16-byte chunks per LDS row and stage
+
+template <int TAG = 0>
+__global__ __launch_bounds__(768, 3) void gemm_bf16_wide_kernel(GemmBatch batch) {
+    constexpr int BM = 128, BN = GEMP_BN, RC = GEMW_RC;
+    constexpr int BUF = (BM + BN) * RC;               // 16-byte chunks per LDS stage
+    __shared__ u32x4 lds[GEMP_STAGES * BUF + GEMP_BIAS_FLOATS / 4];
+    float* bias_s = reinterpret_cast<float*>(lds + GEMP_STAGES * BUF);
+
+    int act[GEMM_MAX_GROUP], pre[GEMM_MAX_GROUP + 1], rows[GEMM_MAX_GROUP], boff[GEMM_MAX_GROUP];
+    pre[0] = 0;
+    {
+        int o = 0;
+#pragma unroll
+        for (int i = 0; i < GEMM_MAX_GROUP; ++i) {
+            act[i] = 0, rows[i] = 0, boff[i] = o;
+            if (i < batch.count) {
+                const GemmArgs& q = batch.p[i];
+                rows[i] = q.M_dev ? min(*q.M_dev, q.M) : q.M;
+                act[i] = ((rows[i] + BM - 1) / BM) * (q.N / BN);
+                for (int n = threadIdx.x; n < q.N; n += 768)
+                    bias_s[o + n] = (q.bias_hi && n >= q.split_n) ? q.bias_hi[n - q.split_n] : (q.bias ? q.bias[n] : 0.f);
+                o += q.N;
+            }
+            pre[i + 1] = pre[i] + ((act[i] + 7) & ~7);
+        }
+    }
+    const int total = pre[GEMM_MAX_GROUP];
+    const int stride = gridDim.x;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // 0-7 MFMA waves, 8-11 loader waves
+
+    auto next_valid = [&](int t) {
+        for (; t < total; t += stride) {
+            int pi = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (t >= pre[k]) pi = k;
+            if (t - pre[pi] < act[pi]) return t;
+        }
+        return total;
+    };
+    struct Meta {
+        int m0, n0, M, pi, KT;
+    };
+    auto meta_of = [&](int t) {
+        int pi = 0;
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+            if (t >= pre[k]) pi = k;
+        const GemmArgs& g = batch.p[pi];
+        const int nbn = g.N / BN;
+        int wg = t - pre[pi];
+        {
+            const int active = act[pi];
+            const int q = active >> 3, r8 = active & 7, xcd = wg & 7, local = wg >> 3;
+            wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + local;
+        }
+        Meta m;
+        m.pi = pi, m.M = rows[pi], m.KT = g.K / GEMW_BK;
+        m.m0 = (wg / nbn) * BM, m.n0 = (wg % nbn) * BN;
+        return m;
+    };
+
+    const int t0 = next_valid(blockIdx.x);
+    __syncthreads();                          // the biases are staged
+    if (t0 >= total) return;
+    int nsteps = 0;                           // 64-k stages of this workgroup's whole stream of work items
+    for (int tt = t0; tt < total; tt = next_valid(tt + stride)) nsteps += meta_of(tt).KT;
+
+    if (wid < 8) {
+        // ---- MFMA waves ------------------------------------------------------------------------------------------------
+        const int wm = wid >> 2, wn = wid & 3;
+        const int r = lane & 31, h = lane >> 5;
+        const int sw = (r >> 1) & 7;
+        const int a_row = (wm * 64 + r) * RC, w_row = (BM + wn * 64 + r) * RC;      // + u * 32 rows; + slot of the sub-step's chunk
+        int cx[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cx[ks] = (2 * ks + h) ^ sw;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        auto write_out = [&](const Meta& m) {
+            const GemmArgs& g = batch.p[m.pi];
+            const int relu = g.relu, ldy = g.ldy, y32 = g.y_f32;
+            uint16_t* Y16 = reinterpret_cast<uint16_t*>(g.Y);
+            int bo = 0;
+#pragma unroll
+            for (int k = 1; k < GEMM_MAX_GROUP; ++k)
+                if (m.pi >= k) bo = boff[k];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = m.n0 + wn * 64 + j * 32 + r;
+                const float bias = bias_s[bo + n];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = m.m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        float v = acc[i][j][e] + bias;
+                        if (relu) v = fmaxf(v, 0.f);
+                        acc[i][j][e] = 0.f;
+                        if (row < m.M) {
+                            if (y32) g.Y[(size_t)row * ldy + n] = v;
+                            else Y16[(size_t)row * ldy + n] = (uint16_t)pack_bf16x2(v, 0.f);
+                        }
+                    }
+                }
+            }
+        };
+        int t = t0, kt = 0;
+        Meta cm = meta_of(t0);
+        bf16x8 a[4][2], b[4][2];
+        __builtin_amdgcn_s_barrier();         // B(-1): stages 0 and 1 hold the first two stages of the stream
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a[ks][u] = __builtin_bit_cast(bf16x8, lds[a_row + u * 32 * RC + cx[ks]]);
+                b[ks][u] = __builtin_bit_cast(bf16x8, lds[w_row + u * 32 * RC + cx[ks]]);
+            }
+        // interval g: the MFMAs of stage g out of registers, the fragments of stage g + 1 out of LDS stage (g + 1) % 3 (filled in
+        // interval g - 1); the loaders fill LDS stage (g + 2) % 3, last read in interval g - 2
+        for (int g = 0; g < nsteps; ++g) {
+            const u32x4* nx = lds + ((g + 1) % GEMP_STAGES) * BUF;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    a[ks][u] = __builtin_bit_cast(bf16x8, nx[a_row + u * 32 * RC + cx[ks]]);
+                    b[ks][u] = __builtin_bit_cast(bf16x8, nx[w_row + u * 32 * RC + cx[ks]]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++kt == cm.KT) {              // the work item is complete
+                write_out(cm);
+                t = next_valid(t + stride), kt = 0;
+                if (t < total) cm = meta_of(t);
+                else cm.KT = 1 << 30;
+            }
+            __builtin_amdgcn_s_barrier();     // B(g)
+        }
+        return;
+    }
+
+    // ---- loader waves: twelve 16-byte chunks per thread and stage (A: 128 rows x 8, W: 256 rows x 8), nothing else -----------------
+    const int tid = threadIdx.x - 512;
+    struct Ctx {
+        const char* a_base;
+        const char* w_base;
+        uint32_t off[12];                  // chunk i of this thread, stage 0 of the work item
+        int KT;
+    };
+    int dst[12];                           // LDS slot of chunk i (16-byte units inside a stage)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int ch = tid + i * 256, row = ch >> 3, c = ch & 7;               // rows 0-127: A, 128-383: W
+        dst[i] = row * RC + (c ^ ((row >> 1) & 7));
+    }
+    auto setup = [&](Ctx& c, int t) {
+        const Meta m = meta_of(t);
+        const GemmArgs& g = batch.p[m.pi];
+        c.KT = m.KT;
+        c.a_base = reinterpret_cast<const char*>(g.A);
+        // a 256-column tile lies inside ONE weight matrix (split_n is a multiple of 256: the launcher checks)
+        c.w_base = (g.W_hi && m.n0 >= g.split_n)
+                       ? reinterpret_cast<const char*>(g.W_hi) + (size_t)(m.n0 - g.split_n) * 2 * g.K
+                       : reinterpret_cast<const char*>(g.W) + (size_t)m.n0 * 2 * g.K;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int ch = tid + i * 256, row = ch >> 3, cc = ch & 7;
+            if (i < 4) {                       // A rows (bf16, lda elements apart); rows beyond M clamped, never predicated
+                const int gr = min(m.m0 + row, m.M - 1);
+                const int ar = g.arow ? g.arow[gr] : gr;
+                c.off[i] = (uint32_t)ar * (uint32_t)(g.lda * 2) + cc * 16;
+            } else {
+                c.off[i] = (uint32_t)(row - BM) * (uint32_t)(g.K * 2) + cc * 16;
+            }
+        }
+    };
+    struct Regs {
+        u32x4 v[12];
+    };
+    Ctx pf;
+    int pf_t = t0, pf_kt = 0;
+    bool pf_valid = true;
+    setup(pf, t0);
+    auto issue = [&](Regs& R) {               // loads of the next stage of the stream, unconditional (see gemm_split_kernel)
+        const uint32_t ks = (uint32_t)pf_kt * 128u;            // a stage: 128 bytes further in every row
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            R.v[i] = *reinterpret_cast<const u32x4*>((i < 4 ? pf.a_base : pf.w_base) + (pf.off[i] + ks));
+        if (pf_valid && ++pf_kt == pf.KT) {
+            const int tn = next_valid(pf_t + stride);
+            if (tn < total) {
+                setup(pf, tn);
+                pf_t = tn, pf_kt = 0;
+            } else {
+                pf_valid = false, pf_kt = pf.KT - 1;
+            }
+        }
+    };
+    auto fill = [&](int st, const Regs& R) {
+        u32x4* stage = lds + (st % GEMP_STAGES) * BUF;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) stage[dst[i]] = R.v[i];
+    };
+    Regs R0, R1;
+    issue(R0);                                 // stage 0
+    issue(R1);                                 // stage 1
+    fill(0, R0);
+    issue(R0);                                 // stage 2
+    fill(1, R1);
+    issue(R1);                                 // stage 3
+    wait_lds_done();
+    __builtin_amdgcn_s_barrier();              // B(-1)
+    // interval g: Ra (stage g + 2) -> LDS stage (g + 2) % 3, Ra <- stage g + 4; every wave of the workgroup runs nsteps + 1 barriers
+    auto step = [&](int g, Regs& Ra) {
+        fill(g + 2, Ra);
+        issue(Ra);
+        wait_lds_done();
+        __builtin_amdgcn_s_barrier();          // B(g)
+    };
+    for (int g = 0; g < nsteps; g += 2) {
+        step(g, R0);
+        if (g + 1 < nsteps) step(g + 1, R1);
+    }
+}
+
 // [rows][K / 16][3][16] planes -> blocks of RB rows, [rows / RB][K / 16][RB][3][16]: what a 16-k step of gemm_planes_kernel reads
 // from one operand (12 KB of 128 A rows, 24 KB of 256 W rows) is one contiguous run.  Rows beyond `rows` are written as zeros.
 __global__ __launch_bounds__(256) void planes_to_blocks_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int rows, int K, int RB) {

@@ -49,7 +49,11 @@ def random_obs(n, bs, seed):
 
 
 @pytest.mark.parametrize("M,N,K,relu,y_f32,tile", [(1000, 512, 512, 0, 0, 0), (77, 64, 64, 1, 1, 0), (4096, 256, 1152, 1, 0, 0),
-                                                   (333, 512, 128, 0, 1, 2), (1, 64, 128, 0, 0, 0), (5000, 128, 128, 1, 0, 2)])
+                                                   (333, 512, 128, 0, 1, 2), (1, 64, 128, 0, 0, 0), (5000, 128, 128, 1, 0, 2),
+                                                   # tile 3: the 128 x 256 kernel of the large launches (ragged rows, one row,
+                                                   # several work items per workgroup, two-stage and eighteen-stage streams)
+                                                   (1000, 512, 512, 1, 0, 3), (1, 256, 128, 0, 1, 3), (40000, 512, 512, 0, 0, 3),
+                                                   (129, 256, 1152, 1, 1, 3), (15473, 1024, 512, 1, 0, 3)])
 def test_gemm_bf16_matches_torch(M, N, K, relu, y_f32, tile):
     from melissa_amd import _lib
     lib = _lib.load()
