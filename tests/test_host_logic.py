@@ -434,3 +434,28 @@ def test_collect_result_has_the_reference_field_set():
     assert res["n/ep"] == 2 and res["n/st"] == 40 and res["coverage"] == 0.75 and res["len"] == 8.0 and "nope" not in res
     empty = result_from_episode_log(stats[:0], meta[:0], total=0, steps=5, dt=1.0)
     assert empty.returns_stat is None and empty.lens_stat is None and len(empty.returns) == 0 and empty.info.stats == {}
+
+
+def test_fused_relu_mlp_and_optimizer_wrapper_on_host_tensors():
+    """Host-side halves of two round-3 learn-path changes: ``networks.common.mlp`` folds a Linear + ReLU pair (and the callers'
+    trailing ``F.relu``) into one call per layer - same values as the module itself -, and ``optim.adam_step`` leaves anything its
+    kernel does not cover (here: CPU parameters) to ``torch.optim.Adam.step`` unchanged."""
+    import copy
+    import torch.nn.functional as F
+    from melissa_amd.networks.common import MLP, mlp
+    from melissa_amd.optim import adam_step
+    torch.manual_seed(1)
+    module = MLP(5, 128, [128])
+    x = torch.randn(37, 5)
+    np.testing.assert_array_equal(mlp(module, x, hip=False).detach().numpy(), module(x).detach().numpy())
+    np.testing.assert_array_equal(mlp(module, x, hip=False, final_relu=True).detach().numpy(), F.relu(module(x)).detach().numpy())
+    twin = copy.deepcopy(module)
+    a, b = torch.optim.Adam(module.parameters(), lr=1e-2), torch.optim.Adam(twin.parameters(), lr=1e-2)
+    for _ in range(3):
+        for m, o in ((module, a), (twin, b)):
+            o.zero_grad()
+            m(x).pow(2).mean().backward()
+        adam_step(a)
+        b.step()
+    for p, q in zip(module.parameters(), twin.parameters()):
+        assert torch.equal(p, q)
