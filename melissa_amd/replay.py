@@ -115,6 +115,10 @@ class RoundReplay:
     def _sample_device(self, batch_size: int, n_step: int, gamma: float, generator):
         import ctypes as C
         dev, lib = self.obs.device, _lib.load()
+        if not getattr(self, "_nonempty", False):               # (one host read, until the first record is seen)
+            if int(self.cursor.max()) < 1:
+                raise ValueError("cannot sample from an empty replay: run the collect loop first")
+            self._nonempty = True
         if not hasattr(self, "_draws"):
             self._draws = torch.zeros(1, dtype=torch.int64, device=dev)            # device-side draw counter
             self._prefix = torch.empty(self.B * self.K + 1, dtype=torch.int32, device=dev)

@@ -322,6 +322,8 @@ def test_replay_sampling_and_dqn_learner():
     venv = HipGraphVectorEnv(B, n, graph_pool=graphs, dynamic_graph=True, device="cuda", max_moves=48,
                              construct_like_reference=False)
     replay = RoundReplay(B, n, K, "cuda")
+    with pytest.raises(ValueError):
+        replay.sample(8, n_step, gamma)                       # nothing recorded yet: an error, not a batch of garbage
     loop = RoundLoop(venv, policy, episodes_per_env=10, seed=3, eps=0.3, replay=replay)
     with torch.no_grad():
         loop.run(40)
