@@ -475,6 +475,13 @@ __global__ __launch_bounds__(256, 2) void plan_enc_kernel(PlanListsArgs pa, Gemm
     else plan_lists_body<W>(pa, (int)blockIdx.x - gemm_blocks);
 }
 
+// HL-DGN's counterpart: its tuple ids (feature_ids) beside the encoder rows of the table, one launch instead of two
+__global__ __launch_bounds__(256, 2) void fid_enc_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride, int node_cols,
+                                                         PlanBuffers p, int table_rows, GemmBatch batch, int gemm_blocks) {
+    if ((int)blockIdx.x < gemm_blocks) gemm_f32_tile<2, 2, 1, 1, GEMM_MODE_ENC>(batch, (int)blockIdx.x);
+    else feature_ids_body(obs, bs, n, obs_stride, node_cols, p, table_rows, (int)blockIdx.x - gemm_blocks);
+}
+
 // ------------------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------------------
@@ -1297,6 +1304,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     if (mel_status st = resolve_projections(w, L, pw, pw_alt, s)) return st;
     const int T = n * FEATURE_TUPLES_PER_DEGREE;      // node-feature table (plan_masks.hpp): every node is a row here
     const bool table = (w->flags & MEL_FWD_INTEGER_FEATURES) && w->in_dim == 5 && M >= 2L * T;
+    bool fused_enc = false;
 
     {
         StageScope t(MEL_STAGE_PLAN, s);
@@ -1308,8 +1316,25 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
                                (const uint64_t*)nullptr, L.plan, index_col ? 0 : -1);
             if (mel_status st = check_launch("plan_masks")) return st;
         }
-        MEL_LAUNCH(feature_ids_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan,
-                   table ? T : 0);
+        // fp32 + node-feature table evaluated by this call: the tuple ids and the encoder rows of the tuples are independent
+        // (the table depends on the weights only) - one launch runs both, as plan_enc_kernel does for L-DGN
+        fused_enc = table && !bf && !sp && !(w->tables && w->tables_nodes == n);
+        if (fused_enc) {
+            GemmArgs g;
+            g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
+            g.W = pw.enc1, g.bias = w->encoder.layer[1].bias;
+            g.Y = L.h0, g.ldy = hidden, g.M = T, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
+            if (mel_status st = check_gemm_shape(g, "encoder (feature tuples)")) return st;
+            GemmBatch batch{};
+            batch.count = 1, batch.p[0] = g, batch.start[0] = 0;
+            const int tiles = ((((T + 63) / 64) * (hidden / 64)) + 7) & ~7;
+            batch.start[1] = tiles;
+            MEL_LAUNCH(fid_enc_kernel, dim3(tiles + (int)((bs + 3) / 4)), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan, T,
+                       batch, tiles);
+        } else {
+            MEL_LAUNCH(feature_ids_kernel, dim3((bs + 3) / 4), dim3(256), 0, s, obs, (int)bs, n, obs_width, node_cols, L.plan,
+                       table ? T : 0);
+        }
         if (mel_status st = check_launch("feature_ids")) return st;
     }
     {
@@ -1335,7 +1360,7 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
     FeatureTables ft{L.h0, L.xl1, nullptr};
     if (table) {
         if (w->tables && w->tables_nodes == n) ft = carve_tables(w, n, const_cast<void*>(w->tables), nullptr);
-        else if (mel_status st = run_feature_tables(w, pw, n, ft, s)) return st;
+        else if (mel_status st = run_feature_tables(w, pw, n, ft, s, /*encoder_done=*/fused_enc)) return st;
     }
     {
         AttArgs a{};

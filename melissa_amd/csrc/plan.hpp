@@ -233,9 +233,9 @@ template <int W>
 __global__ __launch_bounds__(256) void plan_lists_kernel(PlanListsArgs a) { plan_lists_body<W>(a, (int)blockIdx.x); }
 
 // HL-DGN has no row lists: the tuple ids alone (one wave per env)
-__global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
-                                                          int node_cols, PlanBuffers p, int table_rows) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void feature_ids_body(const float* __restrict__ obs, int bs, int n, int obs_stride, int node_cols,
+                                                 const PlanBuffers& p, int table_rows, const int block) {
+    const int b = block * 4 + (threadIdx.x >> 6);
     if (b >= bs) return;
     const int lane = lane_id();
     if (b == 0 && lane == 0) p.fmeta[0] = table_rows;
@@ -248,6 +248,10 @@ __global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restric
         p.fid[(size_t)b * n + node] = node_feature_id(obs + (size_t)b * obs_stride + node * node_cols + 2, n, &bad);
     const int any_bad = __ballot(bad != 0) != 0ull;
     if (lane == 0) p.fbad[b] = any_bad;
+}
+__global__ __launch_bounds__(256) void feature_ids_kernel(const float* __restrict__ obs, int bs, int n, int obs_stride,
+                                                          int node_cols, PlanBuffers p, int table_rows) {
+    feature_ids_body(obs, bs, n, obs_stride, node_cols, p, table_rows, (int)blockIdx.x);
 }
 
 }  // namespace mel
