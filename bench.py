@@ -487,8 +487,8 @@ def learner_leg(args, device, rank, world, parallel, updates=30, rounds_per_upda
     venv = HipGraphVectorEnv(envs, args.nodes, graph_pool=synthetic_graph_pool(args.nodes, 64, 0), dynamic_graph=True,
                              device=device, max_moves=48, seed=5000 + rank * envs, construct_like_reference=False)
     replay = RoundReplay(envs, args.nodes, 32, device)
-    loop = RoundLoop(venv, policy, seed=5000 + rank * envs, eps=0.1, replay=replay, ring=RING, use_graph=True,
-                     graph_rounds=rounds_per_update)        # an iteration's rounds: one graph replay
+    loop = RoundLoop(venv, policy, seed=5000 + rank * envs, eps=0.1, replay=replay, ring=RING, use_graph=world == 1,
+                     graph_rounds=rounds_per_update)        # one rank: an iteration's rounds are one graph replay
     reducer = parallel.FlatGradAllReducer(net)
     learner = DQNLearner(policy, replay, batch_size=32, n_step=4, gamma=0.99, grad_hook=reducer, seed=rank)
     with torch.no_grad():
