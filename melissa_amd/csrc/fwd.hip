@@ -927,6 +927,9 @@ static mel_status run_feature_tables(const mel_weights* w, const ProjWeights& pw
         GemmArgs g;
         g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
         g.W = pw.enc1, g.bias = w->encoder.layer[1].bias, g.bf16 = bf, g.split = sp;
+        // bf16 feature path: the table's encoder rows come from the exact-fp32 tile on the fp32 weights, stored as bf16 - the form
+        // the forward's fused launch (plan_enc_kernel / fid_enc_kernel) evaluates, so prepared and per-call tables are identical
+        if (bf) g.W = w->encoder.layer[1].weight, g.bf16 = 0, g.y_bf16 = 1;
         g.Y = t.h0, g.ldy = hidden, g.M = T, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
         StageScope sc(MEL_STAGE_ENCODER, s);
         if (mel_status st = launch_gemm(g, GEMM_MODE_ENC, s, "encoder (feature tuples)", T)) return st;
@@ -1025,12 +1028,14 @@ static mel_status ldgn_forward_impl(const mel_weights* w, const float* obs, cons
         }
         // fp32 + node-feature table: the row lists and the encoder rows of the feature tuples (which depend on the weights
         // only) are independent - ONE launch runs both (plan_enc_kernel) instead of two latency-bound ones back to back
-        fused_enc = table && !bf && !sp && !(w->tables && w->tables_nodes == n);
+        // (bf16 feature path: the same fp32 tile on the fp32 encoder weights, its rows stored as bf16 - the bf16 ENC launch of the
+        //  2 000 tuples alone took 15 us)
+        fused_enc = table && !sp && !(w->tables && w->tables_nodes == n);
         const PlanListsArgs pa{obs, (int)bs, n, obs_stride, node_cols, L.plan, row_offsets_out, tconv ? 0 : 1, inline_scan, table ? T : 0};
         if (fused_enc) {
             GemmArgs g;
             g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-            g.W = pw.enc1, g.bias = w->encoder.layer[1].bias;
+            g.W = bf ? w->encoder.layer[1].weight : pw.enc1, g.bias = w->encoder.layer[1].bias, g.y_bf16 = bf;
             g.Y = L.h0, g.ldy = hidden, g.M = T, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
             if (mel_status st = check_gemm_shape(g, "encoder (feature tuples)")) return st;
             GemmBatch batch{};
@@ -1318,11 +1323,11 @@ static mel_status hldgn_forward_impl(const mel_weights* w, int32_t aggregator, c
         }
         // fp32 + node-feature table evaluated by this call: the tuple ids and the encoder rows of the tuples are independent
         // (the table depends on the weights only) - one launch runs both, as plan_enc_kernel does for L-DGN
-        fused_enc = table && !bf && !sp && !(w->tables && w->tables_nodes == n);
+        fused_enc = table && !sp && !(w->tables && w->tables_nodes == n);
         if (fused_enc) {
             GemmArgs g;
             g.feat_domain = 1, g.in_dim = w->in_dim, g.enc_w = w->encoder.layer[0].weight, g.enc_b = w->encoder.layer[0].bias;
-            g.W = pw.enc1, g.bias = w->encoder.layer[1].bias;
+            g.W = bf ? w->encoder.layer[1].weight : pw.enc1, g.bias = w->encoder.layer[1].bias, g.y_bf16 = bf;
             g.Y = L.h0, g.ldy = hidden, g.M = T, g.N = hidden, g.K = w->encoder.layer[0].out_dim, g.relu = 1;
             if (mel_status st = check_gemm_shape(g, "encoder (feature tuples)")) return st;
             GemmBatch batch{};

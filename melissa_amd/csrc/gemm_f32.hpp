@@ -63,6 +63,9 @@ struct GemmArgs {
     // fp32 when y_f32 is set.  bias / rscale / obs / enc_* are fp32 on both paths.
     int bf16 = 0;
     int y_f32 = 0;
+    // exact-fp32 kernels only (gemm_f32_tile's epilogue): the result rows are stored as bf16 (Y: bf16 elements, ldy in elements) -
+    // the bf16 feature path's node-feature table, whose encoder rows are evaluated by the fp32 tile that rides with the plan lists
+    int y_bf16 = 0;
     // split path (gemm_split.hpp): A / Y fp32 as usual, W / W_hi point at [N][K / 16][3][16] bf16 planes (hi | mid | lo per 16 k)
     int split = 0;
     // MEL_PREC_F32_AUTO: W / W_hi are the fp32 matrices as usual and Ws / Ws_hi their bf16 planes; the launcher takes the split
@@ -170,6 +173,18 @@ __device__ __forceinline__ void store_block_f32(const GemmArgs& g, const f32x16&
     for (int e = 0; e < 16; ++e) {
         v[e] = acc[e] * o.sc[e] + o.bias;
         if (relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (g.y_bf16) {                           // round to nearest even, as v_cvt_pk_bf16_f32 does
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        uint16_t* col16 = reinterpret_cast<uint16_t*>(Y) + n;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m_lane + (e & 3) + 8 * (e >> 2);
+            const uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{v[e], 0.f}, bf16x2_t));
+            if (m < M) col16[(size_t)m * ldy] = (uint16_t)w;
+        }
+        return;
     }
     float* col = Y + n;
 #pragma unroll
